@@ -1,0 +1,263 @@
+#!/usr/bin/env python3
+"""Generate the golden fixtures under tests/golden/ by running the REFERENCE.
+
+Runs only in the build container (needs /root/reference, which never travels
+to the GPU box).  For every case it
+  * builds the reference CVAEMemRand on CPU,
+  * loads the weights produced by oracle.vsv_oracle.init_weights(seed, scale)
+    (regenerated from the seed on the GPU box, so weights are never committed),
+  * injects the noise (torch.randn_like / torch.randn patched to pop from a
+    queue of stored tensors),
+  * stores inputs, noise and the reference's outputs in one small .npz.
+
+Usage:  python oracle/make_goldens.py            (writes tests/golden/*.npz)
+"""
+from __future__ import annotations
+
+import os
+import sys
+
+import numpy as np
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, REPO)
+sys.path.insert(0, "/root/reference")
+
+import torch  # noqa: E402
+
+from oracle import vsv_oracle as vo  # noqa: E402
+from vae.cvae_with_mem_randomized import CVAEMemRand, QuantileLoss  # noqa: E402  (the reference)
+
+OUT = os.path.join(REPO, "tests", "golden")
+
+
+class NoiseQueue:
+    """Patches torch.randn / torch.randn_like to return queued tensors."""
+
+    def __init__(self):
+        self.queue = []
+        self.used = []
+
+    def push(self, arr):
+        self.queue.append(arr)
+
+    def _pop(self, shape, dtype):
+        arr = self.queue.pop(0)
+        assert tuple(arr.shape) == tuple(shape), (arr.shape, shape)
+        self.used.append(arr)
+        return torch.from_numpy(np.ascontiguousarray(arr)).to(dtype)
+
+    def __enter__(self):
+        self._randn, self._randn_like = torch.randn, torch.randn_like
+
+        def randn(*size, **kw):
+            if len(size) == 1 and isinstance(size[0], (tuple, list, torch.Size)):
+                size = tuple(size[0])
+            return self._pop(size, kw.get("dtype") or torch.get_default_dtype())
+
+        def randn_like(t, **kw):
+            return self._pop(t.shape, t.dtype)
+
+        torch.randn, torch.randn_like = randn, randn_like
+        return self
+
+    def __exit__(self, *a):
+        torch.randn, torch.randn_like = self._randn, self._randn_like
+        assert not self.queue, "unused injected noise"
+
+
+def build_reference(cfg: dict, seed: int, scale: float, np_dtype):
+    tdtype = torch.float64 if np_dtype == np.float64 else torch.float32
+    torch.set_default_dtype(tdtype)
+    model = CVAEMemRand(dict(cfg))
+    W = vo.init_weights(cfg, seed, scale, np_dtype)
+    sd = model.state_dict()
+    for k, v in W.items():
+        assert tuple(sd[k].shape) == v.shape, k
+        sd[k] = torch.from_numpy(v.copy())
+    model.load_state_dict(sd, strict=True)
+    model.eval()
+    return model, W
+
+
+def synth(rng, B, T, X, np_dtype):
+    """The reference's own synthetic test distribution
+    (experiments/diagnostics/test_multi_offset_training.py:65-66)."""
+    surf = (0.2 + 0.1 * rng.standard_normal((B, T, 5, 5))).astype(np_dtype)
+    ex = (0.01 * rng.standard_normal((B, T, X))).astype(np_dtype) if X else None
+    return surf, ex
+
+
+def t2n(t):
+    return t.detach().cpu().numpy()
+
+
+def case_forward(name, cfg, seed, scale, np_dtype, B, T, horizon):
+    """G1: model.forward with injected eps; G3: test_step losses."""
+    model, _ = build_reference(cfg, seed, scale, np_dtype)
+    rng = np.random.Generator(np.random.PCG64(1000 + seed))
+    X, L = cfg["ex_feats_dim"], cfg["latent_dim"]
+    surf, ex = synth(rng, B, T, X, np_dtype)
+    eps = rng.standard_normal((B, T, L)).astype(np_dtype)
+    x = {"surface": torch.from_numpy(surf)}
+    if X:
+        x["ex_feats"] = torch.from_numpy(ex)
+    model.horizon = horizon
+    with NoiseQueue() as nq:
+        nq.push(eps)
+        out = model.forward(x)
+    with NoiseQueue() as nq:
+        nq.push(eps)
+        losses = model.test_step(x)
+    d = dict(surface=surf, eps=eps, horizon=horizon, seed=seed, scale=scale,
+             recon=t2n(out[0]), z_mean=t2n(out[-3]), z_log_var=t2n(out[-2]), z=t2n(out[-1]))
+    if X:
+        d["ex_feats"] = ex
+        d["ex_recon"] = t2n(out[1])
+    for k, v in losses.items():
+        d["loss_" + k] = np.float64(t2n(v).reshape(-1)[0])
+    save(name, cfg, d)
+
+
+def case_prior(name, cfg, seed, scale, np_dtype, B, C, H):
+    """G2: get_surface_given_conditions(c, z=z.clone(), horizon=H)."""
+    model, _ = build_reference(cfg, seed, scale, np_dtype)
+    rng = np.random.Generator(np.random.PCG64(2000 + seed))
+    X, L = cfg["ex_feats_dim"], cfg["latent_dim"]
+    surf, ex = synth(rng, B, C, X, np_dtype)
+    z = rng.standard_normal((B, C + H, L)).astype(np_dtype)
+    c = {"surface": torch.from_numpy(surf)}
+    if X:
+        c["ex_feats"] = torch.from_numpy(ex)
+    zt = torch.from_numpy(z.copy())
+    out = model.get_surface_given_conditions(c, z=zt, horizon=H)
+    d = dict(surface=surf, z=z, horizon=H, seed=seed, scale=scale, z_after=t2n(zt))
+    if X:
+        d["ex_feats"] = ex
+        d["surf_out"], d["ex_out"] = t2n(out[0]), t2n(out[1])
+    else:
+        d["surf_out"] = t2n(out)
+    # submodule outputs (analysis scripts call these directly)
+    with NoiseQueue() as nq:
+        nq.push(np.zeros((B, C, L), dtype=np_dtype))
+        zm, zl, _ = model.encoder(c)
+    d["enc_z_mean"], d["enc_z_log_var"] = t2n(zm), t2n(zl)
+    d["ctx_embedding"] = t2n(model.ctx_encoder(c))
+    save(name, cfg, d)
+
+
+def case_ar(name, cfg, seed, scale, B, C, H):
+    """G6: generate_autoregressive_sequence, float64 default dtype (z is
+    created float64 at cvae_with_mem_randomized.py:693-694)."""
+    np_dtype = np.float64
+    model, _ = build_reference(cfg, seed, scale, np_dtype)
+    rng = np.random.Generator(np.random.PCG64(3000 + seed))
+    X, L = cfg["ex_feats_dim"], cfg["latent_dim"]
+    surf, ex = synth(rng, B, C, X, np_dtype)
+    zs = rng.standard_normal((H, B, C + 1, L))
+    c = {"surface": torch.from_numpy(surf)}
+    if X:
+        c["ex_feats"] = torch.from_numpy(ex)
+    with NoiseQueue() as nq:
+        for h in range(H):
+            nq.push(zs[h])                      # torch.randn at :693
+            nq.push(np.zeros((B, C, L)))        # encoder's own randn_like at :198 (result unused)
+        out = model.generate_autoregressive_sequence(c, horizon=H)
+    d = dict(surface=surf, z_steps=zs, horizon=H, seed=seed, scale=scale)
+    if X:
+        d["ex_feats"] = ex
+        d["surf_out"], d["ex_out"] = t2n(out[0]), t2n(out[1])
+    else:
+        d["surf_out"] = t2n(out)
+    save(name, cfg, d)
+
+
+def case_ar_offset(name, cfg, seed, scale, B, C, H, steps):
+    """G7: generate_autoregressive_offset(ar_steps, horizon=H, offset=H)."""
+    np_dtype = np.float64
+    cfg = dict(cfg, context_len=C)
+    model, _ = build_reference(cfg, seed, scale, np_dtype)
+    rng = np.random.Generator(np.random.PCG64(4000 + seed))
+    X, L = cfg["ex_feats_dim"], cfg["latent_dim"]
+    surf, ex = synth(rng, B, C, X, np_dtype)
+    zs = rng.standard_normal((steps, B, C + H, L))
+    c = {"surface": torch.from_numpy(surf)}
+    if X:
+        c["ex_feats"] = torch.from_numpy(ex)
+    with NoiseQueue() as nq:
+        for k in range(steps):
+            nq.push(zs[k])
+            nq.push(np.zeros((B, C, L)))
+        out = model.generate_autoregressive_offset(c, ar_steps=steps, horizon=H, offset=H)
+    d = dict(surface=surf, z_steps=zs, horizon=H, seed=seed, scale=scale)
+    if X:
+        d["ex_feats"] = ex
+        d["surf_out"], d["ex_out"] = t2n(out[0]), t2n(out[1])
+    else:
+        d["surf_out"] = t2n(out)
+    save(name, cfg, d)
+
+
+def case_losses():
+    """G3: QuantileLoss on small tensors incl. the reference's own KATs
+    (test_code/test_quantile_decoder.py:58-66, 70-94)."""
+    torch.set_default_dtype(torch.float32)
+    rng = np.random.Generator(np.random.PCG64(5))
+    preds = rng.standard_normal((3, 4, 3, 5, 5)).astype(np.float32)
+    target = rng.standard_normal((3, 4, 5, 5)).astype(np.float32)
+    d = dict(preds=preds, target=target)
+    for tag, w in (("w111", None), ("w515", [5.0, 1.0, 5.0])):
+        fn = QuantileLoss([0.05, 0.5, 0.95], w)
+        d["loss_" + tag] = np.float64(fn(torch.from_numpy(preds), torch.from_numpy(target)).item())
+    fn = QuantileLoss([0.05, 0.5, 0.95])
+    d["kat_equal"] = np.float64(fn(torch.ones(2, 1, 3, 5, 5), torch.ones(2, 1, 5, 5)).item())
+    yt = torch.ones(1, 1, 2, 2)
+    d["kat_under"] = np.float64(fn(torch.zeros(1, 1, 3, 2, 2), yt).item())
+    d["kat_over"] = np.float64(fn(torch.full((1, 1, 3, 2, 2), 2.0), yt).item())
+    np.savez_compressed(os.path.join(OUT, "g3_quantile_loss.npz"), **d)
+    print("wrote g3_quantile_loss")
+
+
+def save(name, cfg, d):
+    d = dict(d)
+    d["cfg_latent_dim"] = cfg["latent_dim"]
+    d["cfg_ex_feats_dim"] = cfg["ex_feats_dim"]
+    d["cfg_mem_layers"] = cfg["mem_layers"]
+    d["cfg_quantile_loss_weights"] = np.asarray(cfg.get("quantile_loss_weights") or [1.0, 1.0, 1.0])
+    path = os.path.join(OUT, name + ".npz")
+    np.savez_compressed(path, **d)
+    print("wrote", name, os.path.getsize(path) // 1024, "KiB")
+
+
+def main():
+    os.makedirs(OUT, exist_ok=True)
+    f32, f64 = np.float32, np.float64
+    no_ex = vo.make_config(5, 0)
+    ex5 = vo.make_config(5, 3)
+    ex12 = vo.make_config(12, 3, quantile_loss_weights=[5.0, 1.0, 5.0])
+    one_layer = vo.make_config(5, 0, mem_layers=1)
+
+    # G1 / G3: forward + test_step
+    case_forward("g1_fwd_noex_T6_h1_f32", no_ex, 0, 1.0, f32, 4, 6, 1)
+    case_forward("g1_fwd_noex_T21_h1_f64", no_ex, 1, 2.0, f64, 4, 21, 1)
+    case_forward("g1_fwd_ex5_T2_h1_f32", ex5, 2, 1.0, f32, 4, 2, 1)
+    case_forward("g1_fwd_ex5_T21_h1_f32", ex5, 3, 2.0, f32, 4, 21, 1)
+    case_forward("g1_fwd_ex5_T50_h7_f64", ex5, 4, 2.0, f64, 4, 50, 7)
+    case_forward("g1_fwd_ex12_T50_h30_f32", ex12, 5, 2.0, f32, 4, 50, 30)
+    case_forward("g1_fwd_ex12_T90_h30_f64", ex12, 6, 3.0, f64, 3, 90, 30)
+    case_forward("g1_fwd_1layer_T6_h1_f32", one_layer, 7, 1.0, f32, 2, 6, 1)
+    # G2: prior generation
+    case_prior("g2_prior_noex_C5_H1_f32", no_ex, 10, 1.0, f32, 8, 5, 1)
+    case_prior("g2_prior_noex_C20_H1_f64", no_ex, 11, 2.0, f64, 8, 20, 1)
+    case_prior("g2_prior_ex5_C20_H7_f32", ex5, 12, 2.0, f32, 8, 20, 7)
+    case_prior("g2_prior_ex12_C60_H30_f32", ex12, 13, 2.0, f32, 8, 60, 30)
+    case_prior("g2_prior_ex12_C60_H90_f64", ex12, 14, 3.0, f64, 4, 60, 90)
+    # G6 / G7: autoregressive
+    case_ar("g6_ar_noex_C20_H30", no_ex, 20, 2.0, 4, 20, 30)
+    case_ar("g6_ar_ex5_C20_H30", ex5, 21, 2.0, 4, 20, 30)
+    case_ar_offset("g7_aroff_ex12_C60_H60x3", ex12, 22, 2.0, 2, 60, 60, 3)
+    case_losses()
+
+
+if __name__ == "__main__":
+    main()

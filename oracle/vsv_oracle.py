@@ -1,0 +1,514 @@
+"""CPU restatement (numpy) of the reference's CVAEMemRand hot path.
+
+TEST INFRASTRUCTURE ONLY -- never imported by the product path (see
+oracle/__init__.py).  Written from the equations, not from the reference's
+code: the reference delegates all arithmetic to torch.nn ops
+(nn.Conv2d / nn.ConvTranspose2d / nn.LSTM / nn.Linear, torch>=2.9.0,
+pyproject.toml:18), so each function below restates the published algorithm of
+the op and cites the reference call site it stands for.  All citations are
+into /root/reference/.
+
+Pinning: ``oracle/make_goldens.py`` imports the reference in the build
+container, loads the weights produced by :func:`init_weights`, injects the
+noise and stores the reference's outputs under ``tests/golden/``;
+``tests/test_oracle_vs_golden.py`` checks every function here against them.
+
+Everything is dtype-generic: pass float32 or float64 arrays.
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import numpy as np
+
+Weights = Dict[str, np.ndarray]
+
+
+# --------------------------------------------------------------------------
+# configuration + deterministic weights
+# --------------------------------------------------------------------------
+
+def make_config(latent_dim=5, ex_feats_dim=0, mem_hidden=100, mem_layers=2,
+                surface_hidden=(5, 5, 5), quantiles=(0.05, 0.5, 0.95),
+                **extra) -> dict:
+    """Model config dict with the keys CVAEMemRand.check_input expects
+    (vae/cvae_with_mem_randomized.py:969-1020)."""
+    cfg = {
+        "feat_dim": (5, 5),
+        "latent_dim": latent_dim,
+        "device": "cpu",
+        "kl_weight": 1e-5,
+        "re_feat_weight": 1.0,
+        "surface_hidden": list(surface_hidden),
+        "ex_feats_dim": ex_feats_dim,
+        "ex_feats_hidden": None,
+        "mem_type": "lstm",
+        "mem_hidden": mem_hidden,
+        "mem_layers": mem_layers,
+        "mem_dropout": 0.0,
+        "ctx_surface_hidden": list(surface_hidden),
+        "ctx_ex_feats_hidden": None,
+        "interaction_layers": None,
+        "use_dense_surface": False,
+        "compress_context": True,
+        "ex_loss_on_ret_only": True,
+        "ex_feats_loss_type": "l2",
+        "quantiles": list(quantiles),
+    }
+    cfg.update(extra)
+    return cfg
+
+
+def state_dict_spec(cfg: dict) -> List[Tuple[str, Tuple[int, ...]]]:
+    """Parameter names and shapes of CVAEMemRand.state_dict() in module
+    registration order (built by
+    cvae_with_mem_randomized.py:77-110, 144-160, 230-262, 296-312, 380-450)."""
+    L = cfg["latent_dim"]
+    X = cfg["ex_feats_dim"]
+    Hm = cfg["mem_hidden"]
+    nl = cfg["mem_layers"]
+    sh = list(cfg["surface_hidden"])
+    csh = list(cfg["ctx_surface_hidden"])
+    Q = len(cfg["quantiles"])
+    E = sh[-1] * 25 + X
+    Ec = csh[-1] * 25 + X
+    Hd = sh[-1] * 25 + X
+    spec: List[Tuple[str, Tuple[int, ...]]] = []
+
+    def conv_stack(prefix, names, chans, cin):
+        for nm, co in zip(names, chans):
+            spec.append((f"{prefix}.{nm}.weight", (co, cin, 3, 3)))
+            spec.append((f"{prefix}.{nm}.bias", (co,)))
+            cin = co
+
+    def lstm(prefix, inp, hid):
+        for l in range(nl):
+            i = inp if l == 0 else hid
+            spec.append((f"{prefix}.weight_ih_l{l}", (4 * hid, i)))
+            spec.append((f"{prefix}.weight_hh_l{l}", (4 * hid, hid)))
+            spec.append((f"{prefix}.bias_ih_l{l}", (4 * hid,)))
+            spec.append((f"{prefix}.bias_hh_l{l}", (4 * hid,)))
+
+    conv_stack("encoder.surface_embedding", [f"enc_conv_{i}" for i in range(len(sh))], sh, 1)
+    lstm("encoder.mem", E, Hm)
+    spec += [("encoder.z_mean_layer.weight", (L, Hm)), ("encoder.z_mean_layer.bias", (L,)),
+             ("encoder.z_log_var_layer.weight", (L, Hm)), ("encoder.z_log_var_layer.bias", (L,))]
+    conv_stack("ctx_encoder.ctx_surface_embedding", [f"ctx_enc_conv_{i}" for i in range(len(csh))], csh, 1)
+    lstm("ctx_encoder.mem", Ec, Hm)
+    spec += [("ctx_encoder.final_compression.weight", (L, Hm)),
+             ("ctx_encoder.final_compression.bias", (L,))]
+    lstm("decoder.mem", 2 * L, Hd)
+    spec += [("decoder.surface_decoder_input.weight", (sh[-1] * 25, Hd)),
+             ("decoder.surface_decoder_input.bias", (sh[-1] * 25,))]
+    # ConvTranspose2d weights are (in, out, kH, kW)
+    cin = sh[-1]
+    for i, co in enumerate(reversed(sh[:-1])):
+        spec.append((f"decoder.surface_decoder.dec_deconv_{i}.weight", (cin, co, 3, 3)))
+        spec.append((f"decoder.surface_decoder.dec_deconv_{i}.bias", (co,)))
+        cin = co
+    spec.append(("decoder.surface_decoder.dec_final.weight", (cin, cin, 3, 3)))
+    spec.append(("decoder.surface_decoder.dec_final.bias", (cin,)))
+    spec.append(("decoder.surface_decoder.dec_output.weight", (Q, cin, 3, 3)))
+    spec.append(("decoder.surface_decoder.dec_output.bias", (Q,)))
+    if X > 0:
+        spec += [("decoder.ex_feats_decoder_input.weight", (X, Hd)),
+                 ("decoder.ex_feats_decoder_input.bias", (X,)),
+                 ("decoder.ex_feats_decoder.weight", (X, X)),
+                 ("decoder.ex_feats_decoder.bias", (X,))]
+    return spec
+
+
+def init_weights(cfg: dict, seed: int = 0, scale: float = 1.0,
+                 dtype=np.float32) -> Weights:
+    """Deterministic weights (numpy PCG64) with PyTorch-default-like ranges
+    U(-1/sqrt(fan), 1/sqrt(fan)) * scale.  The same function runs on the GPU
+    box, so only outputs -- never weights -- are committed as goldens."""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    W: Weights = {}
+    Hm = cfg["mem_hidden"]
+    for name, shape in state_dict_spec(cfg):
+        if ".mem." in name:
+            hid = shape[0] // 4
+            fan = hid
+        elif len(shape) == 4:
+            # Conv2d fan_in = Cin*9; ConvTranspose2d (in,out,k,k) fan uses dim 1
+            fan = shape[1] * 9
+        elif name.endswith(".weight"):
+            fan = shape[1]
+        else:
+            # bias: use the fan of its weight
+            wshape = dict(state_dict_spec(cfg))[name[:-4] + "weight"]
+            fan = wshape[1] * (9 if len(wshape) == 4 else 1)
+        bound = scale / math.sqrt(fan)
+        W[name] = rng.uniform(-bound, bound, size=shape).astype(dtype)
+    return W
+
+
+# --------------------------------------------------------------------------
+# primitive ops (the torch.nn ops the reference calls)
+# --------------------------------------------------------------------------
+
+def _sigmoid(x):
+    return 1.0 / (1.0 + np.exp(-x))
+
+
+def conv2d_3x3_same(x: np.ndarray, w: np.ndarray, b: np.ndarray) -> np.ndarray:
+    """nn.Conv2d(k=3, stride=1, padding=1) cross-correlation.
+    x (N,Cin,H,W), w (Cout,Cin,3,3), b (Cout).  Call sites:
+    cvae_with_mem_randomized.py:100-103, 252-255, 428-431."""
+    N, Cin, H, Wd = x.shape
+    xp = np.zeros((N, Cin, H + 2, Wd + 2), dtype=x.dtype)
+    xp[:, :, 1:-1, 1:-1] = x
+    out = np.zeros((N, w.shape[0], H, Wd), dtype=x.dtype)
+    for ky in range(3):
+        for kx in range(3):
+            patch = xp[:, :, ky:ky + H, kx:kx + Wd]          # (N,Cin,H,W)
+            out += np.einsum("nchw,oc->nohw", patch, w[:, :, ky, kx])
+    return out + b[None, :, None, None]
+
+
+def conv_transpose2d_3x3(x: np.ndarray, w: np.ndarray, b: np.ndarray) -> np.ndarray:
+    """nn.ConvTranspose2d(k=3, stride=1, padding=1, output_padding=0).
+    x (N,Cin,H,W), w (Cin,Cout,3,3).  out[y] += in[yi]*w[ky] with
+    y = yi - 1 + ky.  Call sites: cvae_with_mem_randomized.py:413-424."""
+    N, Cin, H, Wd = x.shape
+    full = np.zeros((N, w.shape[1], H + 2, Wd + 2), dtype=x.dtype)
+    for ky in range(3):
+        for kx in range(3):
+            full[:, :, ky:ky + H, kx:kx + Wd] += np.einsum(
+                "nchw,co->nohw", x, w[:, :, ky, kx])
+    return full[:, :, 1:-1, 1:-1] + b[None, :, None, None]
+
+
+def lstm_forward(x: np.ndarray, W: Weights, prefix: str, n_layers: int,
+                 state: Optional[List[Tuple[np.ndarray, np.ndarray]]] = None,
+                 return_cache: bool = False):
+    """nn.LSTM(batch_first=True), eval mode (no inter-layer dropout).
+    Gate row blocks [i; f; g; o]; c' = f*c + i*g; h' = o*tanh(c').
+    x (B,T,I) -> (B,T,H), final [(h,c)] per layer.  Call sites:
+    cvae_with_mem_randomized.py:155, 193, 307, 342, 476, 491."""
+    B, T, _ = x.shape
+    inp = x
+    finals = []
+    caches = []
+    for l in range(n_layers):
+        w_ih = W[f"{prefix}.weight_ih_l{l}"]
+        w_hh = W[f"{prefix}.weight_hh_l{l}"]
+        bias = W[f"{prefix}.bias_ih_l{l}"] + W[f"{prefix}.bias_hh_l{l}"]
+        Hh = w_hh.shape[1]
+        if state is None:
+            h = np.zeros((B, Hh), dtype=x.dtype)
+            c = np.zeros((B, Hh), dtype=x.dtype)
+        else:
+            h, c = state[l]
+            h = np.broadcast_to(h, (B, Hh)).copy()
+            c = np.broadcast_to(c, (B, Hh)).copy()
+        xproj = inp @ w_ih.T + bias                      # (B,T,4H)
+        out = np.empty((B, T, Hh), dtype=x.dtype)
+        cache = {"i": [], "f": [], "g": [], "o": [], "c": [], "h_prev": [], "c_prev": []}
+        for t in range(T):
+            gates = xproj[:, t] + h @ w_hh.T
+            i = _sigmoid(gates[:, 0 * Hh:1 * Hh])
+            f = _sigmoid(gates[:, 1 * Hh:2 * Hh])
+            g = np.tanh(gates[:, 2 * Hh:3 * Hh])
+            o = _sigmoid(gates[:, 3 * Hh:4 * Hh])
+            if return_cache:
+                cache["h_prev"].append(h)
+                cache["c_prev"].append(c)
+            c = f * c + i * g
+            h = o * np.tanh(c)
+            out[:, t] = h
+            if return_cache:
+                for k, v in (("i", i), ("f", f), ("g", g), ("o", o), ("c", c)):
+                    cache[k].append(v)
+        finals.append((h, c))
+        if return_cache:
+            cache["x"] = inp
+            caches.append(cache)
+        inp = out
+    if return_cache:
+        return inp, finals, caches
+    return inp, finals
+
+
+def linear(x, w, b):
+    return x @ w.T + b
+
+
+# --------------------------------------------------------------------------
+# the three modules
+# --------------------------------------------------------------------------
+
+def _embed(surface: np.ndarray, W: Weights, prefix: str, names: Sequence[str]) -> np.ndarray:
+    """Conv2d+ReLU stack then Flatten: (B,T,5,5) -> (B,T,C*25), index
+    ch*25+row*5+col (cvae_with_mem_randomized.py:96-110, 176-178)."""
+    B, T = surface.shape[:2]
+    x = surface.reshape(B * T, 1, 5, 5)
+    for nm in names:
+        x = np.maximum(conv2d_3x3_same(x, W[f"{prefix}.{nm}.weight"], W[f"{prefix}.{nm}.bias"]), 0)
+    return x.reshape(B, T, -1)
+
+
+def encoder_forward(W: Weights, cfg: dict, surface: np.ndarray,
+                    ex_feats: Optional[np.ndarray] = None):
+    """CVAEMemRandEncoder.forward without the sampling line
+    (cvae_with_mem_randomized.py:162-197) -> z_mean, z_log_var (B,T,L)."""
+    n = len(cfg["surface_hidden"])
+    emb = _embed(surface, W, "encoder.surface_embedding", [f"enc_conv_{i}" for i in range(n)])
+    if ex_feats is not None:
+        emb = np.concatenate([emb, ex_feats], axis=-1)          # :188
+    h, _ = lstm_forward(emb, W, "encoder.mem", cfg["mem_layers"])
+    zm = linear(h, W["encoder.z_mean_layer.weight"], W["encoder.z_mean_layer.bias"])
+    zl = linear(h, W["encoder.z_log_var_layer.weight"], W["encoder.z_log_var_layer.bias"])
+    return zm, zl
+
+
+def ctx_encoder_forward(W: Weights, cfg: dict, surface: np.ndarray,
+                        ex_feats: Optional[np.ndarray] = None) -> np.ndarray:
+    """CVAECtxMemRandEncoder.forward (cvae_with_mem_randomized.py:314-344),
+    compress_context=True -> (B,C,L)."""
+    n = len(cfg["ctx_surface_hidden"])
+    emb = _embed(surface, W, "ctx_encoder.ctx_surface_embedding",
+                 [f"ctx_enc_conv_{i}" for i in range(n)])
+    if ex_feats is not None:
+        emb = np.concatenate([emb, ex_feats], axis=-1)
+    h, _ = lstm_forward(emb, W, "ctx_encoder.mem", cfg["mem_layers"])
+    return linear(h, W["ctx_encoder.final_compression.weight"],
+                  W["ctx_encoder.final_compression.bias"])
+
+
+def decoder_head(W: Weights, cfg: dict, h: np.ndarray):
+    """Everything after the decoder LSTM (cvae_with_mem_randomized.py:494-514):
+    Linear -> reshape (.,5,5,5) -> ConvT+ReLU x3 -> Conv -> (B,T,Q,5,5)
+    and, if X>0, Linear -> Linear -> (B,T,X)."""
+    B, T = h.shape[:2]
+    sh = cfg["surface_hidden"]
+    Q = len(cfg["quantiles"])
+    s = linear(h, W["decoder.surface_decoder_input.weight"], W["decoder.surface_decoder_input.bias"])
+    s = s.reshape(B * T, sh[-1], 5, 5)
+    for i in range(len(sh) - 1):
+        p = f"decoder.surface_decoder.dec_deconv_{i}"
+        s = np.maximum(conv_transpose2d_3x3(s, W[p + ".weight"], W[p + ".bias"]), 0)
+    p = "decoder.surface_decoder.dec_final"
+    s = np.maximum(conv_transpose2d_3x3(s, W[p + ".weight"], W[p + ".bias"]), 0)
+    p = "decoder.surface_decoder.dec_output"
+    s = conv2d_3x3_same(s, W[p + ".weight"], W[p + ".bias"]).reshape(B, T, Q, 5, 5)
+    if cfg["ex_feats_dim"] > 0:
+        e = linear(h, W["decoder.ex_feats_decoder_input.weight"], W["decoder.ex_feats_decoder_input.bias"])
+        e = linear(e, W["decoder.ex_feats_decoder.weight"], W["decoder.ex_feats_decoder.bias"])
+        return s, e
+    return s, None
+
+
+def decoder_forward(W: Weights, cfg: dict, dec_in: np.ndarray, state=None):
+    """CVAEMemRandDecoder.forward (cvae_with_mem_randomized.py:482-514)."""
+    h, finals = lstm_forward(dec_in, W, "decoder.mem", cfg["mem_layers"], state)
+    s, e = decoder_head(W, cfg, h)
+    return s, e, finals
+
+
+# --------------------------------------------------------------------------
+# model-level paths
+# --------------------------------------------------------------------------
+
+def forward(W: Weights, cfg: dict, surface: np.ndarray, ex_feats: Optional[np.ndarray],
+            eps: np.ndarray, horizon: int):
+    """CVAEMemRand.forward (cvae_with_mem_randomized.py:1022-1074) with the
+    randn_like of :198 replaced by the injected ``eps`` (B,T,L).
+    Returns recon (B,H,Q,5,5), ex (B,H,X)|None, z_mean, z_log_var, z."""
+    B, T = surface.shape[:2]
+    C = T - horizon
+    if C < 1:
+        raise ValueError("Insufficient sequence length")             # :1043
+    L = cfg["latent_dim"]
+    ctx = ctx_encoder_forward(W, cfg, surface[:, :C], None if ex_feats is None else ex_feats[:, :C])
+    ctx_pad = np.zeros((B, T, L), dtype=surface.dtype)               # :1061-1062
+    ctx_pad[:, :C] = ctx
+    zm, zl = encoder_forward(W, cfg, surface, ex_feats)
+    z = zm + np.exp(0.5 * zl) * eps                                   # :199
+    s, e, _ = decoder_forward(W, cfg, np.concatenate([ctx_pad, z], axis=-1))   # :1066
+    return s[:, C:], (None if e is None else e[:, C:]), zm, zl, z
+
+
+def get_surface_given_conditions(W: Weights, cfg: dict, ctx_surface: np.ndarray,
+                                 ctx_ex: Optional[np.ndarray], z: np.ndarray, horizon: int):
+    """CVAEMemRand.get_surface_given_conditions, literal shape
+    (cvae_with_mem_randomized.py:642-715): z (B,T,L) is MODIFIED IN PLACE
+    (z[:, :C] = encoder z_mean, :700); decodes all T steps, returns [C:]."""
+    B, C = ctx_surface.shape[:2]
+    T = C + horizon
+    L = cfg["latent_dim"]
+    zm, _ = encoder_forward(W, cfg, ctx_surface, ctx_ex)
+    z[:, :C] = zm
+    ctx = ctx_encoder_forward(W, cfg, ctx_surface, ctx_ex)
+    ctx_pad = np.zeros((B, T, L), dtype=ctx_surface.dtype)
+    ctx_pad[:, :C] = ctx
+    s, e, _ = decoder_forward(W, cfg, np.concatenate([ctx_pad, z.astype(ctx_surface.dtype)], axis=-1))
+    return s[:, C:], (None if e is None else e[:, C:])
+
+
+def prior_mc_shared_prefix(W: Weights, cfg: dict, ctx_surface: np.ndarray,
+                           ctx_ex: Optional[np.ndarray], z_future: np.ndarray):
+    """Same result as get_surface_given_conditions called with the context
+    repeated S times, restructured the way the HIP path evaluates it: the
+    decoder state after the C context steps depends only on the day, so it is
+    computed once per day and broadcast to the S samples.
+    ctx_surface (D,C,5,5); z_future (D,S,H,L) -> (D,S,H,Q,5,5)[, (D,S,H,X)]."""
+    D, C = ctx_surface.shape[:2]
+    _, S, H, L = z_future.shape
+    zm, _ = encoder_forward(W, cfg, ctx_surface, ctx_ex)
+    ctx = ctx_encoder_forward(W, cfg, ctx_surface, ctx_ex)
+    _, finals = lstm_forward(np.concatenate([ctx, zm], axis=-1), W, "decoder.mem", cfg["mem_layers"])
+    state = [(np.repeat(h, S, axis=0), np.repeat(c, S, axis=0)) for h, c in finals]
+    dec_in = np.concatenate([np.zeros((D * S, H, L), dtype=ctx_surface.dtype),
+                             z_future.reshape(D * S, H, L).astype(ctx_surface.dtype)], axis=-1)
+    s, e, _ = decoder_forward(W, cfg, dec_in, state)
+    s = s.reshape(D, S, H, -1, 5, 5)
+    return s, (None if e is None else e.reshape(D, S, H, -1))
+
+
+def generate_autoregressive_sequence(W: Weights, cfg: dict, ctx_surface: np.ndarray,
+                                     ctx_ex: Optional[np.ndarray], z_steps: np.ndarray):
+    """CVAEMemRand.generate_autoregressive_sequence
+    (cvae_with_mem_randomized.py:717-807, _update_context :925-967).
+    z_steps (H,B,C+1,L): the randn drawn at :693 in each of the H one-day
+    calls (positions [:C] are overwritten by the posterior mean)."""
+    surf_ctx = ctx_surface.copy()
+    ex_ctx = None if ctx_ex is None else ctx_ex.copy()
+    outs, exs = [], []
+    for step in range(z_steps.shape[0]):
+        s, e = get_surface_given_conditions(W, cfg, surf_ctx, ex_ctx, z_steps[step].copy(), 1)
+        outs.append(s)
+        new_surface = s[:, 0, 1]                                     # p50 channel, :786/:794
+        surf_ctx = np.concatenate([surf_ctx[:, 1:], new_surface[:, None]], axis=1)
+        if e is not None:
+            exs.append(e)
+            ex_ctx = np.concatenate([ex_ctx[:, 1:], e[:, 0][:, None]], axis=1)
+    return np.concatenate(outs, axis=1), (np.concatenate(exs, axis=1) if exs else None)
+
+
+def generate_autoregressive_offset(W: Weights, cfg: dict, ctx_surface: np.ndarray,
+                                   ctx_ex: Optional[np.ndarray], z_steps: Sequence[np.ndarray],
+                                   horizon: int):
+    """CVAEMemRand.generate_autoregressive_offset
+    (cvae_with_mem_randomized.py:809-923): len(z_steps) chunks of ``horizon``
+    days; next context = last C of the concatenated p50 medians (:907-914)."""
+    C = ctx_surface.shape[1]
+    surf_ctx, ex_ctx = ctx_surface, ctx_ex
+    all_s, all_e, med_s, med_e = [], [], [], []
+    for k, z in enumerate(z_steps):
+        s, e = get_surface_given_conditions(W, cfg, surf_ctx, ex_ctx, z.copy(), horizon)
+        all_s.append(s)
+        med_s.append(s[:, :, 1])
+        if e is not None:
+            all_e.append(e)
+            med_e.append(e)
+        if k < len(z_steps) - 1:
+            surf_ctx = np.concatenate(med_s, axis=1)[:, -C:]
+            if e is not None:
+                ex_ctx = np.concatenate(med_e, axis=1)[:, -C:]
+    return np.concatenate(all_s, axis=1), (np.concatenate(all_e, axis=1) if all_e else None)
+
+
+# --------------------------------------------------------------------------
+# losses (always float64 scalars, like the reference: QuantileLoss buffers are
+# float64, cvae_with_mem_randomized.py:23-26)
+# --------------------------------------------------------------------------
+
+def quantile_loss(preds: np.ndarray, target: np.ndarray, quantiles, weights=None) -> float:
+    """QuantileLoss.forward (cvae_with_mem_randomized.py:28-45)."""
+    q = np.asarray(quantiles, dtype=np.float64)
+    w = np.ones_like(q) if weights is None else np.asarray(weights, dtype=np.float64)
+    losses = []
+    for i in range(len(q)):
+        err = (target - preds[:, :, i]).astype(np.float64)
+        losses.append(np.mean(np.maximum((q[i] - 1) * err, q[i] * err)))
+    return float(np.sum(np.asarray(losses) * w) / np.sum(w))
+
+
+def kl_loss(z_mean: np.ndarray, z_log_var: np.ndarray) -> float:
+    """cvae_with_mem_randomized.py:1123-1124: mean over (B,T) of the sum over L."""
+    k = -0.5 * (1 + z_log_var - np.exp(z_log_var) - np.square(z_mean))
+    return float(np.mean(np.sum(k, axis=-1)))
+
+
+def ex_feats_loss(pred: np.ndarray, real: np.ndarray, cfg: dict) -> float:
+    """cvae_with_mem_randomized.py:1115-1118 (MSE if 'l2' else L1, :564-567)."""
+    if cfg.get("ex_loss_on_ret_only", False):
+        pred, real = pred[:, :, :1], real[:, :, :1]
+    d = pred - real
+    return float(np.mean(d * d) if cfg.get("ex_feats_loss_type", "l1") == "l2" else np.mean(np.abs(d)))
+
+
+def test_step(W: Weights, cfg: dict, surface, ex_feats, eps, horizon) -> Dict[str, float]:
+    """CVAEMemRand.test_step (cvae_with_mem_randomized.py:1265-1308)."""
+    s, e, zm, zl, _ = forward(W, cfg, surface, ex_feats, eps, horizon)
+    C = surface.shape[1] - horizon
+    re_s = quantile_loss(s, surface[:, C:], cfg["quantiles"], cfg.get("quantile_loss_weights"))
+    re_e = 0.0
+    recon = re_s
+    if ex_feats is not None:
+        re_e = ex_feats_loss(e, ex_feats[:, C:], cfg)
+        recon = re_s + cfg.get("re_feat_weight", 1.0) * re_e
+    kl = kl_loss(zm, zl)
+    return {"loss": recon + cfg["kl_weight"] * kl, "re_surface": re_s, "re_ex_feats": re_e,
+            "reconstruction_loss": recon, "kl_loss": kl}
+
+
+test_step.__test__ = False   # not a pytest test
+
+
+# --------------------------------------------------------------------------
+# MC reduction + counter-based noise
+# --------------------------------------------------------------------------
+
+def percentile(samples: np.ndarray, qs=(5, 50, 95), axis: int = 1) -> np.ndarray:
+    """np.percentile(..., method='linear') -- the MC->quantile convention of
+    experiments/bootstrap_baseline/generate_bootstrap_autoregressive.py:194-199."""
+    return np.percentile(samples, list(qs), axis=axis)
+
+
+_PHILOX_M0 = np.uint64(0xD2511F53)
+_PHILOX_M1 = np.uint64(0xCD9E8D57)
+_PHILOX_W0 = 0x9E3779B9
+_PHILOX_W1 = 0xBB67AE85
+_MASK32 = np.uint64(0xFFFFFFFF)
+
+
+def philox4x32_10(c0, c1, c2, c3, k0: int, k1: int):
+    """Philox4x32-10 (Salmon et al., SC'11).  Counter words are uint32 arrays
+    (broadcastable); returns four uint32 arrays."""
+    c0, c1, c2, c3 = (np.asarray(c, dtype=np.uint64) & _MASK32 for c in (c0, c1, c2, c3))
+    c0, c1, c2, c3 = np.broadcast_arrays(c0, c1, c2, c3)
+    for r in range(10):
+        p0 = _PHILOX_M0 * c0
+        p1 = _PHILOX_M1 * c2
+        hi0, lo0 = p0 >> np.uint64(32), p0 & _MASK32
+        hi1, lo1 = p1 >> np.uint64(32), p1 & _MASK32
+        kk0 = np.uint64((k0 + r * _PHILOX_W0) & 0xFFFFFFFF)
+        kk1 = np.uint64((k1 + r * _PHILOX_W1) & 0xFFFFFFFF)
+        c0, c1, c2, c3 = (hi1 ^ c1 ^ kk0), lo1, (hi0 ^ c3 ^ kk1), lo0
+    return tuple(c.astype(np.uint32) for c in (c0, c1, c2, c3))
+
+
+def philox_normal(seed: int, day0: int, n_days: int, n_samples: int, step0: int,
+                  n_steps: int, latent_dim: int) -> np.ndarray:
+    """The noise the HIP path draws in on-device RNG mode: element
+    (day, sample, step, f) = BoxMuller(Philox(ctr=(sample, day, step, f>>2),
+    key=seed))[f&3], float32.  Sharding-invariant by construction."""
+    nb = (latent_dim + 3) // 4
+    day = (day0 + np.arange(n_days, dtype=np.uint64))[:, None, None, None]
+    smp = np.arange(n_samples, dtype=np.uint64)[None, :, None, None]
+    stp = (step0 + np.arange(n_steps, dtype=np.uint64))[None, None, :, None]
+    blk = np.arange(nb, dtype=np.uint64)[None, None, None, :]
+    x = philox4x32_10(smp, day, stp, blk, seed & 0xFFFFFFFF, (seed >> 32) & 0xFFFFFFFF)
+    u = [((xi >> np.uint32(8)).astype(np.float32) + np.float32(0.5)) * np.float32(2.0 ** -24) for xi in x]
+    out = np.empty(u[0].shape + (4,), dtype=np.float32)
+    two_pi = np.float32(6.283185307179586)
+    for p in range(2):
+        r = np.sqrt(np.float32(-2.0) * np.log(u[2 * p]))
+        th = two_pi * u[2 * p + 1]
+        out[..., 2 * p] = r * np.cos(th)
+        out[..., 2 * p + 1] = r * np.sin(th)
+    return out.reshape(n_days, n_samples, n_steps, nb * 4)[..., :latent_dim]

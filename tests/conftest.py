@@ -1,0 +1,36 @@
+import os
+import sys
+
+import numpy as np
+import pytest
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+PKG = os.path.join(REPO, "vol-surface-vae-pub_amd")
+for p in (REPO, PKG):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+GOLDEN = os.path.join(REPO, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+def load_golden(name):
+    return dict(np.load(os.path.join(GOLDEN, name + ".npz")))
+
+
+def golden_names(prefix):
+    return sorted(f[:-4] for f in os.listdir(GOLDEN) if f.startswith(prefix) and f.endswith(".npz"))
+
+
+def cfg_of(g):
+    """Rebuild the model config a golden was generated with."""
+    from oracle import vsv_oracle as vo
+    cfg = vo.make_config(int(g["cfg_latent_dim"]), int(g["cfg_ex_feats_dim"]),
+                         mem_layers=int(g["cfg_mem_layers"]))
+    w = [float(x) for x in g["cfg_quantile_loss_weights"]]
+    if w != [1.0, 1.0, 1.0]:
+        cfg["quantile_loss_weights"] = w
+    return cfg

@@ -1,0 +1,121 @@
+"""Pins the CPU oracle (oracle/vsv_oracle.py) against outputs of the
+reference itself (tests/golden/*.npz, made by oracle/make_goldens.py with the
+reference imported in the build container).  CPU only."""
+import numpy as np
+import pytest
+
+from conftest import cfg_of, golden_names, load_golden
+from oracle import vsv_oracle as vo
+
+
+def tol(dtype):
+    # float64 goldens: the oracle evaluates the same equations in another
+    # order; float32 goldens carry the reference's own float32 rounding.
+    return 1e-9 if dtype == np.float64 else 2e-5
+
+
+@pytest.mark.parametrize("name", golden_names("g1_"))
+def test_forward_and_losses(name):
+    g = load_golden(name)
+    cfg = cfg_of(g)
+    dt = g["surface"].dtype
+    W = vo.init_weights(cfg, int(g["seed"]), float(g["scale"]), dt)
+    ex = g.get("ex_feats")
+    H = int(g["horizon"])
+    s, e, zm, zl, z = vo.forward(W, cfg, g["surface"], ex, g["eps"], H)
+    assert s.shape == g["recon"].shape
+    for got, want in ((s, g["recon"]), (zm, g["z_mean"]), (zl, g["z_log_var"]), (z, g["z"])):
+        assert np.max(np.abs(got - want)) <= tol(dt)
+    if ex is not None:
+        assert np.max(np.abs(e - g["ex_recon"])) <= tol(dt)
+    losses = vo.test_step(W, cfg, g["surface"], ex, g["eps"], H)
+    for k, v in losses.items():
+        want = float(g["loss_" + k])
+        assert abs(v - want) <= 1e-3 * abs(want) + 1e-12, (k, v, want)
+
+
+@pytest.mark.parametrize("name", golden_names("g2_"))
+def test_prior_generation(name):
+    g = load_golden(name)
+    cfg = cfg_of(g)
+    dt = g["surface"].dtype
+    W = vo.init_weights(cfg, int(g["seed"]), float(g["scale"]), dt)
+    ex = g.get("ex_feats")
+    H = int(g["horizon"])
+    z = g["z"].copy()
+    s, e = vo.get_surface_given_conditions(W, cfg, g["surface"], ex, z, H)
+    assert np.max(np.abs(s - g["surf_out"])) <= tol(dt)
+    assert np.max(np.abs(z - g["z_after"])) <= tol(dt)          # in-place overwrite (:700)
+    if ex is not None:
+        assert np.max(np.abs(e - g["ex_out"])) <= tol(dt)
+    zm, zl = vo.encoder_forward(W, cfg, g["surface"], ex)
+    assert np.max(np.abs(zm - g["enc_z_mean"])) <= tol(dt)
+    assert np.max(np.abs(zl - g["enc_z_log_var"])) <= tol(dt)
+    ctx = vo.ctx_encoder_forward(W, cfg, g["surface"], ex)
+    assert np.max(np.abs(ctx - g["ctx_embedding"])) <= tol(dt)
+    # the shared-prefix restructuring the HIP path uses gives the same values
+    C = g["surface"].shape[1]
+    s2, e2 = vo.prior_mc_shared_prefix(W, cfg, g["surface"], ex, g["z"][:, None, C:])
+    assert np.max(np.abs(s2[:, 0] - g["surf_out"])) <= tol(dt)
+    if ex is not None:
+        assert np.max(np.abs(e2[:, 0] - g["ex_out"])) <= tol(dt)
+
+
+@pytest.mark.parametrize("name", golden_names("g6_"))
+def test_autoregressive(name):
+    g = load_golden(name)
+    cfg = cfg_of(g)
+    W = vo.init_weights(cfg, int(g["seed"]), float(g["scale"]), np.float64)
+    s, e = vo.generate_autoregressive_sequence(W, cfg, g["surface"], g.get("ex_feats"), g["z_steps"])
+    assert s.shape == g["surf_out"].shape
+    assert np.max(np.abs(s - g["surf_out"])) <= 1e-9
+    if e is not None:
+        assert np.max(np.abs(e - g["ex_out"])) <= 1e-9
+
+
+@pytest.mark.parametrize("name", golden_names("g7_"))
+def test_autoregressive_offset(name):
+    g = load_golden(name)
+    cfg = cfg_of(g)
+    W = vo.init_weights(cfg, int(g["seed"]), float(g["scale"]), np.float64)
+    s, e = vo.generate_autoregressive_offset(W, cfg, g["surface"], g.get("ex_feats"),
+                                             list(g["z_steps"]), int(g["horizon"]))
+    assert s.shape == g["surf_out"].shape
+    assert np.max(np.abs(s - g["surf_out"])) <= 1e-9
+    if e is not None:
+        assert np.max(np.abs(e - g["ex_out"])) <= 1e-9
+
+
+def test_quantile_loss_kats():
+    g = load_golden("g3_quantile_loss")
+    q = [0.05, 0.5, 0.95]
+    assert abs(vo.quantile_loss(g["preds"], g["target"], q) - float(g["loss_w111"])) < 1e-7
+    assert abs(vo.quantile_loss(g["preds"], g["target"], q, [5, 1, 5]) - float(g["loss_w515"])) < 1e-7
+    # the reference's own known-answer cases (test_code/test_quantile_decoder.py:58-94)
+    assert vo.quantile_loss(np.ones((2, 1, 3, 5, 5)), np.ones((2, 1, 5, 5)), q) == 0.0
+    yt = np.ones((1, 1, 2, 2))
+    assert abs(vo.quantile_loss(np.zeros((1, 1, 3, 2, 2)), yt, q) - 0.5) < 1e-12
+    assert abs(vo.quantile_loss(np.full((1, 1, 3, 2, 2), 2.0), yt, q) - 0.5) < 1e-12
+    assert abs(float(g["kat_under"]) - 0.5) < 1e-6 and abs(float(g["kat_over"]) - 0.5) < 1e-6
+    assert float(g["kat_equal"]) == 0.0
+
+
+def test_philox_known_answers():
+    # Random123 kat_vectors for philox4x32-10
+    out = vo.philox4x32_10(0, 0, 0, 0, 0, 0)
+    assert [int(x) for x in out] == [0x6627e8d5, 0xe169c58d, 0xbc57ac4c, 0x9b00dbd8]
+    f = 0xFFFFFFFF
+    out = vo.philox4x32_10(f, f, f, f, f, f)
+    assert [int(x) for x in out] == [0x408f276d, 0x41c83b0e, 0xa20bc7c6, 0x6d5451fd]
+    out = vo.philox4x32_10(0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344, 0xa4093822, 0x299f31d0)
+    assert [int(x) for x in out] == [0xd16cfe09, 0x94fdcceb, 0x5001e420, 0x24126ea1]
+
+
+def test_philox_normal_is_standard_normal():
+    from scipy import stats
+    z = vo.philox_normal(7, 3, 16, 500, 0, 4, 5)
+    assert z.shape == (16, 500, 4, 5) and z.dtype == np.float32
+    assert stats.kstest(z.ravel().astype(np.float64), "norm").pvalue > 1e-3
+    # sharding invariance: a sub-range of days gives the same numbers
+    z2 = vo.philox_normal(7, 5, 4, 500, 0, 4, 5)
+    assert np.array_equal(z2, z[2:6])

@@ -1,0 +1,164 @@
+/*
+ * vsv_hip.h -- C ABI of libvsv_hip.so: the CVAEMemRand hot path on MI355X (gfx950).
+ *
+ * The reference (0xC000005/vol-surface-vae-pub) is pure PyTorch and has no FFI:
+ * its "operator boundary" for this path is the Python class
+ * vae/cvae_with_mem_randomized.py:CVAEMemRand and the torch.nn ops it calls.
+ * Each entry point below therefore cites the reference Python call site whose
+ * arithmetic it replaces.  All citations are file:line into the reference.
+ *
+ * Conventions
+ *   - plain pointers and sizes only; no torch types; every data pointer is a
+ *     DEVICE pointer to float32 unless the name ends in _host;
+ *   - `stream` is a hipStream_t passed as void*;
+ *   - return value: 0 ok, <0 argument error (vsv_last_error() has the text),
+ *     >0 a hipError_t from a launch;
+ *   - nothing here allocates or frees device memory, synchronises the device
+ *     or keeps global state; scratch space comes in through `ws` (size from the
+ *     matching *_ws_bytes query); calls on different streams do not interact;
+ *   - rows are independent sequences (a training sample, a day's context window,
+ *     or one (day, MC sample) pair).
+ */
+#ifndef VSV_HIP_H
+#define VSV_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define VSV_ABI_VERSION 1
+#define VSV_MAX_CONV 4
+
+/* Model shape: the subset of the reference's config dict that fixes tensor
+ * shapes (cvae_with_mem_randomized.py:969-1020; state_dict layout SURVEY.md
+ * appendix A).  Only the production topology is implemented: conv surface
+ * embedding on a 5x5 grid, LSTM memory, compress_context=True,
+ * interaction_layers=None, ex_feats_hidden=None. */
+typedef struct vsv_dims {
+    int latent_dim;                    /* L: config["latent_dim"]            */
+    int ex_feats_dim;                  /* X: config["ex_feats_dim"] (0 or >0) */
+    int mem_hidden;                    /* config["mem_hidden"]               */
+    int mem_layers;                    /* config["mem_layers"]: 1 or 2       */
+    int n_conv;                        /* len(config["surface_hidden"])      */
+    int surface_hidden[VSV_MAX_CONV];  /* conv channels, encoder + decoder   */
+    int n_ctx_conv;                    /* len(config["ctx_surface_hidden"])  */
+    int ctx_surface_hidden[VSV_MAX_CONV];
+    int n_quantiles;                   /* Q = len(config["quantiles"])       */
+} vsv_dims;
+
+/* Raw parameters in PyTorch state_dict layout (HOST pointers, float32,
+ * contiguous).  Names follow SURVEY.md appendix A. */
+typedef struct vsv_lstm_raw {
+    const float *w_ih[2], *w_hh[2], *b_ih[2], *b_hh[2];   /* per layer */
+} vsv_lstm_raw;
+
+typedef struct vsv_raw_weights {
+    /* encoder.* */
+    const float *enc_conv_w[VSV_MAX_CONV], *enc_conv_b[VSV_MAX_CONV];
+    vsv_lstm_raw enc_mem;
+    const float *z_mean_w, *z_mean_b, *z_log_var_w, *z_log_var_b;
+    /* ctx_encoder.* */
+    const float *ctx_conv_w[VSV_MAX_CONV], *ctx_conv_b[VSV_MAX_CONV];
+    vsv_lstm_raw ctx_mem;
+    const float *ctx_comp_w, *ctx_comp_b;                 /* final_compression */
+    /* decoder.* */
+    vsv_lstm_raw dec_mem;
+    const float *dec_in_w, *dec_in_b;                     /* surface_decoder_input */
+    const float *dec_deconv_w[VSV_MAX_CONV], *dec_deconv_b[VSV_MAX_CONV]; /* dec_deconv_i..., dec_final last */
+    const float *dec_out_w, *dec_out_b;                   /* dec_output (Conv2d) */
+    const float *ex_in_w, *ex_in_b, *ex_out_w, *ex_out_b; /* ex_feats_decoder_input / ex_feats_decoder (X>0) */
+} vsv_raw_weights;
+
+int vsv_abi_version(void);
+/* Text of the last argument error raised on the calling thread. */
+const char *vsv_last_error(void);
+
+/* ---- weights -------------------------------------------------------------
+ * The kernels read weights in an MFMA-fragment order (one 1 KiB block per
+ * (4 k-steps x 16 output rows) tile of v_mfma_f32_16x16x4_f32; conv layers are
+ * expanded to their dense 5x5 Toeplitz matrices).  vsv_pack_weights converts a
+ * state_dict once on the host; the caller uploads the blob and passes its device
+ * address as `packed` to every compute call.  Replaces: nn.Module parameter
+ * storage read by nn.Conv2d/nn.ConvTranspose2d/nn.LSTM/nn.Linear at
+ * cvae_with_mem_randomized.py:100,155,196-197,252,307,343,383,413,421,428,476. */
+size_t vsv_packed_floats(const vsv_dims *dims);
+int vsv_pack_weights(const vsv_dims *dims, const vsv_raw_weights *raw, float *packed_host);
+
+/* ---- encoders --------------------------------------------------------------
+ * which = 0: CVAEMemRandEncoder.forward (cvae_with_mem_randomized.py:162-197):
+ *            conv embedding + LSTM + z_mean / z_log_var heads;
+ *            out is (n_rows, T, 2L): [..., :L] = z_mean, [..., L:] = z_log_var.
+ * which = 1: CVAECtxMemRandEncoder.forward (:314-344): out is (n_rows, T, L).
+ * surface element (row, t, p) is surf[row*surf_row_stride + t*surf_t_stride + p],
+ * p < 25 -- so overlapping day windows of one calendar array can be encoded in
+ * place (row stride 25, t stride 25).  ex may be NULL when X == 0. */
+size_t vsv_encode_ws_bytes(const vsv_dims *dims, long n_rows, int T);
+int vsv_encode(const vsv_dims *dims, const float *packed, int which,
+               const float *surf, long surf_row_stride, long surf_t_stride,
+               const float *ex, long ex_row_stride, long ex_t_stride,
+               long n_rows, int T, float *out,
+               void *ws, size_t ws_bytes, void *stream);
+
+/* ---- decoder ---------------------------------------------------------------
+ * CVAEMemRandDecoder.forward (cvae_with_mem_randomized.py:482-514) over T steps
+ * for n_rows independent rows, with the LSTM input assembled on the fly
+ * (the torch.cat at :707 / :1066) from:
+ *   ctx part  f <  L: ctx[(row/ctx_div)*ctx_rs + t*L + f]        for t < ctx_T, else 0
+ *                     (the zero padding of :704-705 / :1061-1062);
+ *   z   part  f >= L: base + scale * eps, where for t < z_T
+ *                       base  = zb[(row/z_div)*z_rs + t*L + f]
+ *                       scale = lv ? exp(0.5*lv[same index]) : 0   (reparameterisation, :199)
+ *                     and for t >= z_T   base = mu0, scale = std0 (prior N(mu,std), :693-694);
+ *                     eps = eps_in[(row*eps_T + (t-eps_t0))*L + f] when eps_in != NULL,
+ *                     otherwise Philox4x32-10 + Box-Muller keyed by
+ *                     (seed; sample = row % S, day = day0 + row / S, step = step0 + t - eps_t0, f).
+ * The LSTM starts from state_in[(row/state_div)] (layout (n, layers, 2, HP) with
+ * HP = vsv_state_floats(dims)/(2*layers): h then c, unit-major) or from zero when NULL,
+ * and writes its final state to state_out (same layout, one per row) when not NULL.
+ * For steps t >= t_out0 the head (Linear -> ConvT+ReLU x3 -> Conv [, ex Linear x2],
+ * :494-510) is evaluated and written to
+ *   out_mode 0: surf_out (n_rows, T-t_out0, Q, 5, 5), the reference layout;
+ *   out_mode 1: surf_out (n_rows/S, T-t_out0, Q*25, S), MC-sample-minor, the layout
+ *               vsv_percentile reads (requires n_rows % S == 0);
+ * and ex_out (n_rows, T-t_out0, X) when X > 0 and ex_out != NULL.
+ * z_out, when not NULL, receives the z part that was fed in: (n_rows, T, L).
+ * Pass t_out0 = T to run the LSTM only (context prefix: state_out is the product). */
+typedef struct vsv_decode_in {
+    const float *ctx;   long ctx_rs;  int ctx_T;  long ctx_div;
+    const float *zb;    const float *lv;  long z_rs;  int z_T;  long z_div;
+    float mu0, std0;
+    const float *eps_in; int eps_T; int eps_t0;
+    uint64_t seed; long S; long day0; int step0;
+    const float *state_in; long state_div;
+} vsv_decode_in;
+
+size_t vsv_state_floats(const vsv_dims *dims);   /* floats of decoder LSTM state per row */
+size_t vsv_decode_ws_bytes(const vsv_dims *dims, long n_rows, int T, int t_out0);
+int vsv_decode(const vsv_dims *dims, const float *packed, const vsv_decode_in *in,
+               long n_rows, int T, int t_out0,
+               float *state_out, float *z_out,
+               float *surf_out, int out_mode, float *ex_out,
+               void *ws, size_t ws_bytes, void *stream);
+
+/* ---- MC reduction ------------------------------------------------------------
+ * np.percentile(x, q, axis=samples) with linear interpolation -- the MC->quantile
+ * convention of experiments/bootstrap_baseline/generate_bootstrap_autoregressive.py:194-199.
+ * in: (n_vec, S) sample-minor.  out[(v / inner)*nq*inner + k*inner + v % inner] is
+ * the k-th percentile of vector v (inner = 25 gives (..., nq, 5, 5) per (day, step)).
+ * q_host: nq percentiles in [0,100] (host).  S <= 16384. */
+int vsv_percentile(const float *in, long n_vec, int S, const double *q_host, int nq,
+                   int inner, float *out, void *stream);
+
+/* ---- noise ---------------------------------------------------------------------
+ * The eps the decoder draws in Philox mode, materialised: out (n_days*S, n_steps, L).
+ * Stands in for torch.randn at cvae_with_mem_randomized.py:693-694. */
+int vsv_philox_normal(uint64_t seed, long day0, long n_days, long S, int step0, int n_steps,
+                      int L, float *out, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VSV_HIP_H */

@@ -1,0 +1,320 @@
+// Host side of libvsv_hip.so: shape validation, blob layout and weight packing.
+// No device code here.
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <functional>
+#include <vector>
+
+#include "vsv_layout.h"
+
+namespace vsv {
+
+static thread_local char g_err[512] = "";
+
+void set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
+
+static Sec alloc_sec(size_t& cur, int nq, int nt, int n_out, int n_relu) {
+    Sec s;
+    s.nq = nq;
+    s.nt = nt;
+    s.n_out = n_out;
+    s.n_relu = n_relu;
+    s.w_off = cur;
+    cur += (size_t)nq * nt * 256;
+    s.b_off = cur;
+    cur += (size_t)nt * 256;
+    return s;
+}
+
+int make_layout(const vsv_dims& d, Layout& lay, const char** msg) {
+    static thread_local char why[256];
+    auto fail = [&](const char* m) {
+        snprintf(why, sizeof(why), "%s", m);
+        if (msg) *msg = why;
+        return -1;
+    };
+    lay = Layout();
+    lay.L = d.latent_dim;
+    lay.X = d.ex_feats_dim;
+    lay.Hm = d.mem_hidden;
+    lay.NL = d.mem_layers;
+    lay.Q = d.n_quantiles;
+    if (lay.L < 1 || lay.L > 16) return fail("latent_dim must be in [1,16]");
+    if (lay.X < 0 || lay.X > 16) return fail("ex_feats_dim must be in [0,16]");
+    if (lay.NL < 1 || lay.NL > 2) return fail("mem_layers must be 1 or 2");
+    if (lay.Hm < 4 || lay.Hm > 128) return fail("mem_hidden must be in [4,128]");
+    if (lay.Q < 1 || lay.Q * 25 > kMaxFeat) return fail("n_quantiles*25 must be <= 128");
+    if (d.n_conv < 1 || d.n_conv > VSV_MAX_CONV || d.n_ctx_conv < 1 || d.n_ctx_conv > VSV_MAX_CONV)
+        return fail("1..4 conv layers supported");
+    for (int i = 0; i < d.n_conv; ++i)
+        if (d.surface_hidden[i] < 1 || d.surface_hidden[i] * 25 + lay.X > kMaxFeat)
+            return fail("surface_hidden[i]*25 + ex_feats_dim must be <= 128");
+    for (int i = 0; i < d.n_ctx_conv; ++i)
+        if (d.ctx_surface_hidden[i] < 1 || d.ctx_surface_hidden[i] * 25 + lay.X > kMaxFeat)
+            return fail("ctx_surface_hidden[i]*25 + ex_feats_dim must be <= 128");
+    lay.NTm = cdiv(lay.Hm, 4);
+    const int c_last = d.surface_hidden[d.n_conv - 1];
+    lay.Hd = c_last * 25 + lay.X;
+    lay.NTd = cdiv(lay.Hd, 4);
+
+    size_t cur = 0;
+    for (int which = 0; which < 2; ++which) {
+        EncLayout& e = lay.enc[which];
+        const int* ch = which ? d.ctx_surface_hidden : d.surface_hidden;
+        e.n_conv = which ? d.n_ctx_conv : d.n_conv;
+        int nt_prev = 0;
+        for (int i = 0; i < e.n_conv; ++i) {
+            const bool last = (i == e.n_conv - 1);
+            const int n_out = ch[i] * 25 + (last ? lay.X : 0);
+            const int nt = cdiv(n_out, 16);
+            const int nq = (i == 0) ? cdiv(cdiv(25, 4), 4) : nt_prev;
+            e.conv[i] = alloc_sec(cur, nq, nt, n_out, ch[i] * 25);
+            nt_prev = nt;
+        }
+        e.E = ch[e.n_conv - 1] * 25 + lay.X;
+        e.ex_f0 = ch[e.n_conv - 1] * 25;
+        e.kx = 4 * nt_prev;
+        e.lstm[0] = alloc_sec(cur, cdiv(e.kx + lay.NTm, 4), lay.NTm, 4 * lay.Hm, 0);
+        if (lay.NL == 2) e.lstm[1] = alloc_sec(cur, cdiv(2 * lay.NTm, 4), lay.NTm, 4 * lay.Hm, 0);
+        e.nh = which ? lay.L : 2 * lay.L;
+        e.head = alloc_sec(cur, cdiv(lay.NTm, 4), cdiv(e.nh, 16), e.nh, 0);
+    }
+    DecLayout& dc = lay.dec;
+    dc.kx = cdiv(2 * lay.L, 4);
+    dc.lstm[0] = alloc_sec(cur, cdiv(dc.kx + lay.NTd, 4), lay.NTd, 4 * lay.Hd, 0);
+    if (lay.NL == 2) dc.lstm[1] = alloc_sec(cur, cdiv(2 * lay.NTd, 4), lay.NTd, 4 * lay.Hd, 0);
+    // head: Linear(Hd -> c_last*25 [+X]) ; ConvT x n_conv ; Conv -> Q*25
+    int nh = 0;
+    {
+        const int n_out = c_last * 25 + lay.X;
+        dc.head[nh++] = alloc_sec(cur, cdiv(lay.NTd, 4), cdiv(n_out, 16), n_out, 0);
+    }
+    int cin = c_last;
+    for (int i = 0; i < d.n_conv; ++i) {
+        // dec_deconv_i maps reversed(surface_hidden[:-1])[i]; dec_final keeps the channel count
+        const int cout = (i < d.n_conv - 1) ? d.surface_hidden[d.n_conv - 2 - i] : cin;
+        const bool carries_ex = (i == 0 && lay.X > 0);
+        const int n_out = cout * 25 + (carries_ex ? lay.X : 0);
+        const int nt_prev = dc.head[nh - 1].nt;
+        if (carries_ex) {
+            dc.ex_layer = nh;
+            dc.ex_f0 = cout * 25;
+        }
+        dc.head[nh++] = alloc_sec(cur, nt_prev, cdiv(n_out, 16), n_out, cout * 25);
+        cin = cout;
+    }
+    {
+        const int nt_prev = dc.head[nh - 1].nt;
+        dc.head[nh++] = alloc_sec(cur, nt_prev, cdiv(lay.Q * 25, 16), lay.Q * 25, 0);
+    }
+    dc.n_head = nh;
+    dc.n_surf = lay.Q * 25;
+    lay.total = cur;
+    return 0;
+}
+
+// ---- generic fragment packer ------------------------------------------------
+using OutMap = std::function<int(int t, int i)>;            // -> output row or -1
+using InMap = std::function<int(int s, int kg)>;            // -> input column or -1
+using WFn = std::function<float(int row, int col)>;
+using BFn = std::function<float(int row)>;
+
+static void pack_sec(float* blob, const Sec& s, const OutMap& fo, const InMap& fi, const WFn& W, const BFn& B) {
+    float* w = blob + s.w_off;
+    for (int q = 0; q < s.nq; ++q)
+        for (int t = 0; t < s.nt; ++t)
+            for (int l = 0; l < 64; ++l)
+                for (int j = 0; j < 4; ++j) {
+                    const int r = fo(t, l & 15), c = fi(4 * q + j, l >> 4);
+                    w[(((size_t)q * s.nt + t) * 64 + l) * 4 + j] = (r >= 0 && c >= 0) ? W(r, c) : 0.0f;
+                }
+    float* b = blob + s.b_off;
+    for (int t = 0; t < s.nt; ++t)
+        for (int l = 0; l < 64; ++l)
+            for (int r4 = 0; r4 < 4; ++r4) {
+                const int r = fo(t, 4 * (l >> 4) + r4);
+                b[((size_t)t * 64 + l) * 4 + r4] = (r >= 0) ? B(r) : 0.0f;
+            }
+}
+
+static OutMap out_nat16(int n_out) {
+    return [=](int t, int i) { const int f = 16 * t + i; return f < n_out ? f : -1; };
+}
+// LSTM gates: tile t holds units 4t..4t+3; D row i = 4*unit_local + gate
+static OutMap out_gate(int H) {
+    return [=](int t, int i) { const int u = 4 * t + (i >> 2); return u < H ? (i & 3) * H + u : -1; };
+}
+static InMap in_nat(int n_in) {
+    return [=](int s, int kg) { const int f = 4 * s + kg; return f < n_in ? f : -1; };
+}
+static InMap in_perm(int n_in) {
+    return [=](int s, int kg) { const int f = 16 * (s >> 2) + 4 * kg + (s & 3); return f < n_in ? f : -1; };
+}
+
+// Dense (Toeplitz) matrix of a 3x3, stride 1, pad 1 conv on a 5x5 grid.
+// transposed=false: nn.Conv2d weight (cout,cin,3,3); true: nn.ConvTranspose2d weight (cin,cout,3,3).
+static std::vector<float> conv_matrix(const float* w, int cin, int cout, bool transposed) {
+    std::vector<float> M((size_t)cout * 25 * cin * 25, 0.0f);
+    for (int co = 0; co < cout; ++co)
+        for (int y = 0; y < 5; ++y)
+            for (int x = 0; x < 5; ++x)
+                for (int ci = 0; ci < cin; ++ci)
+                    for (int ky = 0; ky < 3; ++ky)
+                        for (int kx = 0; kx < 3; ++kx) {
+                            const int yi = transposed ? y + 1 - ky : y + ky - 1;
+                            const int xi = transposed ? x + 1 - kx : x + kx - 1;
+                            if (yi < 0 || yi >= 5 || xi < 0 || xi >= 5) continue;
+                            const float v = transposed ? w[((ci * cout + co) * 3 + ky) * 3 + kx]
+                                                       : w[((co * cin + ci) * 3 + ky) * 3 + kx];
+                            M[(size_t)(co * 25 + y * 5 + x) * (cin * 25) + ci * 25 + yi * 5 + xi] = v;
+                        }
+    return M;
+}
+
+static void pack_lstm(float* blob, const Sec* secs, const vsv_lstm_raw& raw, int NL, int H, int in0,
+                      int kx, const InMap& x_map) {
+    const int NT = (H + 3) / 4;
+    for (int l = 0; l < NL; ++l) {
+        const float *wih = raw.w_ih[l], *whh = raw.w_hh[l], *bih = raw.b_ih[l], *bhh = raw.b_hh[l];
+        const int n_in = (l == 0) ? in0 : H;
+        const int kin = (l == 0) ? kx : NT;            // k-steps of the input part
+        const InMap imap = (l == 0) ? x_map : in_nat(H);
+        const InMap hmap = in_nat(H);
+        // combined column space: [0, n_in) -> w_ih, [n_in, n_in+H) -> w_hh
+        InMap fi = [=](int s, int kg) {
+            if (s < kin) return imap(s, kg);
+            const int c = hmap(s - kin, kg);
+            return c < 0 ? -1 : n_in + c;
+        };
+        WFn W = [=](int r, int c) { return c < n_in ? wih[(size_t)r * n_in + c] : whh[(size_t)r * H + (c - n_in)]; };
+        BFn B = [=](int r) { return bih[r] + bhh[r]; };
+        pack_sec(blob, secs[l], out_gate(H), fi, W, B);
+    }
+}
+
+}  // namespace vsv
+
+using namespace vsv;
+
+extern "C" int vsv_abi_version(void) { return VSV_ABI_VERSION; }
+extern "C" const char* vsv_last_error(void) { return g_err; }
+
+extern "C" size_t vsv_packed_floats(const vsv_dims* dims) {
+    Layout lay;
+    const char* msg = nullptr;
+    if (!dims || make_layout(*dims, lay, &msg) != 0) {
+        set_error("vsv_packed_floats: %s", msg ? msg : "null dims");
+        return 0;
+    }
+    return lay.total;
+}
+
+extern "C" size_t vsv_state_floats(const vsv_dims* dims) {
+    Layout lay;
+    const char* msg = nullptr;
+    if (!dims || make_layout(*dims, lay, &msg) != 0) {
+        set_error("vsv_state_floats: %s", msg ? msg : "null dims");
+        return 0;
+    }
+    return (size_t)lay.NL * 2 * 4 * lay.NTd;
+}
+
+extern "C" int vsv_pack_weights(const vsv_dims* dims, const vsv_raw_weights* raw, float* out) {
+    Layout lay;
+    const char* msg = nullptr;
+    if (!dims || !raw || !out) {
+        set_error("vsv_pack_weights: null argument");
+        return -1;
+    }
+    if (make_layout(*dims, lay, &msg) != 0) {
+        set_error("vsv_pack_weights: %s", msg);
+        return -1;
+    }
+    const vsv_dims& d = *dims;
+    memset(out, 0, lay.total * sizeof(float));
+    const int L = lay.L, X = lay.X, Hm = lay.Hm;
+
+    for (int which = 0; which < 2; ++which) {
+        const EncLayout& e = lay.enc[which];
+        const int* ch = which ? d.ctx_surface_hidden : d.surface_hidden;
+        const float* const* cw = which ? raw->ctx_conv_w : raw->enc_conv_w;
+        const float* const* cb = which ? raw->ctx_conv_b : raw->enc_conv_b;
+        int cin = 1;
+        for (int i = 0; i < e.n_conv; ++i) {
+            if (!cw[i] || !cb[i]) { set_error("vsv_pack_weights: missing conv weight"); return -1; }
+            const int cout = ch[i];
+            std::vector<float> M = conv_matrix(cw[i], cin, cout, false);
+            const int n_in = cin * 25, n_out = cout * 25;
+            const float* bias = cb[i];
+            WFn W = [&, n_in](int r, int c) { return M[(size_t)r * n_in + c]; };
+            BFn B = [=](int r) { return bias[r / 25]; };
+            // rows >= n_out (ex-feature slots of the last layer) stay zero: out map limited to n_out
+            pack_sec(out, e.conv[i], out_nat16(n_out), i == 0 ? in_nat(n_in) : in_perm(n_in), W, B);
+            cin = cout;
+        }
+        const vsv_lstm_raw& mem = which ? raw->ctx_mem : raw->enc_mem;
+        pack_lstm(out, e.lstm, mem, lay.NL, Hm, e.E, e.kx, in_perm(e.E));
+        if (which == 0) {
+            const float *wm = raw->z_mean_w, *bm = raw->z_mean_b, *wv = raw->z_log_var_w, *bv = raw->z_log_var_b;
+            WFn W = [=](int r, int c) { return r < L ? wm[(size_t)r * Hm + c] : wv[(size_t)(r - L) * Hm + c]; };
+            BFn B = [=](int r) { return r < L ? bm[r] : bv[r - L]; };
+            pack_sec(out, e.head, out_nat16(2 * L), in_nat(Hm), W, B);
+        } else {
+            const float *wc = raw->ctx_comp_w, *bc = raw->ctx_comp_b;
+            WFn W = [=](int r, int c) { return wc[(size_t)r * Hm + c]; };
+            BFn B = [=](int r) { return bc[r]; };
+            pack_sec(out, e.head, out_nat16(L), in_nat(Hm), W, B);
+        }
+    }
+
+    const DecLayout& dc = lay.dec;
+    const int Hd = lay.Hd;
+    pack_lstm(out, dc.lstm, raw->dec_mem, lay.NL, Hd, 2 * L, dc.kx, in_nat(2 * L));
+    int hi = 0;
+    const int c_last = d.surface_hidden[d.n_conv - 1];
+    {   // Linear: rows [surface_decoder_input ; ex_feats_decoder_input]
+        const int ns = c_last * 25;
+        const float *ws = raw->dec_in_w, *bs = raw->dec_in_b, *we = raw->ex_in_w, *be = raw->ex_in_b;
+        if (X > 0 && (!we || !be)) { set_error("vsv_pack_weights: missing ex_feats_decoder_input"); return -1; }
+        WFn W = [=](int r, int c) { return r < ns ? ws[(size_t)r * Hd + c] : we[(size_t)(r - ns) * Hd + c]; };
+        BFn B = [=](int r) { return r < ns ? bs[r] : be[r - ns]; };
+        pack_sec(out, dc.head[hi++], out_nat16(ns + X), in_nat(Hd), W, B);
+    }
+    int cin = c_last;
+    for (int i = 0; i < d.n_conv; ++i) {
+        const int cout = (i < d.n_conv - 1) ? d.surface_hidden[d.n_conv - 2 - i] : cin;
+        if (!raw->dec_deconv_w[i] || !raw->dec_deconv_b[i]) { set_error("vsv_pack_weights: missing deconv weight"); return -1; }
+        std::vector<float> M = conv_matrix(raw->dec_deconv_w[i], cin, cout, true);
+        const int n_in = cin * 25, n_out = cout * 25;
+        const float* bias = raw->dec_deconv_b[i];
+        const bool carries_ex = (i == 0 && X > 0);
+        const float *w2 = raw->ex_out_w, *b2 = raw->ex_out_b;
+        if (carries_ex && (!w2 || !b2)) { set_error("vsv_pack_weights: missing ex_feats_decoder"); return -1; }
+        // ex path rides in features [n_out, n_out+X) of this layer: ex = W2 * ex_in + b2 (no ReLU)
+        WFn W = [&, n_in, n_out](int r, int c) {
+            if (r < n_out) return c < n_in ? M[(size_t)r * n_in + c] : 0.0f;
+            return c >= n_in ? w2[(size_t)(r - n_out) * X + (c - n_in)] : 0.0f;
+        };
+        BFn B = [=](int r) { return r < n_out ? bias[r / 25] : b2[r - n_out]; };
+        const int n_in_tot = n_in + ((i == 0) ? X : 0);
+        pack_sec(out, dc.head[hi++], out_nat16(n_out + (carries_ex ? X : 0)), in_perm(n_in_tot), W, B);
+        cin = cout;
+    }
+    {
+        std::vector<float> M = conv_matrix(raw->dec_out_w, cin, lay.Q, false);
+        const int n_in = cin * 25;
+        const float* bias = raw->dec_out_b;
+        WFn W = [&, n_in](int r, int c) { return M[(size_t)r * n_in + c]; };
+        BFn B = [=](int r) { return bias[r / 25]; };
+        pack_sec(out, dc.head[hi++], out_nat16(lay.Q * 25), in_perm(n_in), W, B);
+    }
+    return 0;
+}

@@ -158,6 +158,11 @@ int vsv_percentile(const float *in, long n_vec, int S, const double *q_host, int
 int vsv_philox_normal(uint64_t seed, long day0, long n_days, long S, int step0, int n_steps,
                       int L, float *out, void *stream);
 
+/* ---- diagnostics ------------------------------------------------------------------
+ * Dumps the packed-blob layout (offsets and tile counts per layer) so a host-side
+ * test can decode the fragments without a GPU.  No counterpart in the reference. */
+int vsv_debug_layout(const vsv_dims *dims, long long *out, int cap);
+
 #ifdef __cplusplus
 }
 #endif

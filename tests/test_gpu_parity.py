@@ -1,0 +1,168 @@
+"""GPU parity tests: the HIP path (through the C ABI of libvsv_hip.so) against
+the reference's own outputs (tests/golden) and against the CPU oracle on seeded
+inputs.  Tolerances are the north-star's: max abs err <= 1e-4 on vols."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import cfg_of, golden_names, load_golden
+from oracle import vsv_oracle as vo
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-4
+
+
+def _engine(cfg, seed, scale):
+    from vsv.engine import Engine
+    W = vo.init_weights(cfg, seed, scale, np.float32)
+    return Engine(cfg, W, "cuda:0"), W
+
+
+def _t(a):
+    return None if a is None else torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).cuda()
+
+
+def _n(t):
+    return t.detach().cpu().numpy().astype(np.float64)
+
+
+def err(a, b):
+    a, b = np.asarray(a, dtype=np.float64), np.asarray(b, dtype=np.float64)
+    assert a.shape == b.shape, (a.shape, b.shape)
+    return float(np.max(np.abs(a - b))) if a.size else 0.0
+
+
+@pytest.mark.parametrize("name", golden_names("g2_"))
+def test_encoders_and_prior_generation_vs_reference(name):
+    from vsv import paths
+    g = load_golden(name)
+    cfg = cfg_of(g)
+    eng, _ = _engine(cfg, int(g["seed"]), float(g["scale"]))
+    surf, ex = _t(g["surface"]), _t(g.get("ex_feats"))
+    C, H = g["surface"].shape[1], int(g["horizon"])
+    zm, zl = paths.encode_both(eng, surf, ex)
+    assert err(_n(zm), g["enc_z_mean"]) <= TOL
+    assert err(_n(zl), g["enc_z_log_var"]) <= TOL
+    ctx = eng.encode(1, surf, ex)
+    assert err(_n(ctx), g["ctx_embedding"]) <= TOL
+    # shared-prefix prior generation with the reference's injected future latents
+    eps = _t(g["z"][:, C:])
+    s, e, _ = paths.prior_generate(eng, surf, ex, H, 1, eps=eps)
+    assert s.shape == g["surf_out"].shape
+    assert err(_n(s), g["surf_out"]) <= TOL
+    if ex is not None:
+        assert err(_n(e), g["ex_out"]) <= TOL
+    # literal evaluation: decoder over all C+H steps on cat([ctx_pad, z_after])
+    s2, e2 = paths.decode_given_z(eng, ctx, _t(g["z_after"]), C)
+    assert err(_n(s2), g["surf_out"]) <= TOL
+    if ex is not None:
+        assert err(_n(e2), g["ex_out"]) <= TOL
+
+
+@pytest.mark.parametrize("name", golden_names("g1_"))
+def test_forward_vs_reference(name):
+    from vsv import paths
+    g = load_golden(name)
+    cfg = cfg_of(g)
+    eng, _ = _engine(cfg, int(g["seed"]), float(g["scale"]))
+    surf, ex = _t(g["surface"]), _t(g.get("ex_feats"))
+    s, e, zm, zl, z = paths.forward(eng, surf, ex, int(g["horizon"]), eps=_t(g["eps"]))
+    assert s.shape == g["recon"].shape
+    assert err(_n(zm), g["z_mean"]) <= TOL
+    assert err(_n(zl), g["z_log_var"]) <= TOL
+    assert err(_n(z), g["z"]) <= TOL
+    assert err(_n(s), g["recon"]) <= TOL
+    if ex is not None:
+        assert err(_n(e), g["ex_recon"]) <= TOL
+
+
+@pytest.mark.parametrize("L,X,D,S,C,H", [(5, 0, 3, 40, 20, 1), (12, 3, 5, 24, 60, 7), (5, 3, 2, 1000, 5, 2)])
+def test_prior_mc_vs_oracle_ragged_tiles(L, X, D, S, C, H):
+    """rows = D*S is not a multiple of the 16-row tile and tiles straddle days."""
+    from vsv import paths
+    cfg = vo.make_config(L, X)
+    eng, W = _engine(cfg, 77, 2.0)
+    rng = np.random.default_rng(5)
+    surf = (0.2 + 0.1 * rng.standard_normal((D, C, 5, 5))).astype(np.float32)
+    ex = (0.01 * rng.standard_normal((D, C, X))).astype(np.float32) if X else None
+    eps = rng.standard_normal((D, S, H, L)).astype(np.float32)
+    W64 = {k: v.astype(np.float64) for k, v in W.items()}
+    want_s, want_e = vo.prior_mc_shared_prefix(W64, cfg, surf.astype(np.float64),
+                                               None if ex is None else ex.astype(np.float64),
+                                               eps.astype(np.float64))
+    s, e, _ = paths.prior_generate(eng, _t(surf), _t(ex), H, S, eps=_t(eps.reshape(D * S, H, L)))
+    assert err(_n(s).reshape(want_s.shape), want_s) <= TOL
+    if X:
+        assert err(_n(e).reshape(want_e.shape), want_e) <= TOL
+    # sample-minor layout holds the same numbers
+    s1, _, _ = paths.prior_generate(eng, _t(surf), _t(ex), H, S, eps=_t(eps.reshape(D * S, H, L)), out_mode=1)
+    assert s1.shape == (D, H, 75, S)
+    ref = s.view(D, S, H, 75).permute(0, 2, 3, 1)
+    assert torch.equal(s1, ref)
+
+
+def test_percentile_matches_numpy():
+    cfg = vo.make_config(5, 0)
+    eng, _ = _engine(cfg, 0, 1.0)
+    rng = np.random.default_rng(1)
+    for S in (1000, 10000, 37, 1, 2):
+        x = rng.standard_normal((4, 25, S)).astype(np.float32)
+        got = _n(eng.percentile(_t(x), (5, 50, 95), inner=25))          # (4, 3, 25)
+        want = np.percentile(x.astype(np.float64), [5, 50, 95], axis=-1).transpose(1, 0, 2)
+        assert got.shape == want.shape
+        assert err(got, want) <= 1e-6, S
+    # ties and infinities do not break the selection
+    x = np.zeros((1, 25, 100), dtype=np.float32)
+    x[..., 50:] = 1.0
+    got = _n(eng.percentile(_t(x), (5, 50, 95), inner=25))
+    want = np.percentile(x, [5, 50, 95], axis=-1).transpose(1, 0, 2)
+    assert err(got, want) <= 1e-7
+
+
+def test_philox_matches_oracle_and_fused_mode():
+    from scipy import stats
+    cfg = vo.make_config(5, 0)
+    eng, _ = _engine(cfg, 3, 2.0)
+    L = 5
+    z = _n(eng.philox_normal(1234, 7, 6, 50, 2, 3))                 # (6*50, 3, 5)
+    want = vo.philox_normal(1234, 7, 6, 50, 2, 3, L).reshape(300, 3, L)
+    assert err(z, want) <= 1e-4                                        # device vs numpy log/sin/cos
+    big = _n(eng.philox_normal(99, 0, 64, 1000, 0, 1)).ravel()
+    assert stats.kstest(big, "norm").pvalue > 1e-3
+    assert abs(big.mean()) < 0.01 and abs(big.std() - 1) < 0.01
+    # fused Philox decode == decode with the materialised noise injected (bit-exact)
+    from vsv import paths
+    rng = np.random.default_rng(2)
+    D, S, C, H = 3, 50, 20, 4
+    surf = _t(0.2 + 0.1 * rng.standard_normal((D, C, 5, 5)))
+    eps = eng.philox_normal(55, 100, D, S, 0, H)
+    a, _, _ = paths.prior_generate(eng, surf, None, H, S, seed=55, day0=100)
+    b, _, _ = paths.prior_generate(eng, surf, None, H, S, eps=eps)
+    assert torch.equal(a, b)
+    # sharding invariance: days [1,3) alone give the same samples
+    c, _, _ = paths.prior_generate(eng, surf[1:], None, H, S, seed=55, day0=101)
+    assert torch.equal(c, a.view(D, S, H, 3, 5, 5)[1:].reshape(c.shape))
+
+
+def test_prior_mc_windows_reduction_vs_oracle():
+    """End-to-end MC backfill on a small calendar: Philox noise materialised, fed
+    to the oracle, np.percentile on the oracle's samples."""
+    from vsv import paths
+    L, X, C, H, S, N = 5, 3, 5, 2, 64, 6
+    cfg = vo.make_config(L, X)
+    eng, W = _engine(cfg, 11, 2.0)
+    rng = np.random.default_rng(9)
+    vol = (0.2 + 0.1 * rng.standard_normal((N + C, 5, 5))).astype(np.float32)
+    ex = (0.01 * rng.standard_normal((N + C, X))).astype(np.float32)
+    q = paths.prior_mc_windows(eng, _t(vol), _t(ex), C, N, C, H, S, seed=5, chunk_days=4, channel=None)
+    assert q.shape == (N, H, 3, 3, 5, 5)
+    eps = _n(eng.philox_normal(5, C, N, S, 0, H)).reshape(N, S, H, L)
+    W64 = {k: v.astype(np.float64) for k, v in W.items()}
+    win = np.stack([vol[d:d + C] for d in range(N)]).astype(np.float64)
+    wex = np.stack([ex[d:d + C] for d in range(N)]).astype(np.float64)
+    smp, _ = vo.prior_mc_shared_prefix(W64, cfg, win, wex, eps)           # (N,S,H,3,5,5)
+    want = np.percentile(smp, [5, 50, 95], axis=1).transpose(1, 2, 0, 3, 4, 5)   # (N,H,3q,3ch,5,5)
+    assert err(_n(q), want) <= TOL
+    q1 = paths.prior_mc_windows(eng, _t(vol), _t(ex), C, N, C, H, S, seed=5, chunk_days=256, channel=1)
+    assert err(_n(q1), want[:, :, :, 1]) <= TOL

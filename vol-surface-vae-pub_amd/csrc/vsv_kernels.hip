@@ -234,7 +234,7 @@ struct LstmSeqArgs {
     // fused linear head on the top-layer h (encoders): out (n_rows, T, nh)
     const float* head_w;
     const float* head_b;
-    int head_nq, nh;
+    int head_nq, head_nt, nh;
     float* head_out;
 };
 
@@ -300,6 +300,24 @@ __device__ __forceinline__ void lstm_cell(const f32x4 (&acc)[NC], float* c, floa
         c[s] = cn;
         hn[s] = og * tanhf(cn);
     }
+}
+
+// fused linear head on the top-layer h (encoders): NTH output tiles, natural order
+template <int NTH>
+__device__ __forceinline__ void lstm_head(const LstmSeqArgs& a, const float* htop, int lane, long row,
+                                          bool row_ok, int t) {
+    f32x4 acc2[NTH];
+    load_bias<NTH>(acc2, (const float4*)a.head_b + lane);
+    tile_gemm<NTH>(acc2, (const float4*)a.head_w + lane, htop, a.head_nq);
+    if (!row_ok) return;
+    const int g = lane >> 4;
+#pragma unroll
+    for (int tt = 0; tt < NTH; ++tt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int f = 16 * tt + 4 * g + r;
+            if (f < a.nh) a.head_out[((size_t)row * a.T + t) * a.nh + f] = acc2[tt][r];
+        }
 }
 
 template <int NT, int NL, int XMODE>
@@ -380,18 +398,10 @@ __global__ void __launch_bounds__(256, 2) lstm_seq_kernel(LstmSeqArgs a) {
             for (int s = 0; s < NT; ++s) ho[s * 64] = htop[s * 64];
         }
         if (a.head_w) {
-            f32x4 acc2[2];
-            load_bias<2>(acc2, (const float4*)a.head_b + lane);
-            tile_gemm<2>(acc2, (const float4*)a.head_w + lane, htop, a.head_nq);
-            if (row_ok) {
-#pragma unroll
-                for (int tt = 0; tt < 2; ++tt)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const int f = 16 * tt + 4 * g + r;
-                        if (f < a.nh) a.head_out[((size_t)row * a.T + t) * a.nh + f] = acc2[tt][r];
-                    }
-            }
+            if (a.head_nt == 2)
+                lstm_head<2>(a, htop, lane, row, row_ok, t);
+            else
+                lstm_head<1>(a, htop, lane, row, row_ok, t);
         }
     }
     if (a.state_out && row_ok) {
@@ -594,7 +604,7 @@ extern "C" int vsv_encode(const vsv_dims* dims, const float* packed, int which,
     l.kx = e.kx; l.n_rows = n_rows; l.n_rowtiles = rt; l.T = T;
     l.x_tileb = xe; l.L = lay.L;
     l.t_out0 = T;
-    l.head_w = packed + e.head.w_off; l.head_b = packed + e.head.b_off; l.head_nq = e.head.nq; l.nh = e.nh;
+    l.head_w = packed + e.head.w_off; l.head_b = packed + e.head.b_off; l.head_nq = e.head.nq; l.head_nt = e.head.nt; l.nh = e.nh;
     l.head_out = out;
     return launch_lstm<0>(l, lay.NTm, lay.NL, st);
 }

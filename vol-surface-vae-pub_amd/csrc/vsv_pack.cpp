@@ -318,3 +318,36 @@ extern "C" int vsv_pack_weights(const vsv_dims* dims, const vsv_raw_weights* raw
     }
     return 0;
 }
+
+// Diagnostic: dump the blob layout as int64 records of 6 (w_off, b_off, nq, nt, n_relu, n_out).
+// Order: for which in {enc, ctx}: conv[0..3], lstm[0..1], head; then dec: lstm[0..1], head[0..5];
+// then scalars: enc.kx, ctx.kx, enc.nh, ctx.nh, enc.E, enc.ex_f0, dec.kx, dec.n_head, dec.ex_layer,
+// dec.ex_f0, NTm, NTd, Hd.  Returns the number of int64 written (or needed when out is NULL).
+extern "C" int vsv_debug_layout(const vsv_dims* dims, long long* out, int cap) {
+    Layout lay;
+    const char* msg = nullptr;
+    if (!dims || make_layout(*dims, lay, &msg) != 0) {
+        set_error("vsv_debug_layout: %s", msg ? msg : "null dims");
+        return -1;
+    }
+    std::vector<long long> v;
+    auto put = [&](const Sec& s) {
+        v.push_back((long long)s.w_off); v.push_back((long long)s.b_off); v.push_back(s.nq);
+        v.push_back(s.nt); v.push_back(s.n_relu); v.push_back(s.n_out);
+    };
+    for (int w = 0; w < 2; ++w) {
+        for (int i = 0; i < VSV_MAX_CONV; ++i) put(lay.enc[w].conv[i]);
+        put(lay.enc[w].lstm[0]); put(lay.enc[w].lstm[1]); put(lay.enc[w].head);
+    }
+    put(lay.dec.lstm[0]); put(lay.dec.lstm[1]);
+    for (int i = 0; i < kMaxDenseLayers; ++i) put(lay.dec.head[i]);
+    const long long sc[] = {lay.enc[0].kx, lay.enc[1].kx, lay.enc[0].nh, lay.enc[1].nh, lay.enc[0].E,
+                            lay.enc[0].ex_f0, lay.dec.kx, lay.dec.n_head, lay.dec.ex_layer, lay.dec.ex_f0,
+                            lay.NTm, lay.NTd, lay.Hd};
+    for (long long x : sc) v.push_back(x);
+    if (out) {
+        if (cap < (int)v.size()) { set_error("vsv_debug_layout: buffer too small"); return -1; }
+        for (size_t i = 0; i < v.size(); ++i) out[i] = v[i];
+    }
+    return (int)v.size();
+}

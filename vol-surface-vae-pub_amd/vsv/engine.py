@@ -1,0 +1,227 @@
+"""Host-side driver of the HIP path: packs a CVAEMemRand state_dict for the
+kernels and launches them on torch-owned device memory (torch is plumbing
+here: allocation, streams, dtype casts).  Every compute goes through the C ABI
+of libvsv_hip.so; nothing in this module computes on the CPU.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Dict, Optional, Sequence
+
+import numpy as np
+import torch
+
+from . import lib as _lib
+
+
+def dims_from_config(cfg: dict) -> _lib.VsvDims:
+    """vsv_dims from a reference model config dict
+    (keys as validated by cvae_with_mem_randomized.py:969-1020)."""
+    if cfg.get("mem_type", "lstm") != "lstm":
+        raise NotImplementedError("HIP path implements mem_type='lstm' only")
+    if cfg.get("use_dense_surface", False):
+        raise NotImplementedError("HIP path implements the conv surface embedding only")
+    if cfg.get("interaction_layers"):
+        raise NotImplementedError("HIP path implements interaction_layers=None only")
+    if not cfg.get("compress_context", False):
+        raise NotImplementedError("HIP path implements compress_context=True only")
+    if cfg.get("ex_feats_hidden") is not None or cfg.get("ctx_ex_feats_hidden") is not None:
+        raise NotImplementedError("HIP path implements ex_feats_hidden=None only")
+    if tuple(cfg["feat_dim"]) != (5, 5):
+        raise NotImplementedError("HIP path implements the 5x5 grid only")
+    return _lib.make_dims(cfg["latent_dim"], cfg["ex_feats_dim"], cfg["mem_hidden"], cfg["mem_layers"],
+                          list(cfg["surface_hidden"]), list(cfg["ctx_surface_hidden"]),
+                          len(cfg.get("quantiles", [0.05, 0.5, 0.95])))
+
+
+def _fp(a: np.ndarray):
+    return a.ctypes.data_as(C.POINTER(C.c_float))
+
+
+def pack_state_dict(dims: _lib.VsvDims, sd: Dict[str, np.ndarray]) -> np.ndarray:
+    """state_dict (name -> array, reference key names) -> packed float32 blob."""
+    L = _lib.load()
+    keep = []          # keep the float32 copies alive until packing is done
+
+    def get(name):
+        a = np.ascontiguousarray(np.asarray(sd[name], dtype=np.float32))
+        keep.append(a)
+        return _fp(a)
+
+    raw = _lib.VsvRawWeights()
+
+    def lstm(dst, prefix):
+        for l in range(dims.mem_layers):
+            dst.w_ih[l] = get(f"{prefix}.weight_ih_l{l}")
+            dst.w_hh[l] = get(f"{prefix}.weight_hh_l{l}")
+            dst.b_ih[l] = get(f"{prefix}.bias_ih_l{l}")
+            dst.b_hh[l] = get(f"{prefix}.bias_hh_l{l}")
+
+    for i in range(dims.n_conv):
+        raw.enc_conv_w[i] = get(f"encoder.surface_embedding.enc_conv_{i}.weight")
+        raw.enc_conv_b[i] = get(f"encoder.surface_embedding.enc_conv_{i}.bias")
+    lstm(raw.enc_mem, "encoder.mem")
+    raw.z_mean_w, raw.z_mean_b = get("encoder.z_mean_layer.weight"), get("encoder.z_mean_layer.bias")
+    raw.z_log_var_w, raw.z_log_var_b = get("encoder.z_log_var_layer.weight"), get("encoder.z_log_var_layer.bias")
+    for i in range(dims.n_ctx_conv):
+        raw.ctx_conv_w[i] = get(f"ctx_encoder.ctx_surface_embedding.ctx_enc_conv_{i}.weight")
+        raw.ctx_conv_b[i] = get(f"ctx_encoder.ctx_surface_embedding.ctx_enc_conv_{i}.bias")
+    lstm(raw.ctx_mem, "ctx_encoder.mem")
+    raw.ctx_comp_w, raw.ctx_comp_b = get("ctx_encoder.final_compression.weight"), get("ctx_encoder.final_compression.bias")
+    lstm(raw.dec_mem, "decoder.mem")
+    raw.dec_in_w, raw.dec_in_b = get("decoder.surface_decoder_input.weight"), get("decoder.surface_decoder_input.bias")
+    names = [f"dec_deconv_{i}" for i in range(dims.n_conv - 1)] + ["dec_final"]
+    for i, nm in enumerate(names):
+        raw.dec_deconv_w[i] = get(f"decoder.surface_decoder.{nm}.weight")
+        raw.dec_deconv_b[i] = get(f"decoder.surface_decoder.{nm}.bias")
+    raw.dec_out_w, raw.dec_out_b = get("decoder.surface_decoder.dec_output.weight"), get("decoder.surface_decoder.dec_output.bias")
+    if dims.ex_feats_dim > 0:
+        raw.ex_in_w, raw.ex_in_b = get("decoder.ex_feats_decoder_input.weight"), get("decoder.ex_feats_decoder_input.bias")
+        raw.ex_out_w, raw.ex_out_b = get("decoder.ex_feats_decoder.weight"), get("decoder.ex_feats_decoder.bias")
+
+    n = L.vsv_packed_floats(C.byref(dims))
+    if n == 0:
+        raise ValueError("vsv_packed_floats: " + L.vsv_last_error().decode())
+    out = np.empty(n, dtype=np.float32)
+    _lib.check(L.vsv_pack_weights(C.byref(dims), C.byref(raw), _fp(out)), "vsv_pack_weights")
+    return out
+
+
+def _ptr(t: Optional[torch.Tensor]):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def _f32c(t: torch.Tensor, device) -> torch.Tensor:
+    return t.to(device=device, dtype=torch.float32).contiguous()
+
+
+class Engine:
+    """Packed weights on one GPU + launch helpers.  All tensor arguments are
+    float32 CUDA tensors; outputs are freshly allocated float32 CUDA tensors."""
+
+    def __init__(self, cfg: dict, state_dict: Dict[str, np.ndarray], device="cuda:0"):
+        self.lib = _lib.load()
+        self.device = torch.device(device)
+        if self.device.type != "cuda" or not torch.cuda.is_available():
+            raise RuntimeError("the HIP path needs a GPU (device must be a cuda/ROCm device); "
+                               "there is no CPU fallback")
+        self.dims = dims_from_config(cfg)
+        self.L = self.dims.latent_dim
+        self.X = self.dims.ex_feats_dim
+        self.Q = self.dims.n_quantiles
+        self.state_floats = int(self.lib.vsv_state_floats(C.byref(self.dims)))
+        self.set_weights(state_dict)
+
+    def set_weights(self, state_dict: Dict[str, np.ndarray]) -> None:
+        blob = pack_state_dict(self.dims, state_dict)
+        self.packed = torch.from_numpy(blob).to(self.device)
+
+    # -- helpers ---------------------------------------------------------
+    def _stream(self):
+        return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    def _ws(self, nbytes: int) -> torch.Tensor:
+        return torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=self.device)
+
+    # -- encoders ----------------------------------------------------------
+    def encode(self, which: int, surface: torch.Tensor, ex: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """surface (B,T,5,5) [, ex (B,T,X)] -> (B,T,2L) (which=0: [z_mean|z_log_var])
+        or (B,T,L) (which=1: context embedding)."""
+        surface = _f32c(surface, self.device)
+        B, T = surface.shape[:2]
+        if self.X > 0:
+            if ex is None:
+                raise ValueError("model has ex_feats_dim > 0 but no ex_feats were given")
+            ex = _f32c(ex, self.device)
+        return self.encode_strided(which, surface, T * 25, 25, ex, T * self.X, self.X, B, T)
+
+    def encode_strided(self, which, surf, surf_rs, surf_ts, ex, ex_rs, ex_ts, n_rows, T) -> torch.Tensor:
+        nh = self.L if which else 2 * self.L
+        out = torch.empty((n_rows, T, nh), dtype=torch.float32, device=self.device)
+        nws = self.lib.vsv_encode_ws_bytes(C.byref(self.dims), n_rows, T)
+        ws = self._ws(nws)
+        with torch.cuda.device(self.device):
+            rc = self.lib.vsv_encode(C.byref(self.dims), _ptr(self.packed), which,
+                                     _ptr(surf), surf_rs, surf_ts, _ptr(ex), ex_rs, ex_ts,
+                                     n_rows, T, _ptr(out), _ptr(ws), ws.numel(), self._stream())
+        _lib.check(rc, "vsv_encode")
+        return out
+
+    # -- decoder -----------------------------------------------------------
+    def decode(self, n_rows: int, T: int, t_out0: int, *,
+               ctx: Optional[torch.Tensor] = None, ctx_div: int = 1,
+               zb: Optional[torch.Tensor] = None, lv: Optional[torch.Tensor] = None, z_div: int = 1,
+               mu0: float = 0.0, std0: float = 1.0,
+               eps: Optional[torch.Tensor] = None, eps_t0: int = 0,
+               seed: int = 0, S: int = 1, day0: int = 0, step0: int = 0,
+               state_in: Optional[torch.Tensor] = None, state_div: int = 1,
+               want_state: bool = False, want_z: bool = False, out_mode: int = 0):
+        """See vsv_decode in include/vsv_hip.h.  ctx (n,ctx_T,L); zb/lv (n,z_T,L);
+        eps (n_rows,eps_T,L).  Returns dict(surf, ex, state, z)."""
+        din = _lib.VsvDecodeIn()
+        if ctx is not None:
+            ctx = _f32c(ctx, self.device)
+            din.ctx, din.ctx_rs, din.ctx_T, din.ctx_div = ctx.data_ptr(), ctx.shape[1] * self.L, ctx.shape[1], ctx_div
+        else:
+            din.ctx_div = 1
+        if zb is not None:
+            zb = _f32c(zb, self.device)
+            din.zb, din.z_rs, din.z_T, din.z_div = zb.data_ptr(), zb.shape[1] * self.L, zb.shape[1], z_div
+            if lv is not None:
+                lv = _f32c(lv, self.device)
+                assert lv.shape == zb.shape
+                din.lv = lv.data_ptr()
+        else:
+            din.z_div = 1
+        din.mu0, din.std0 = float(mu0), float(std0)
+        if eps is not None:
+            eps = _f32c(eps, self.device)
+            assert eps.shape[0] == n_rows and eps.shape[2] == self.L
+            din.eps_in, din.eps_T = eps.data_ptr(), eps.shape[1]
+        din.eps_t0 = eps_t0
+        din.seed, din.S, din.day0, din.step0 = seed & (2 ** 64 - 1), S, day0, step0
+        if state_in is not None:
+            state_in = _f32c(state_in, self.device)
+            din.state_in, din.state_div = state_in.data_ptr(), state_div
+        else:
+            din.state_div = 1
+        touts = T - t_out0
+        dev = self.device
+        state = torch.empty((n_rows, self.state_floats), dtype=torch.float32, device=dev) if want_state else None
+        z = torch.empty((n_rows, T, self.L), dtype=torch.float32, device=dev) if want_z else None
+        surf = ex = None
+        if touts > 0:
+            if out_mode == 0:
+                surf = torch.empty((n_rows, touts, self.Q, 5, 5), dtype=torch.float32, device=dev)
+            else:
+                surf = torch.empty((n_rows // S, touts, self.Q * 25, S), dtype=torch.float32, device=dev)
+            if self.X > 0:
+                ex = torch.empty((n_rows, touts, self.X), dtype=torch.float32, device=dev)
+        ws = self._ws(self.lib.vsv_decode_ws_bytes(C.byref(self.dims), n_rows, T, t_out0))
+        with torch.cuda.device(self.device):
+            rc = self.lib.vsv_decode(C.byref(self.dims), _ptr(self.packed), C.byref(din), n_rows, T, t_out0,
+                                     _ptr(state), _ptr(z), _ptr(surf), out_mode, _ptr(ex),
+                                     _ptr(ws), ws.numel(), self._stream())
+        _lib.check(rc, "vsv_decode")
+        return {"surf": surf, "ex": ex, "state": state, "z": z}
+
+    # -- reduction / noise ---------------------------------------------------
+    def percentile(self, samples: torch.Tensor, qs: Sequence[float] = (5, 50, 95), inner: int = 25) -> torch.Tensor:
+        """samples (..., inner-multiple, S) sample-minor -> (n_vec/inner, nq, inner)."""
+        samples = _f32c(samples, self.device)
+        S = samples.shape[-1]
+        n_vec = samples.numel() // S
+        q = (C.c_double * len(qs))(*[float(x) for x in qs])
+        out = torch.empty((n_vec // inner, len(qs), inner), dtype=torch.float32, device=self.device)
+        with torch.cuda.device(self.device):
+            rc = self.lib.vsv_percentile(_ptr(samples), n_vec, S, q, len(qs), inner, _ptr(out), self._stream())
+        _lib.check(rc, "vsv_percentile")
+        return out
+
+    def philox_normal(self, seed: int, day0: int, n_days: int, S: int, step0: int, n_steps: int) -> torch.Tensor:
+        out = torch.empty((n_days * S, n_steps, self.L), dtype=torch.float32, device=self.device)
+        with torch.cuda.device(self.device):
+            rc = self.lib.vsv_philox_normal(seed & (2 ** 64 - 1), day0, n_days, S, step0, n_steps, self.L,
+                                            _ptr(out), self._stream())
+        _lib.check(rc, "vsv_philox_normal")
+        return out

@@ -1,0 +1,132 @@
+"""ctypes binding of libvsv_hip.so (the C ABI declared in include/vsv_hip.h).
+
+Fails loudly: importing works anywhere (so the CPU test-suite can check the
+exported symbols), but every compute call requires the library AND a GPU --
+there is no CPU fallback in the product path.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(os.path.dirname(_HERE), "lib", "libvsv_hip.so")
+
+VSV_MAX_CONV = 4
+
+
+class VsvDims(C.Structure):
+    _fields_ = [
+        ("latent_dim", C.c_int), ("ex_feats_dim", C.c_int), ("mem_hidden", C.c_int),
+        ("mem_layers", C.c_int), ("n_conv", C.c_int), ("surface_hidden", C.c_int * VSV_MAX_CONV),
+        ("n_ctx_conv", C.c_int), ("ctx_surface_hidden", C.c_int * VSV_MAX_CONV),
+        ("n_quantiles", C.c_int),
+    ]
+
+
+_FP = C.POINTER(C.c_float)
+
+
+class VsvLstmRaw(C.Structure):
+    _fields_ = [("w_ih", _FP * 2), ("w_hh", _FP * 2), ("b_ih", _FP * 2), ("b_hh", _FP * 2)]
+
+
+class VsvRawWeights(C.Structure):
+    _fields_ = [
+        ("enc_conv_w", _FP * VSV_MAX_CONV), ("enc_conv_b", _FP * VSV_MAX_CONV),
+        ("enc_mem", VsvLstmRaw),
+        ("z_mean_w", _FP), ("z_mean_b", _FP), ("z_log_var_w", _FP), ("z_log_var_b", _FP),
+        ("ctx_conv_w", _FP * VSV_MAX_CONV), ("ctx_conv_b", _FP * VSV_MAX_CONV),
+        ("ctx_mem", VsvLstmRaw),
+        ("ctx_comp_w", _FP), ("ctx_comp_b", _FP),
+        ("dec_mem", VsvLstmRaw),
+        ("dec_in_w", _FP), ("dec_in_b", _FP),
+        ("dec_deconv_w", _FP * VSV_MAX_CONV), ("dec_deconv_b", _FP * VSV_MAX_CONV),
+        ("dec_out_w", _FP), ("dec_out_b", _FP),
+        ("ex_in_w", _FP), ("ex_in_b", _FP), ("ex_out_w", _FP), ("ex_out_b", _FP),
+    ]
+
+
+class VsvDecodeIn(C.Structure):
+    _fields_ = [
+        ("ctx", C.c_void_p), ("ctx_rs", C.c_long), ("ctx_T", C.c_int), ("ctx_div", C.c_long),
+        ("zb", C.c_void_p), ("lv", C.c_void_p), ("z_rs", C.c_long), ("z_T", C.c_int), ("z_div", C.c_long),
+        ("mu0", C.c_float), ("std0", C.c_float),
+        ("eps_in", C.c_void_p), ("eps_T", C.c_int), ("eps_t0", C.c_int),
+        ("seed", C.c_uint64), ("S", C.c_long), ("day0", C.c_long), ("step0", C.c_int),
+        ("state_in", C.c_void_p), ("state_div", C.c_long),
+    ]
+
+
+# name -> (restype, argtypes); the full list of symbols include/vsv_hip.h declares
+SIGNATURES = {
+    "vsv_abi_version": (C.c_int, []),
+    "vsv_last_error": (C.c_char_p, []),
+    "vsv_packed_floats": (C.c_size_t, [C.POINTER(VsvDims)]),
+    "vsv_pack_weights": (C.c_int, [C.POINTER(VsvDims), C.POINTER(VsvRawWeights), _FP]),
+    "vsv_encode_ws_bytes": (C.c_size_t, [C.POINTER(VsvDims), C.c_long, C.c_int]),
+    "vsv_encode": (C.c_int, [C.POINTER(VsvDims), C.c_void_p, C.c_int,
+                             C.c_void_p, C.c_long, C.c_long, C.c_void_p, C.c_long, C.c_long,
+                             C.c_long, C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "vsv_state_floats": (C.c_size_t, [C.POINTER(VsvDims)]),
+    "vsv_decode_ws_bytes": (C.c_size_t, [C.POINTER(VsvDims), C.c_long, C.c_int, C.c_int]),
+    "vsv_decode": (C.c_int, [C.POINTER(VsvDims), C.c_void_p, C.POINTER(VsvDecodeIn),
+                             C.c_long, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
+                             C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "vsv_percentile": (C.c_int, [C.c_void_p, C.c_long, C.c_int, C.POINTER(C.c_double), C.c_int,
+                                 C.c_int, C.c_void_p, C.c_void_p]),
+    "vsv_debug_layout": (C.c_int, [C.POINTER(VsvDims), C.POINTER(C.c_longlong), C.c_int]),
+    "vsv_philox_normal": (C.c_int, [C.c_uint64, C.c_long, C.c_long, C.c_long, C.c_int, C.c_int,
+                                    C.c_int, C.c_void_p, C.c_void_p]),
+}
+
+_lib: Optional[C.CDLL] = None
+
+
+def load() -> C.CDLL:
+    """dlopen the in-tree library and attach the signatures.  Raises if the
+    library has not been built (python __graft_entry__.py / make -C csrc)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f"{LIB_PATH} is missing: build it with `make -C vol-surface-vae-pub_amd/csrc` "
+                "(there is no CPU fallback for the HIP path)")
+        lib = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(lib, name)
+            fn.restype = res
+            fn.argtypes = args
+        if lib.vsv_abi_version() != 1:
+            raise RuntimeError("libvsv_hip.so ABI version mismatch")
+        _lib = lib
+    return _lib
+
+
+class VsvError(RuntimeError):
+    pass
+
+
+def check(rc: int, what: str) -> None:
+    if rc != 0:
+        msg = load().vsv_last_error().decode("utf-8", "replace")
+        if rc < 0:
+            raise ValueError(f"{what}: {msg}")
+        raise VsvError(f"{what}: HIP error {rc}: {msg}")
+
+
+def make_dims(latent_dim, ex_feats_dim, mem_hidden, mem_layers, surface_hidden, ctx_surface_hidden,
+              n_quantiles) -> VsvDims:
+    d = VsvDims()
+    d.latent_dim, d.ex_feats_dim, d.mem_hidden, d.mem_layers = latent_dim, ex_feats_dim, mem_hidden, mem_layers
+    if len(surface_hidden) > VSV_MAX_CONV or len(ctx_surface_hidden) > VSV_MAX_CONV:
+        raise NotImplementedError("at most 4 conv layers are supported by the HIP path")
+    d.n_conv = len(surface_hidden)
+    d.n_ctx_conv = len(ctx_surface_hidden)
+    for i, c in enumerate(surface_hidden):
+        d.surface_hidden[i] = int(c)
+    for i, c in enumerate(ctx_surface_hidden):
+        d.ctx_surface_hidden[i] = int(c)
+    d.n_quantiles = n_quantiles
+    return d

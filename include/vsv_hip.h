@@ -158,6 +158,13 @@ int vsv_percentile(const float *in, long n_vec, int S, const double *q_host, int
 int vsv_philox_normal(uint64_t seed, long day0, long n_days, long S, int step0, int n_steps,
                       int L, float *out, void *stream);
 
+/* ---- profiling aid -----------------------------------------------------------------
+ * Arms the NEXT vsv_decode call made by this thread: it records the two hipEvent_t
+ * (created by the caller with timing enabled) on the call's stream immediately before
+ * and after its decoder-LSTM kernel launch, so a benchmark can time that kernel live.
+ * Pass NULLs to disarm.  No counterpart in the reference. */
+void vsv_profile_next_decode(void *ev_start, void *ev_stop);
+
 /* ---- diagnostics ------------------------------------------------------------------
  * Dumps the packed-blob layout (offsets and tile counts per layer) so a host-side
  * test can decode the fragments without a GPU.  No counterpart in the reference. */

@@ -1,0 +1,116 @@
+"""CPU checks of the drop-in model class: checkpoint contract (state_dict keys and
+shapes of SURVEY appendix A), config mutation and error behaviour of the
+reference (cvae_with_mem_randomized.py:969-1020, :581, :1043), the C-ABI symbol
+table, and the device-side gather packing.  No compute call needs a GPU here."""
+import ctypes as C
+import re
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import vsv_oracle as vo
+
+
+def _model(cfg):
+    from vae.cvae_with_mem_randomized import CVAEMemRand
+    return CVAEMemRand(cfg)
+
+
+@pytest.mark.parametrize("L,X,NL", [(5, 0, 2), (5, 3, 2), (12, 3, 2), (5, 0, 1)])
+def test_state_dict_contract(L, X, NL):
+    cfg = vo.make_config(L, X, mem_layers=NL)
+    m = _model(cfg)
+    sd = m.state_dict()
+    spec = vo.state_dict_spec(cfg)
+    want = [n for n, _ in spec] + ["quantile_loss_fn.quantiles", "quantile_loss_fn.weights"]
+    assert list(sd.keys()) == want
+    for n, shape in spec:
+        assert tuple(sd[n].shape) == shape, n
+    assert sd["quantile_loss_fn.quantiles"].dtype == torch.float64
+    if NL == 2:
+        assert len(sd) == (58 if X else 54)
+        total = sum(p.numel() for p in m.parameters())
+        assert total == {(5, 0): 556813, (5, 3): 569263, (12, 3): 578552}[(L, X)]
+    # a reference-shaped checkpoint loads strictly
+    W = vo.init_weights(cfg, 3)
+    ck = {k: torch.from_numpy(v) for k, v in W.items()}
+    ck["quantile_loss_fn.quantiles"] = sd["quantile_loss_fn.quantiles"]
+    ck["quantile_loss_fn.weights"] = sd["quantile_loss_fn.weights"]
+    m.load_weights(dict_to_load={"model": ck})
+    assert torch.equal(m.decoder.mem.weight_hh_l0, ck["decoder.mem.weight_hh_l0"])
+
+
+def test_config_defaults_and_mutation():
+    cfg = {"feat_dim": (5, 5), "latent_dim": 5, "device": "cpu", "kl_weight": 1e-5, "surface_hidden": [5, 5, 5],
+           "ex_feats_dim": 0, "mem_hidden": 100, "mem_layers": 2, "ctx_surface_hidden": [5, 5, 5],
+           "compress_context": True}
+    m = _model(cfg)
+    assert m.config is cfg
+    assert cfg["padding"] == 1 and cfg["deconv_output_padding"] == 0 and cfg["num_quantiles"] == 3
+    assert cfg["mem_type"] == "lstm" and cfg["ex_feats_loss_type"] == "l1" and cfg["re_feat_weight"] == 1.0
+    assert m.horizon == 1 and m.kl_weight == 1e-5 and m.device == "cpu"
+    assert isinstance(m.ex_feats_loss_fn, torch.nn.L1Loss)
+    assert hasattr(m.encoder, "mem") and hasattr(m.ctx_encoder, "final_compression")
+    assert m.count_parameters()["num_params"].iloc[-1] == 556813
+
+
+def test_reference_error_behaviour():
+    base = vo.make_config(5, 0)
+    with pytest.raises(KeyError):                       # kl_weight is read before defaulting (base.py:38)
+        _model({k: v for k, v in base.items() if k != "kl_weight"})
+    with pytest.raises(ValueError):
+        _model({k: v for k, v in base.items() if k != "mem_hidden"})
+    with pytest.raises(ValueError):
+        _model(dict(base, horizon=0))
+    with pytest.raises(TypeError):
+        _model(dict(base, ex_feats_hidden=[4]))
+    m = _model(dict(base))
+    with pytest.raises(RuntimeError, match="GPU"):      # product path fails loudly without a GPU
+        m.get_surface_given_conditions({"surface": torch.zeros(1, 5, 5, 5)})
+    with pytest.raises(ValueError):
+        m.generate_autoregressive_sequence({"ex_feats": torch.zeros(1, 5, 3)})
+    with pytest.raises(ValueError):
+        m.generate_autoregressive_offset({"surface": torch.zeros(1, 5, 5, 5)})   # context_len defaults to 60
+
+
+def test_quantile_loss_module_matches_reference_values():
+    from vae.cvae_with_mem_randomized import QuantileLoss
+    from conftest import load_golden
+    g = load_golden("g3_quantile_loss")
+    p, t = torch.from_numpy(g["preds"]), torch.from_numpy(g["target"])
+    assert abs(QuantileLoss()(p, t).item() - float(g["loss_w111"])) < 1e-7
+    assert abs(QuantileLoss(weights=[5.0, 1.0, 5.0])(p, t).item() - float(g["loss_w515"])) < 1e-7
+    assert QuantileLoss()(torch.ones(2, 1, 3, 5, 5), torch.ones(2, 1, 5, 5)).item() == 0.0
+    assert QuantileLoss()(p, t).dtype == torch.float64
+
+
+def test_library_exports_every_declared_symbol():
+    import os
+    from vsv import lib as vlib
+    here = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    text = open(os.path.join(here, "include", "vsv_hip.h")).read()
+    declared = set(re.findall(r"\b(vsv_[a-z_0-9]+)\s*\(", text))
+    assert declared == set(vlib.SIGNATURES), declared ^ set(vlib.SIGNATURES)
+    L = vlib.load()
+    for name in declared:
+        assert hasattr(L, name), name
+    assert L.vsv_abi_version() == 1
+    # argument validation happens before any GPU work
+    d = vlib.make_dims(5, 0, 100, 2, [5, 5, 5], [5, 5, 5], 3)
+    assert L.vsv_packed_floats(C.byref(d)) > 0
+    bad = vlib.make_dims(40, 0, 100, 2, [5, 5, 5], [5, 5, 5], 3)
+    assert L.vsv_packed_floats(C.byref(bad)) == 0
+    assert b"latent_dim" in L.vsv_last_error()
+
+
+@pytest.mark.parametrize("L,X", [(5, 0), (12, 3)])
+def test_gather_maps_reproduce_host_packing(L, X):
+    from vsv.engine import build_gather_maps, dims_from_config, pack_state_dict
+    cfg = vo.make_config(L, X)
+    W = vo.init_weights(cfg, 9, 2.0)
+    dims = dims_from_config(cfg)
+    spec = vo.state_dict_spec(cfg)
+    ia, ib = build_gather_maps(dims, spec)
+    flat = np.concatenate([[0.0]] + [W[n].ravel() for n, _ in spec]).astype(np.float32)
+    assert np.array_equal(flat[ia] + flat[ib], pack_state_dict(dims, W))

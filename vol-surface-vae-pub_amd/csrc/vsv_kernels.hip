@@ -538,6 +538,8 @@ static int launch_lstm(const LstmSeqArgs& a, int NT, int NL, hipStream_t st) {
 #undef VSV_CASE
 }
 
+static thread_local hipEvent_t g_prof_ev[2] = {nullptr, nullptr};
+
 static void fill_dense(DenseChainArgs& a, int li, const float* packed, const Sec& s) {
     a.layer[li].w = packed + s.w_off;
     a.layer[li].b = packed + s.b_off;
@@ -663,7 +665,11 @@ extern "C" int vsv_decode(const vsv_dims* dims, const float* packed, const vsv_d
     l.state_out = state_out;
     l.hout = touts > 0 ? hbuf : nullptr;
     l.t_out0 = t_out0;
+    hipEvent_t ev0 = g_prof_ev[0], ev1 = g_prof_ev[1];
+    g_prof_ev[0] = g_prof_ev[1] = nullptr;
+    if (ev0) (void)hipEventRecord(ev0, st);
     int rc = launch_lstm<1>(l, lay.NTd, lay.NL, st);
+    if (ev1) (void)hipEventRecord(ev1, st);
     if (rc || touts == 0) return rc;
 
     DenseChainArgs a = {};
@@ -675,6 +681,11 @@ extern "C" int vsv_decode(const vsv_dims* dims, const float* packed, const vsv_d
     a.aux_layer = (lay.X > 0 && ex_out) ? dc.ex_layer : -1;
     a.aux = ex_out; a.aux_f0 = dc.ex_f0; a.aux_n = lay.X;
     return launch_dense_chain(a, st);
+}
+
+extern "C" void vsv_profile_next_decode(void* ev_start, void* ev_stop) {
+    g_prof_ev[0] = (hipEvent_t)ev_start;
+    g_prof_ev[1] = (hipEvent_t)ev_stop;
 }
 
 extern "C" int vsv_percentile(const float* in, long n_vec, int S, const double* q_host, int nq,

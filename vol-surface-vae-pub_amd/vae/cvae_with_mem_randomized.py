@@ -1,0 +1,528 @@
+"""CVAEMemRand on MI355X: drop-in for the reference class
+/root/reference/vae/cvae_with_mem_randomized.py:516 (same constructor/config
+contract, same state_dict keys and shapes, same method signatures and return
+types), with every forward computation executed by the hand-written gfx950
+kernels of libvsv_hip.so through its C ABI (vsv/engine.py).
+
+The torch.nn layers held by the three sub-modules are PARAMETER CONTAINERS: they
+give the model the reference's parameter names, shapes, default initialisation and
+checkpoint compatibility, but their own forward() is never called.  There is no
+CPU fallback: calling a compute method without a GPU raises.
+
+Implemented topology (what every config in the reference repo uses): conv surface
+embedding, mem_type="lstm", compress_context=True, interaction_layers=None,
+ex_feats_hidden=None.  Other switches parse and then raise NotImplementedError
+at the first compute call.
+"""
+from __future__ import annotations
+
+import weakref
+from collections import OrderedDict
+from typing import Dict, Optional, Tuple, Union
+
+import torch
+import torch.nn as nn
+
+from vae.base import BaseDecoder, BaseEncoder, BaseVAE
+
+
+class QuantileLoss(nn.Module):
+    """Pinball loss (reference :9-45): for each quantile q_i,
+    mean(max((q_i-1)*e, q_i*e)) with e = target - pred[:, :, i]; weighted mean over
+    quantiles.  Buffers are float64 like the reference's, so the result is float64."""
+
+    def __init__(self, quantiles=[0.05, 0.5, 0.95], weights=None):
+        super().__init__()
+        self.register_buffer("quantiles", torch.tensor(quantiles, dtype=torch.float64))
+        w = [1.0] * len(quantiles) if weights is None else weights
+        self.register_buffer("weights", torch.tensor(w, dtype=torch.float64))
+
+    def forward(self, preds, target):
+        q = self.quantiles.to(preds.device).view(1, 1, -1, 1, 1)
+        e = (target.unsqueeze(2) - preds).to(torch.float64)
+        per_q = torch.maximum((q - 1) * e, q * e).mean(dim=(0, 1, 3, 4))
+        w = self.weights.to(preds.device)
+        return torch.sum(per_q * w) / torch.sum(w)
+
+
+# ---------------------------------------------------------------------------
+# parameter containers
+# ---------------------------------------------------------------------------
+
+def _conv_stack(prefix: str, channels, padding: int) -> nn.Sequential:
+    """{prefix}_conv_i / {prefix}_activation_i / flatten -- the registration names the
+    reference's state_dict uses (:96-107, :248-259)."""
+    layers = OrderedDict()
+    cin = 1
+    for i, cout in enumerate(channels):
+        layers[f"{prefix}_conv_{i}"] = nn.Conv2d(cin, cout, kernel_size=3, stride=1, padding=padding)
+        layers[f"{prefix}_activation_{i}"] = nn.ReLU()
+        cin = cout
+    layers["flatten"] = nn.Flatten()
+    return nn.Sequential(layers)
+
+
+def _memory(config: dict, input_size: int, hidden_size: int) -> nn.Module:
+    kind = {"lstm": nn.LSTM, "gru": nn.GRU}.get(config["mem_type"], nn.RNN)
+    return kind(input_size=input_size, hidden_size=hidden_size, num_layers=config["mem_layers"],
+                batch_first=True, dropout=config["mem_dropout"])
+
+
+def _interaction(config: dict, prefix: str, act_prefix: str, width: int) -> nn.Module:
+    n = config["interaction_layers"]
+    if n is None or n <= 0:
+        return nn.Identity()
+    layers = OrderedDict()
+    for i in range(n):
+        layers[f"{prefix}_linear_{i}"] = nn.Linear(width, width)
+        layers[f"{act_prefix}_activation_{i}"] = nn.ReLU()
+    layers[f"{prefix}_linear_final"] = nn.Linear(width, width)
+    return nn.Sequential(layers)
+
+
+def _dense_stack(prefix: str, sizes, in_feats: int) -> Tuple[nn.Sequential, int]:
+    layers = OrderedDict()
+    layers["flatten"] = nn.Flatten()
+    for i, out in enumerate(sizes):
+        layers[f"{prefix}_dense_{i}"] = nn.Linear(in_feats, out)
+        layers[f"{prefix}_activation_{i}"] = nn.ReLU()
+        in_feats = out
+    return nn.Sequential(layers), in_feats
+
+
+class _HipSubmodule:
+    """Mixin: reach the owning CVAEMemRand (and through it the kernel engine)
+    without registering it as a child module."""
+
+    def _owner(self) -> "CVAEMemRand":
+        ref = self.__dict__.get("_vsv_owner")
+        owner = ref() if ref is not None else None
+        if owner is None:
+            raise RuntimeError("this sub-module is not attached to a CVAEMemRand; the HIP path "
+                               "needs the full model (weights are packed per model)")
+        return owner
+
+
+class CVAEMemRandEncoder(BaseEncoder, _HipSubmodule):
+    """Posterior encoder (reference :48-200): conv embedding of every day, optional
+    ex-features appended, LSTM over time, z_mean / z_log_var heads, z sampled at
+    every position."""
+
+    def __init__(self, config: dict):
+        super().__init__(config)
+        fh, fw = config["feat_dim"]
+        hidden = config["surface_hidden"]
+        if config["use_dense_surface"]:
+            self.surface_embedding, surf_dim = _dense_stack("enc", hidden, fh * fw)
+        else:
+            self.surface_embedding = _conv_stack("enc", hidden, config["padding"])
+            surf_dim = hidden[-1] * fh * fw
+        ex_dim = 0
+        if config["ex_feats_dim"] > 0:
+            if config["ex_feats_hidden"] is not None:
+                raise NotImplementedError("ex_feats_hidden must be None (the reference's non-None branch is untested, :121)")
+            self.ex_feats_embedding = nn.Identity()
+            ex_dim = config["ex_feats_dim"]
+        self.interaction = _interaction(config, "enc_interact", "enc_interaction", surf_dim + ex_dim)
+        self.mem = _memory(config, surf_dim + ex_dim, config["mem_hidden"])
+        self.z_mean_layer = nn.Linear(config["mem_hidden"], config["latent_dim"])
+        self.z_log_var_layer = nn.Linear(config["mem_hidden"], config["latent_dim"])
+
+    def forward(self, x):
+        """x: {"surface": (B,T,H,W)[, "ex_feats": (B,T,n)]} -> (z_mean, z_log_var, z), each (B,T,L)."""
+        return self._owner()._encode_posterior(x)
+
+
+class CVAECtxMemRandEncoder(BaseEncoder, _HipSubmodule):
+    """Context encoder (reference :202-344): same stack, deterministic, followed by
+    the final_compression Linear when compress_context is set."""
+
+    def __init__(self, config: dict):
+        super().__init__(config)
+        fh, fw = config["feat_dim"]
+        hidden = config["ctx_surface_hidden"]
+        if config["use_dense_surface"]:
+            self.ctx_surface_embedding, surf_dim = _dense_stack("ctx_enc", hidden, fh * fw)
+        else:
+            self.ctx_surface_embedding = _conv_stack("ctx_enc", hidden, config["padding"])
+            surf_dim = hidden[-1] * fh * fw
+        ex_dim = 0
+        if config["ex_feats_dim"] > 0:
+            if config["ctx_ex_feats_hidden"] is not None:
+                raise NotImplementedError("ctx_ex_feats_hidden must be None")
+            self.ctx_ex_feats_embedding = nn.Identity()
+            ex_dim = config["ex_feats_dim"]
+        self.interaction = _interaction(config, "ctx_interact", "ctx_interaction", surf_dim + ex_dim)
+        self.mem = _memory(config, surf_dim + ex_dim, config["mem_hidden"])
+        if config["compress_context"]:
+            self.final_compression = nn.Linear(config["mem_hidden"], config["latent_dim"])
+        else:
+            self.final_compression = nn.Identity()
+
+    def forward(self, x):
+        """x: {"surface": (B,C,H,W)[, "ex_feats": (B,C,n)]} -> context embedding (B,C,L)."""
+        return self._owner()._encode_context(x)
+
+
+class CVAEMemRandDecoder(BaseDecoder, _HipSubmodule):
+    """Decoder (reference :346-514): LSTM on cat([ctx embedding, z]) -> Linear ->
+    ConvTranspose+ReLU stack -> Conv to Q quantile channels; ex-features through two
+    Linears when ex_feats_dim > 0."""
+
+    def __init__(self, config: dict):
+        super().__init__(config)
+        fh, fw = config["feat_dim"]
+        hidden = config["surface_hidden"]
+        L = config["latent_dim"]
+        ctx_dim = L if config["compress_context"] else config["mem_hidden"]
+        self.surface_final_hidden_size = hidden[-1]
+        self.n_info = self.ex_feats_final_hidden_size = config["ex_feats_dim"]
+        self.n_surface = hidden[-1] if config["use_dense_surface"] else hidden[-1] * fh * fw
+        width = self.n_surface + self.n_info
+        self.mem = _memory(config, L + ctx_dim, width)
+        self.interaction = _interaction(config, "dec_interact", "dec_interaction", width)
+        self.surface_decoder_input = nn.Linear(width, self.n_surface)
+        Q = config.get("num_quantiles", 3)
+        layers = OrderedDict()
+        cin = hidden[-1]
+        if config["use_dense_surface"]:
+            for i, cout in enumerate(reversed(hidden[:-1])):
+                layers[f"dec_dense_{i}"] = nn.Linear(cin, cout)
+                layers[f"dec_activation_{i}"] = nn.ReLU()
+                cin = cout
+            layers["dec_final"] = nn.Linear(cin, fh * fw)
+            layers["dec_final_activation"] = nn.ReLU()
+            layers["dec_output"] = nn.Linear(fh * fw, fh * fw * Q)
+        else:
+            pad, opad = config["padding"], config["deconv_output_padding"]
+            for i, cout in enumerate(reversed(hidden[:-1])):
+                layers[f"dec_deconv_{i}"] = nn.ConvTranspose2d(cin, cout, kernel_size=3, stride=1,
+                                                              padding=pad, output_padding=opad)
+                layers[f"dec_activation_{i}"] = nn.ReLU()
+                cin = cout
+            layers["dec_final"] = nn.ConvTranspose2d(cin, cin, kernel_size=3, stride=1,
+                                                     padding=pad, output_padding=opad)
+            layers["dec_final_activation"] = nn.ReLU()
+            layers["dec_output"] = nn.Conv2d(cin, Q, kernel_size=3, padding="same")
+        self.surface_decoder = nn.Sequential(layers)
+        if self.n_info > 0:
+            self.ex_feats_decoder_input = nn.Linear(width, self.n_info)
+            self.ex_feats_decoder = nn.Linear(config["ex_feats_dim"], config["ex_feats_dim"])
+
+    def forward(self, x):
+        """x: (B,T,ctx_dim+L) = cat([padded ctx embedding, z]) -> (B,T,Q,H,W)[, (B,T,n)]."""
+        return self._owner()._decode(x)
+
+
+# ---------------------------------------------------------------------------
+# the model
+# ---------------------------------------------------------------------------
+
+class CVAEMemRand(BaseVAE):
+    def __init__(self, config: dict):
+        super().__init__(config)
+        self.check_input(config)
+        if not config["use_dense_surface"]:
+            # 'same' 3x3 convolution on the grid (reference :545-558): for the 5x5 grid
+            # padding = 1 and no output padding
+            extra = 3 - 1          # (out-1)*stride + kernel - in, stride 1
+            config["padding"] = extra // 2 + extra % 2
+            config["deconv_output_padding"] = extra % 2
+        self.encoder = CVAEMemRandEncoder(config)
+        self.ctx_encoder = CVAECtxMemRandEncoder(config)
+        self.decoder = CVAEMemRandDecoder(config)
+        self.ex_feats_loss_fn = nn.MSELoss() if config["ex_feats_loss_type"] == "l2" else nn.L1Loss()
+        self.quantile_loss_fn = QuantileLoss(quantiles=config["quantiles"],
+                                             weights=config.get("quantile_loss_weights"))
+        for sub in (self.encoder, self.ctx_encoder, self.decoder):
+            sub.__dict__["_vsv_owner"] = weakref.ref(self)
+        self.to(self.device)
+        self.horizon = config.get("horizon", 1)
+        if self.horizon < 1:
+            raise ValueError(f"horizon must be >= 1, got {self.horizon}")
+        self.__dict__["_vsv_engine"] = None
+        self.__dict__["_vsv_key"] = None
+
+    # -- config ------------------------------------------------------------
+    def check_input(self, config: dict):
+        """Validation and defaulting of the reference (:969-1020); mutates config."""
+        for req in ("feat_dim", "latent_dim"):
+            if req not in config:
+                raise ValueError(f"config doesn't contain: {req}")
+        config.setdefault("device", "cuda" if torch.cuda.is_available() else "cpu")
+        config.setdefault("kl_weight", 1.0)
+        for req in ("surface_hidden", "ex_feats_dim", "mem_hidden", "mem_layers", "ctx_surface_hidden"):
+            if req not in config:
+                raise ValueError(f"config doesn't contain {req}")
+        for key in ("surface_hidden", "ctx_surface_hidden"):
+            if isinstance(config[key], int):
+                config[key] = [config[key]]
+        for key in ("ex_feats_hidden", "ctx_ex_feats_hidden"):
+            config.setdefault(key, None)
+            if config[key] is not None:
+                # the reference calls isinstance() with one argument here (:991/:993)
+                raise TypeError("isinstance expected 2 arguments, got 1")
+        defaults = {"mem_type": "lstm", "mem_dropout": 0, "re_feat_weight": 1.0, "ex_feats_loss_type": "l1",
+                    "ex_loss_on_ret_only": False, "interaction_layers": None, "use_dense_surface": False,
+                    "compress_context": False, "quantiles": [0.05, 0.5, 0.95]}
+        for k, v in defaults.items():
+            config.setdefault(k, v)
+        config["num_quantiles"] = len(config["quantiles"])
+
+    # -- engine plumbing -------------------------------------------------------
+    def _param_dtype(self):
+        return self.encoder.z_mean_layer.weight.dtype
+
+    def _hip_named_params(self):
+        return [(n, p) for n, p in self.named_parameters()]
+
+    def _engine(self):
+        """The kernel engine with weights packed from the CURRENT parameters
+        (re-packed on device whenever a parameter changed)."""
+        from vsv.engine import Engine
+        dev = torch.device(self.device)
+        if dev.type != "cuda" or not torch.cuda.is_available():
+            raise RuntimeError("CVAEMemRand (MI355X build) computes only on a GPU: config['device'] must be "
+                               "a cuda/ROCm device and libvsv_hip.so must be built; there is no CPU fallback")
+        if dev.index is None:
+            dev = torch.device("cuda", torch.cuda.current_device())
+        eng = self.__dict__["_vsv_engine"]
+        if eng is None:
+            eng = Engine(self.config, None, dev)
+            self.__dict__["_vsv_engine"] = eng
+        params = self._hip_named_params()
+        key = tuple((p.data_ptr(), p._version) for _, p in params)
+        if key != self.__dict__["_vsv_key"]:
+            with torch.no_grad():
+                eng.set_weights_from_params(params)
+            self.__dict__["_vsv_key"] = key
+        return eng
+
+    @staticmethod
+    def _draw_seed() -> int:
+        """A Philox key drawn from torch's global generator, so set_seeds() makes
+        the on-device noise reproducible (the reference uses torch.randn here)."""
+        return int(torch.randint(0, 2 ** 62, (1,)).item())
+
+    def _batched(self, x: Dict[str, torch.Tensor]):
+        surf = x["surface"].to(self.device)
+        if surf.dim() == 3:
+            surf = surf.unsqueeze(0)
+        ex = None
+        if "ex_feats" in x:
+            ex = x["ex_feats"].to(self.device)
+            if ex.dim() == 2:
+                ex = ex.unsqueeze(0)
+        return surf, ex
+
+    # -- sub-module entry points (analysis scripts call these directly) --------
+    def _encode_posterior(self, x):
+        from vsv import paths
+        eng = self._engine()
+        surf, ex = self._batched(x)
+        zm, zl = paths.encode_both(eng, surf, ex)
+        eps = eng.philox_normal(self._draw_seed(), 0, zm.shape[0], 1, 0, zm.shape[1])
+        z = zm + torch.exp(0.5 * zl) * eps
+        dt = self._param_dtype()
+        return zm.to(dt), zl.to(dt), z.to(dt)
+
+    def _encode_context(self, x):
+        eng = self._engine()
+        surf, ex = self._batched(x)
+        return eng.encode(1, surf, ex).to(self._param_dtype())
+
+    def _decode(self, dec_in: torch.Tensor):
+        eng = self._engine()
+        L = eng.L
+        dec_in = dec_in.to(self.device)
+        B, T = dec_in.shape[:2]
+        r = eng.decode(B, T, 0, ctx=dec_in[..., :L].contiguous(), zb=dec_in[..., L:].contiguous())
+        dt = self._param_dtype()
+        if eng.X > 0:
+            return r["surf"].to(dt), r["ex"].to(dt)
+        return r["surf"].to(dt)
+
+    # -- forward / generation ------------------------------------------------------
+    def forward(self, x: Dict[str, torch.Tensor]):
+        """Reference :1022-1074.  Returns (recon (B,H,Q,5,5)[, ex (B,H,n)], z_mean, z_log_var, z)."""
+        from vsv import paths
+        surf, ex = self._batched(x)
+        T = surf.shape[1]
+        C = T - self.horizon
+        if C < 1:
+            raise ValueError(f"Insufficient sequence length: T={T}, horizon={self.horizon}, "
+                             f"resulting in C={C}. Need at least C >= 1.")
+        eng = self._engine()
+        s, e, zm, zl, z = paths.forward(eng, surf, ex, self.horizon, seed=self._draw_seed())
+        dt = self._param_dtype()
+        if ex is not None:
+            return s.to(dt), e.to(dt), zm.to(dt), zl.to(dt), z.to(dt)
+        return s.to(dt), zm.to(dt), zl.to(dt), z.to(dt)
+
+    def load_fitted_prior(self, prior_params_path: str):
+        """GMM fitted to the aggregated posterior (reference :583-603; file written by
+        analysis_code/fit_aggregated_posterior.py:139-155)."""
+        params = torch.load(prior_params_path, map_location=self.device)
+        fp = {k: params[k].to(self.device).to(torch.float64) for k in ("means", "covariances", "weights")}
+        fp["n_components"] = params["n_components"]
+        fp["cholesky"] = torch.linalg.cholesky(fp["covariances"])
+        self.fitted_prior = fp
+        print(f"Loaded fitted prior with {params['n_components']} components from {prior_params_path}")
+
+    def _sample_from_fitted_prior(self, batch_size: int, seq_len: int) -> torch.Tensor:
+        """Reference :605-640: component ~ multinomial(weights), z = mean + chol @ eps."""
+        fp = getattr(self, "fitted_prior", None)
+        if fp is None:
+            raise ValueError("Fitted prior not loaded. Call load_fitted_prior() first.")
+        n, L = batch_size * seq_len, self.config["latent_dim"]
+        comp = torch.multinomial(fp["weights"].expand(n, -1), num_samples=1).squeeze(-1)
+        eps = torch.randn(n, L, device=self.device, dtype=torch.float64)
+        z = fp["means"][comp] + torch.einsum("bij,bj->bi", fp["cholesky"][comp], eps)
+        return z.reshape(batch_size, seq_len, L)
+
+    def get_surface_given_conditions(self, c: Dict[str, torch.Tensor], z: torch.Tensor = None, mu=0, std=1,
+                                     horizon=None, prior_mode="standard"):
+        """Prior generation (reference :642-715): context positions use the posterior
+        mean, future positions z ~ N(mu, std) (or the fitted GMM, or the caller's z,
+        whose [:, :C] is overwritten IN PLACE like the reference does at :700).
+        Returns (B,horizon,Q,5,5)[, (B,horizon,n)]."""
+        from vsv import paths
+        surf, ex = self._batched(c)
+        B, C = surf.shape[:2]
+        if ex is not None:
+            assert ex.shape[1] == C, "context length mismatch"
+        if horizon is None:
+            horizon = self.horizon
+        T = C + horizon
+        eng = self._engine()
+        dt = self._param_dtype()
+        if z is None and prior_mode == "fitted":
+            z = self._sample_from_fitted_prior(B, T)
+        if z is not None:
+            if z.dim() == 2:
+                z = z.unsqueeze(0)
+            zm, _ = paths.encode_both(eng, surf, ex)
+            z[:, :C, ...] = zm.to(z.dtype)
+            ctx = eng.encode(1, surf, ex)
+            s, e = paths.decode_given_z(eng, ctx, z, C)
+        else:
+            s, e, _ = paths.prior_generate(eng, surf, ex, horizon, 1, mu=float(mu), std=float(std),
+                                           seed=self._draw_seed())
+        if ex is not None:
+            return s.to(dt), e.to(dt)
+        return s.to(dt)
+
+    def generate_autoregressive_sequence(self, initial_context: Dict[str, torch.Tensor], horizon: int = 30,
+                                         z: Optional[torch.Tensor] = None
+                                         ) -> Union[torch.Tensor, Tuple[torch.Tensor, torch.Tensor]]:
+        """Day-by-day rollout (reference :717-807): each step generates one day from the
+        prior, the p50 channel (and the predicted ex-features) slide into the context.
+        `z` is ignored, as in the reference (:776)."""
+        if "surface" not in initial_context:
+            raise ValueError("initial_context must contain 'surface' key")
+        nd = initial_context["surface"].dim()
+        if nd not in (3, 4):
+            raise ValueError(f"surface must be (C, H, W) or (B, C, H, W), got shape {initial_context['surface'].shape}")
+        has_ex = "ex_feats" in initial_context
+        if has_ex and initial_context["ex_feats"].dim() not in (2, 3):
+            raise ValueError(f"ex_feats must be (C, D) or (B, C, D), got shape {initial_context['ex_feats'].shape}")
+        context = {k: v.clone() if torch.is_tensor(v) else v for k, v in initial_context.items()}
+        surfaces, exs = [], []
+        for _ in range(horizon):
+            result = self.get_surface_given_conditions(context, z=None)
+            pred_s, pred_e = result if has_ex else (result, None)
+            surfaces.append(pred_s)
+            if has_ex:
+                exs.append(pred_e)
+            context = self._update_context(context, pred_s[:, 0, 1, :, :], pred_e[:, 0, :] if has_ex else None)
+        out = torch.cat(surfaces, dim=1)
+        return (out, torch.cat(exs, dim=1)) if has_ex else out
+
+    def generate_autoregressive_offset(self, initial_context: Dict[str, torch.Tensor], ar_steps: int = 3,
+                                       horizon: int = 60, offset: int = 60, z: Optional[torch.Tensor] = None
+                                       ) -> Union[torch.Tensor, Tuple[torch.Tensor, torch.Tensor]]:
+        """Chunked rollout (reference :809-923): ar_steps generations of `horizon` days;
+        the next context is the last C of the concatenated p50 medians."""
+        if "surface" not in initial_context:
+            raise ValueError("initial_context must contain 'surface' key")
+        C = self.config.get("context_len", 60)
+        has_ex = "ex_feats" in initial_context
+        if initial_context["surface"].shape[1] != C:
+            raise ValueError(f"Context length must be {C}, got {initial_context['surface'].shape[1]}")
+        context = {k: v.clone() if torch.is_tensor(v) else v for k, v in initial_context.items()}
+        all_s, all_e, med_s, med_e = [], [], [], []
+        for step in range(ar_steps):
+            saved, self.horizon = self.horizon, horizon
+            try:
+                result = self.get_surface_given_conditions(context, z=None)
+            finally:
+                self.horizon = saved
+            pred_s, pred_e = result if has_ex else (result, None)
+            all_s.append(pred_s)
+            med_s.append(pred_s[:, :, 1, :, :])
+            if has_ex:
+                all_e.append(pred_e)
+                med_e.append(pred_e)
+            if step < ar_steps - 1:
+                context["surface"] = torch.cat(med_s, dim=1)[:, -C:, :, :]
+                if has_ex:
+                    context["ex_feats"] = torch.cat(med_e, dim=1)[:, -C:, :]
+        out = torch.cat(all_s, dim=1)
+        return (out, torch.cat(all_e, dim=1)) if has_ex else out
+
+    def _update_context(self, context: Dict[str, torch.Tensor], new_surface: torch.Tensor,
+                        new_ex_feat: Optional[torch.Tensor] = None) -> Dict[str, torch.Tensor]:
+        """Sliding window: drop the oldest day, append the new one (reference :925-967)."""
+        old = context["surface"]
+        if old.dim() == 3:
+            old = old.unsqueeze(0)
+        updated = {"surface": torch.cat([old[:, 1:], new_surface.to(old.device, old.dtype).unsqueeze(1)], dim=1)}
+        if "ex_feats" in context and new_ex_feat is not None:
+            old_e = context["ex_feats"]
+            if old_e.dim() == 2:
+                old_e = old_e.unsqueeze(0)
+            updated["ex_feats"] = torch.cat([old_e[:, 1:], new_ex_feat.to(old_e.device, old_e.dtype).unsqueeze(1)], dim=1)
+        return updated
+
+    # -- losses / steps --------------------------------------------------------------
+    def _losses(self, x, outputs, horizon):
+        """The loss terms of reference :1113-1125 from forward() outputs."""
+        surface = x["surface"]
+        if surface.dim() == 3:
+            surface = surface.unsqueeze(0)
+        C = surface.shape[1] - horizon
+        surface_real = surface[:, C:].to(self.device)
+        has_ex = "ex_feats" in x
+        if has_ex:
+            recon, ex_recon, z_mean, z_log_var, _ = outputs
+        else:
+            recon, z_mean, z_log_var, _ = outputs
+        re_surface = self.quantile_loss_fn(recon, surface_real)
+        if has_ex:
+            ex = x["ex_feats"]
+            if ex.dim() == 2:
+                ex = ex.unsqueeze(0)
+            ex_real = ex[:, C:].to(self.device)
+            if self.config["ex_loss_on_ret_only"]:
+                ex_recon, ex_real = ex_recon[:, :, :1], ex_real[:, :, :1]
+            re_ex = self.ex_feats_loss_fn(ex_recon, ex_real)
+            recon_err = re_surface + self.config["re_feat_weight"] * re_ex
+        else:
+            re_ex = torch.zeros(1)
+            recon_err = re_surface
+        kl = -0.5 * (1 + z_log_var - torch.exp(z_log_var) - torch.square(z_mean))
+        kl = torch.mean(torch.sum(kl, dim=-1))
+        return {"loss": recon_err + self.kl_weight * kl, "re_surface": re_surface, "re_ex_feats": re_ex,
+                "reconstruction_loss": recon_err, "kl_loss": kl}
+
+    def test_step(self, x):
+        """Reference :1265-1308: forward + losses, returns a dict of tensors."""
+        return self._losses(x, self.forward(x), self.horizon)
+
+    def train_step(self, x, optimizer: torch.optim.Optimizer):
+        raise NotImplementedError("training kernels (BPTT) are not built yet in this round; "
+                                  "see DESIGN.md 'status'")
+
+    def train_step_multihorizon(self, x, optimizer: torch.optim.Optimizer, horizons=[1, 7, 14, 30]):
+        raise NotImplementedError("training kernels (BPTT) are not built yet in this round; "
+                                  "see DESIGN.md 'status'")

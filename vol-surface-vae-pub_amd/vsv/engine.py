@@ -87,6 +87,28 @@ def pack_state_dict(dims: _lib.VsvDims, sd: Dict[str, np.ndarray]) -> np.ndarray
     return out
 
 
+def build_gather_maps(dims: _lib.VsvDims, spec):
+    """Index maps that express the packing as two gathers: with
+    flat = cat([0, p.flatten() for p in params in `spec` order]),
+    packed = flat[idx_a] + flat[idx_b]  (idx_b is non-zero only where the packer
+    sums b_ih + b_hh).  Built by packing state_dicts whose values are their own
+    (1-based) flat offsets, so it is exactly vsv_pack_weights' mapping.
+    spec: list of (name, shape)."""
+    fake_a, fake_b = {}, {}
+    off = 1
+    for name, shape in spec:
+        n = int(np.prod(shape))
+        ids = np.arange(off, off + n, dtype=np.float32).reshape(shape)
+        is_bhh = ".bias_hh_l" in name
+        fake_a[name] = np.zeros(shape, np.float32) if is_bhh else ids
+        fake_b[name] = ids if is_bhh else np.zeros(shape, np.float32)
+        off += n
+    assert off < 2 ** 24, "parameter count exceeds float32-exact index range"
+    idx_a = pack_state_dict(dims, fake_a).astype(np.int64)
+    idx_b = pack_state_dict(dims, fake_b).astype(np.int64)
+    return idx_a, idx_b
+
+
 def _ptr(t: Optional[torch.Tensor]):
     return None if t is None else C.c_void_p(t.data_ptr())
 
@@ -99,7 +121,7 @@ class Engine:
     """Packed weights on one GPU + launch helpers.  All tensor arguments are
     float32 CUDA tensors; outputs are freshly allocated float32 CUDA tensors."""
 
-    def __init__(self, cfg: dict, state_dict: Dict[str, np.ndarray], device="cuda:0"):
+    def __init__(self, cfg: dict, state_dict: Optional[Dict[str, np.ndarray]], device="cuda:0"):
         self.lib = _lib.load()
         self.device = torch.device(device)
         if self.device.type != "cuda" or not torch.cuda.is_available():
@@ -110,11 +132,30 @@ class Engine:
         self.X = self.dims.ex_feats_dim
         self.Q = self.dims.n_quantiles
         self.state_floats = int(self.lib.vsv_state_floats(C.byref(self.dims)))
-        self.set_weights(state_dict)
+        self.packed = None
+        self._maps = None
+        if state_dict is not None:
+            self.set_weights(state_dict)
 
     def set_weights(self, state_dict: Dict[str, np.ndarray]) -> None:
+        """Host packing through vsv_pack_weights (numpy state_dict)."""
         blob = pack_state_dict(self.dims, state_dict)
         self.packed = torch.from_numpy(blob).to(self.device)
+
+    def set_weights_from_params(self, named_params) -> torch.Tensor:
+        """Device-side packing of live nn.Parameters: two gathers through the index
+        maps of build_gather_maps (differentiable, so gradients w.r.t. the packed
+        blob flow back to the parameters)."""
+        named_params = list(named_params)
+        if self._maps is None:
+            spec = [(n, tuple(p.shape)) for n, p in named_params]
+            ia, ib = build_gather_maps(self.dims, spec)
+            self._maps = (torch.from_numpy(ia).to(self.device), torch.from_numpy(ib).to(self.device))
+        flat = torch.cat([torch.zeros(1, dtype=torch.float32, device=self.device)] +
+                         [p.reshape(-1).to(device=self.device, dtype=torch.float32) for _, p in named_params])
+        packed = flat[self._maps[0]] + flat[self._maps[1]]
+        self.packed = packed.detach()
+        return packed
 
     # -- helpers ---------------------------------------------------------
     def _stream(self):

@@ -76,6 +76,7 @@ SIGNATURES = {
                              C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     "vsv_percentile": (C.c_int, [C.c_void_p, C.c_long, C.c_int, C.POINTER(C.c_double), C.c_int,
                                  C.c_int, C.c_void_p, C.c_void_p]),
+    "vsv_profile_next_decode": (None, [C.c_void_p, C.c_void_p]),
     "vsv_debug_layout": (C.c_int, [C.POINTER(VsvDims), C.POINTER(C.c_longlong), C.c_int]),
     "vsv_philox_normal": (C.c_int, [C.c_uint64, C.c_long, C.c_long, C.c_long, C.c_int, C.c_int,
                                     C.c_int, C.c_void_p, C.c_void_p]),

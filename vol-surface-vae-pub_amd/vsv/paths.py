@@ -58,7 +58,7 @@ def prior_generate(eng: Engine, surf_ctx: torch.Tensor, ex_ctx: Optional[torch.T
 def prior_mc_windows(eng: Engine, vol: torch.Tensor, ex: Optional[torch.Tensor], first_day: int, n_days: int,
                      ctx_len: int, horizon: int, n_samples: int, seed: int = 0,
                      qs: Sequence[float] = (5, 50, 95), channel: Optional[int] = 1,
-                     chunk_days: int = 256, day_index0: Optional[int] = None):
+                     chunk_days: int = 256, day_index0: Optional[int] = None, decode_events=None):
     """The Monte-Carlo backfill loop (eval_scripts/eval_utils.py:42-70 /
     generate_surfaces.py:60-102) for days [first_day, first_day+n_days): context
     window vol[day-C:day], S prior samples per day, reduced on device to
@@ -67,7 +67,9 @@ def prior_mc_windows(eng: Engine, vol: torch.Tensor, ex: Optional[torch.Tensor],
     Returns (n_days, horizon, nq, 5, 5) for one decoder channel (default p50),
     or (n_days, horizon, nq, Q, 5, 5) when channel is None.
     Philox counters use the GLOBAL day index (day_index0 + i), so any sharding of
-    the day range gives identical numbers."""
+    the day range gives identical numbers.
+    decode_events: optional list; a (start, stop) hipevents.Event pair bracketing the
+    decoder-LSTM kernel of every chunk is appended (benchmark instrumentation)."""
     assert first_day >= ctx_len and first_day + n_days <= vol.shape[0]
     vol = vol.to(device=eng.device, dtype=torch.float32).contiguous()
     if eng.X > 0:
@@ -85,6 +87,11 @@ def prior_mc_windows(eng: Engine, vol: torch.Tensor, ex: Optional[torch.Tensor],
         zm = enc[..., :L].contiguous()
         ctx = eng.encode_strided(1, sv, 25, 25, se, eng.X, eng.X, nd, ctx_len)
         pre = eng.decode(nd, ctx_len, ctx_len, ctx=ctx, zb=zm, want_state=True)
+        if decode_events is not None:
+            from .hipevents import Event
+            ev = (Event(), Event())
+            eng.lib.vsv_profile_next_decode(ev[0].h, ev[1].h)
+            decode_events.append((ev[0], ev[1], nd * n_samples))
         r = eng.decode(nd * n_samples, horizon, 0, state_in=pre["state"], state_div=n_samples,
                        seed=seed, S=n_samples, day0=day_index0 + d0, out_mode=1)
         smp = r["surf"]                                    # (nd, H, Q*25, S)

@@ -1,0 +1,213 @@
+#!/usr/bin/env python3
+"""Benchmark of the CVAEMemRand Monte-Carlo prior generation path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+
+One "step" = one pass of the hot path over one batch of synthetic input: the
+whole backfill of `--days` context windows x `--samples` prior MC samples x
+`--horizon` decoded days (BASELINE.json configs[3]: context 60, latent 12,
+3 extra features, 4000 days x 1000 samples), ending in the on-device
+p05/p50/p95 reduction.  Inputs (the calendar of surfaces, the packed weights)
+are resident in HBM before the timed region.  With N > 1 (one process per GPU,
+launched by torch.distributed.run) every rank owns its own date range of
+`--days` days (weak scaling, global Philox day counters) and the reduced
+quantile tensors are all-gathered over RCCL at the end of every step.
+
+Prints ONE JSON line on rank 0.  See DESIGN.md "Measurement".
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+PKG = os.path.join(REPO, "vol-surface-vae-pub_amd")
+for _p in (REPO, PKG):
+    if _p not in sys.path:
+        sys.path.insert(0, _p)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+PEAK_F32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32, dense
+
+
+def flops_per_unit(L: int, X: int, Hm: int = 100, c_last: int = 5, Q: int = 3):
+    """Algorithmic FLOPs (2*MAC, no padding, no recomputation) per time step of one
+    row, SURVEY.md 8(d): encoder stack, context stack, decoder LSTM, decoder head."""
+    E = c_last * 25 + X
+    Hd = c_last * 25 + X
+    conv_enc = 2 * 25 * 9 * (1 * 5 + 5 * 5 + 5 * 5)                 # 3x3 convs on 5x5 incl. padding taps = 24750
+    lstm_enc = 2 * 4 * Hm * (E + Hm) + 2 * 4 * Hm * (2 * Hm)
+    f_enc = conv_enc + lstm_enc + 2 * Hm * 2 * L
+    f_ctx = conv_enc + lstm_enc + 2 * Hm * L
+    f_dec_lstm = 2 * 4 * Hd * (2 * L + Hd) + 2 * 4 * Hd * (2 * Hd)
+    conv_dec = 2 * 25 * 9 * (5 * 5 * 3 + 5 * Q)
+    f_dec_head = 2 * 125 * Hd + conv_dec + (2 * X * Hd + 2 * X * X if X else 0)
+    return {"enc": f_enc, "ctx": f_ctx, "dec_lstm": f_dec_lstm, "dec_head": f_dec_head}
+
+
+def synthetic_calendar(n_days: int, C: int, X: int, seed: int = 1234):
+    """The reference's own synthetic test distribution
+    (experiments/diagnostics/test_multi_offset_training.py:65-66)."""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    vol = (0.2 + 0.1 * rng.standard_normal((n_days + C, 5, 5))).astype(np.float32)
+    ex = (0.01 * rng.standard_normal((n_days + C, X))).astype(np.float32) if X else None
+    return vol, ex
+
+
+def cpu_baseline(cfg, W, vol, ex, C, H, S, budget_s: float):
+    """The CPU port (oracle/torch_port.py: the torch CPU ops the reference calls,
+    float32, all host threads torch was given) in the reference's strongest loop
+    shape: one get_surface_given_conditions call per day with batch = S samples
+    (generate_surfaces.py:41-49), literal evaluation (all C+H decoder steps for
+    every sample, as the reference does).  Bounded sample: whole days until
+    `budget_s` seconds have been spent (>= 2 days after one untimed warm-up day)."""
+    from oracle.torch_port import TorchPort
+    port = TorchPort(cfg, W, torch.float32)
+    L = cfg["latent_dim"]
+    gen = torch.Generator().manual_seed(99)
+    tv = torch.from_numpy(vol)
+    te = None if ex is None else torch.from_numpy(ex)
+
+    def one_day(d):
+        win = tv[d:d + C].unsqueeze(0).expand(S, C, 5, 5).contiguous()
+        wex = None if te is None else te[d:d + C].unsqueeze(0).expand(S, C, te.shape[1]).contiguous()
+        z = torch.randn((S, C + H, L), generator=gen)
+        port.get_surface_given_conditions(win, wex, z, H)
+
+    one_day(0)
+    t0 = time.perf_counter()
+    days = 0
+    while True:
+        one_day(days % max(1, vol.shape[0] - C))
+        days += 1
+        el = time.perf_counter() - t0
+        if days >= 2 and el >= budget_s:
+            break
+    return {"value": days * S * H / el, "unit": "surfaces/s", "cores": int(torch.get_num_threads()), "kind": "port",
+            "sample": f"{days} days x {S} samples x horizon {H}, one batched call per day (literal C+H decode), "
+                      f"torch CPU float32, {el:.1f} s"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--days", type=int, default=4000, help="days per rank")
+    ap.add_argument("--samples", type=int, default=1000)
+    ap.add_argument("--context", type=int, default=60)
+    ap.add_argument("--horizon", type=int, default=1)
+    ap.add_argument("--latent", type=int, default=12)
+    ap.add_argument("--ex-feats", type=int, default=3)
+    ap.add_argument("--chunk-days", type=int, default=500)
+    ap.add_argument("--cpu-budget", type=float, default=15.0, help="seconds of CPU baseline work (0 = skip)")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise RuntimeError("bench.py needs a GPU: the HIP path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=dev)
+
+    from oracle import vsv_oracle as vo          # config/weight helpers + the cpu_baseline leg only
+    from vsv import paths
+    from vsv.engine import Engine
+    from vsv.hipevents import Event  # noqa: F401
+
+    L, X, C, H, S, N = args.latent, args.ex_feats, args.context, args.horizon, args.samples, args.days
+    cfg = vo.make_config(L, X)
+    W = vo.init_weights(cfg, 0, 1.0, np.float32)
+    eng = Engine(cfg, W, dev)
+    vol_np, ex_np = synthetic_calendar(N * world, C, X)
+    lo = rank * N
+    vol = torch.from_numpy(vol_np[lo:lo + N + C]).to(dev)
+    ex = torch.from_numpy(ex_np[lo:lo + N + C]).to(dev) if X else None
+    gathered = [torch.empty((N, H, 3, 5, 5), dtype=torch.float32, device=dev) for _ in range(world)] if dist else None
+
+    def one_step(events=None):
+        q = paths.prior_mc_windows(eng, vol, ex, C, N, C, H, S, seed=0, qs=(5, 50, 95), channel=1,
+                                   chunk_days=args.chunk_days, day_index0=C + lo, decode_events=events)
+        if dist:
+            dist.all_gather(gathered, q.contiguous())
+        return q
+
+    def fence():
+        if dist:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        one_step()
+    fence()
+    events = []
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        one_step(events)
+    fence()
+    dt = time.perf_counter() - t0
+    if dist:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    fl = flops_per_unit(L, X)
+    k_ms = [a.elapsed_ms(b) for a, b, _ in events]
+    k_rows = [r for _, _, r in events]
+    avg_ms = float(np.mean(k_ms))
+    flops_per_launch = float(np.mean(k_rows)) * H * fl["dec_lstm"]
+    achieved = flops_per_launch / (avg_ms * 1e-3) / 1e12
+    traffic = None
+    tpath = os.path.join(REPO, "profiles", "pmc_traffic.json")
+    if os.path.exists(tpath):
+        try:
+            tj = json.load(open(tpath))
+            if tj.get("workload") == f"c3-L{L}-X{X}-C{C}-H{H}-S{S}-chunk{args.chunk_days}":
+                traffic = tj.get("hbm_bytes_per_launch")
+        except Exception:
+            traffic = None
+
+    surfaces = world * N * S * H * args.steps
+    out = {
+        "metric": "MC surfaces/sec (5x5 grid, 1000 samples/day)",
+        "value": surfaces / dt,
+        "unit": "surfaces/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": dt / args.steps * 1e3,
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "f32",
+        "data": "synthetic (0.2+0.1*randn surfaces, 0.01*randn ex-features, seeded random weights, Philox noise)",
+        "config": {"workload": f"BASELINE configs[3]: CVAEMemRand context {C}, latent {L}, ex_feats {X}, prior MC "
+                               f"generation, {N} days/GPU x {S} samples x horizon {H}, p05/p50/p95 reduced on device",
+                   "days_per_gpu": N, "samples_per_day": S, "context_len": C, "horizon": H,
+                   "chunk_days": args.chunk_days, "parallelism": f"date-range shards x{world}"},
+        "roofline": {"bound": "mfma", "kernel": "lstm_seq_kernel<decoder> (MC decode LSTM)",
+                     "achieved": achieved, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                     "frac": achieved / PEAK_F32_MFMA_TFLOPS, "traffic": traffic,
+                     "flops_per_launch": flops_per_launch, "avg_launch_ms": avg_ms, "launches": len(k_ms)},
+    }
+    if rank == 0 and args.cpu_budget > 0:
+        out["cpu_baseline"] = cpu_baseline(cfg, W, vol_np, ex_np, C, H, S, args.cpu_budget)
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    if dist:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

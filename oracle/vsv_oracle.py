@@ -156,28 +156,31 @@ def _sigmoid(x):
 def conv2d_3x3_same(x: np.ndarray, w: np.ndarray, b: np.ndarray) -> np.ndarray:
     """nn.Conv2d(k=3, stride=1, padding=1) cross-correlation.
     x (N,Cin,H,W), w (Cout,Cin,3,3), b (Cout).  Call sites:
-    cvae_with_mem_randomized.py:100-103, 252-255, 428-431."""
+    cvae_with_mem_randomized.py:100-103, 252-255, 428-431.
+    out[n,o,y,x] = b[o] + sum_{c,ky,kx} xpad[n,c,y+ky,x+kx] * w[o,c,ky,kx],
+    evaluated as one matrix product over the (c,ky,kx) patch axis."""
     N, Cin, H, Wd = x.shape
     xp = np.zeros((N, Cin, H + 2, Wd + 2), dtype=x.dtype)
     xp[:, :, 1:-1, 1:-1] = x
-    out = np.zeros((N, w.shape[0], H, Wd), dtype=x.dtype)
-    for ky in range(3):
-        for kx in range(3):
-            patch = xp[:, :, ky:ky + H, kx:kx + Wd]          # (N,Cin,H,W)
-            out += np.einsum("nchw,oc->nohw", patch, w[:, :, ky, kx])
-    return out + b[None, :, None, None]
+    win = np.lib.stride_tricks.sliding_window_view(xp, (3, 3), axis=(2, 3))   # (N,Cin,H,W,3,3)
+    patches = win.transpose(0, 2, 3, 1, 4, 5).reshape(N * H * Wd, Cin * 9)
+    out = patches @ w.reshape(w.shape[0], Cin * 9).T + b                      # (N*H*W, Cout)
+    return np.ascontiguousarray(out.reshape(N, H, Wd, w.shape[0]).transpose(0, 3, 1, 2))
 
 
 def conv_transpose2d_3x3(x: np.ndarray, w: np.ndarray, b: np.ndarray) -> np.ndarray:
     """nn.ConvTranspose2d(k=3, stride=1, padding=1, output_padding=0).
-    x (N,Cin,H,W), w (Cin,Cout,3,3).  out[y] += in[yi]*w[ky] with
-    y = yi - 1 + ky.  Call sites: cvae_with_mem_randomized.py:413-424."""
+    x (N,Cin,H,W), w (Cin,Cout,3,3).  Scatter form: every input pixel adds
+    in[yi,xi]*w[:, :, ky, kx] to out[yi-1+ky, xi-1+kx].  Call sites:
+    cvae_with_mem_randomized.py:413-424."""
     N, Cin, H, Wd = x.shape
-    full = np.zeros((N, w.shape[1], H + 2, Wd + 2), dtype=x.dtype)
+    Cout = w.shape[1]
+    contrib = x.transpose(0, 2, 3, 1).reshape(N * H * Wd, Cin) @ w.reshape(Cin, Cout * 9)
+    contrib = contrib.reshape(N, H, Wd, Cout, 3, 3)
+    full = np.zeros((N, Cout, H + 2, Wd + 2), dtype=x.dtype)
     for ky in range(3):
         for kx in range(3):
-            full[:, :, ky:ky + H, kx:kx + Wd] += np.einsum(
-                "nchw,co->nohw", x, w[:, :, ky, kx])
+            full[:, :, ky:ky + H, kx:kx + Wd] += contrib[:, :, :, :, ky, kx].transpose(0, 3, 1, 2)
     return full[:, :, 1:-1, 1:-1] + b[None, :, None, None]
 
 
@@ -503,7 +506,8 @@ def philox_normal(seed: int, day0: int, n_days: int, n_samples: int, step0: int,
     stp = (step0 + np.arange(n_steps, dtype=np.uint64))[None, None, :, None]
     blk = np.arange(nb, dtype=np.uint64)[None, None, None, :]
     x = philox4x32_10(smp, day, stp, blk, seed & 0xFFFFFFFF, (seed >> 32) & 0xFFFFFFFF)
-    u = [((xi >> np.uint32(8)).astype(np.float32) + np.float32(0.5)) * np.float32(2.0 ** -24) for xi in x]
+    # 23 random bits + 0.5 is exact in float32, so u lies strictly inside (0, 1)
+    u = [((xi >> np.uint32(9)).astype(np.float32) + np.float32(0.5)) * np.float32(2.0 ** -23) for xi in x]
     out = np.empty(u[0].shape + (4,), dtype=np.float32)
     two_pi = np.float32(6.283185307179586)
     for p in range(2):

@@ -119,3 +119,51 @@ def test_philox_normal_is_standard_normal():
     # sharding invariance: a sub-range of days gives the same numbers
     z2 = vo.philox_normal(7, 5, 4, 500, 0, 4, 5)
     assert np.array_equal(z2, z[2:6])
+
+
+# ---- the torch-CPU port (oracle/torch_port.py: bench cpu_baseline + autograd oracle) ----
+
+def _port(g, dt):
+    import torch
+    from oracle.torch_port import TorchPort
+    cfg = cfg_of(g)
+    W = vo.init_weights(cfg, int(g["seed"]), float(g["scale"]), dt)
+    tdt = torch.float64 if dt == np.float64 else torch.float32
+    return TorchPort(cfg, W, tdt), cfg, tdt
+
+
+@pytest.mark.parametrize("name", golden_names("g1_"))
+def test_torch_port_forward_and_losses(name):
+    import torch
+    g = load_golden(name)
+    dt = g["surface"].dtype
+    port, cfg, tdt = _port(g, dt)
+    ex = g.get("ex_feats")
+    T = lambda a: None if a is None else torch.tensor(a, dtype=tdt)      # noqa: E731
+    with torch.no_grad():
+        s, e, zm, zl, z = port.forward(T(g["surface"]), T(ex), T(g["eps"]), int(g["horizon"]))
+        losses = port.losses(T(g["surface"]), T(ex), T(g["eps"]), int(g["horizon"]),
+                             cfg.get("quantile_loss_weights"))
+    for got, want in ((s, g["recon"]), (zm, g["z_mean"]), (zl, g["z_log_var"]), (z, g["z"])):
+        assert np.max(np.abs(got.numpy() - want)) <= tol(dt)
+    if ex is not None:
+        assert np.max(np.abs(e.numpy() - g["ex_recon"])) <= tol(dt)
+    for k, v in losses.items():
+        want = float(g["loss_" + k])
+        assert abs(float(v) - want) <= 1e-3 * abs(want) + 1e-12, (k, float(v), want)
+
+
+@pytest.mark.parametrize("name", golden_names("g2_"))
+def test_torch_port_prior_generation(name):
+    import torch
+    g = load_golden(name)
+    dt = g["surface"].dtype
+    port, cfg, tdt = _port(g, dt)
+    ex = g.get("ex_feats")
+    z = torch.tensor(g["z"], dtype=tdt)
+    s, e = port.get_surface_given_conditions(torch.tensor(g["surface"], dtype=tdt),
+                                             None if ex is None else torch.tensor(ex, dtype=tdt), z, int(g["horizon"]))
+    assert np.max(np.abs(s.numpy() - g["surf_out"])) <= tol(dt)
+    assert np.max(np.abs(z.numpy() - g["z_after"])) <= tol(dt)
+    if ex is not None:
+        assert np.max(np.abs(e.numpy() - g["ex_out"])) <= tol(dt)

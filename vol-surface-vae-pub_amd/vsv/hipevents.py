@@ -8,7 +8,8 @@ _hip = None
 def _lib():
     global _hip
     if _hip is None:
-        _hip = C.CDLL("libamdhip64.so")
+        import torch  # noqa: F401  (load torch's HIP runtime first; the SONAME below then resolves to it)
+        _hip = C.CDLL("libamdhip64.so.7")
         _hip.hipEventCreate.argtypes = [C.POINTER(C.c_void_p)]
         _hip.hipEventDestroy.argtypes = [C.c_void_p]
         _hip.hipEventRecord.argtypes = [C.c_void_p, C.c_void_p]

@@ -77,22 +77,24 @@ def prior_mc_windows(eng: Engine, vol: torch.Tensor, ex: Optional[torch.Tensor],
     if day_index0 is None:
         day_index0 = first_day
     L, Q = eng.L, eng.Q
+    # context prefix for ALL days in one go (three sequential-in-time kernels whose
+    # parallelism is the day count): posterior means, context embedding, decoder state
+    w0 = first_day - ctx_len                               # first calendar row of the first window
+    sv = vol[w0:]
+    se = ex[w0:] if eng.X > 0 else None
+    enc = eng.encode_strided(0, sv, 25, 25, se, eng.X, eng.X, n_days, ctx_len)
+    zm = enc[..., :L].contiguous()
+    ctx = eng.encode_strided(1, sv, 25, 25, se, eng.X, eng.X, n_days, ctx_len)
+    state = eng.decode(n_days, ctx_len, ctx_len, ctx=ctx, zb=zm, want_state=True)["state"]
     outs = []
     for d0 in range(0, n_days, chunk_days):
         nd = min(chunk_days, n_days - d0)
-        w0 = first_day + d0 - ctx_len                      # first calendar row of the first window
-        sv = vol[w0:]
-        se = ex[w0:] if eng.X > 0 else None
-        enc = eng.encode_strided(0, sv, 25, 25, se, eng.X, eng.X, nd, ctx_len)
-        zm = enc[..., :L].contiguous()
-        ctx = eng.encode_strided(1, sv, 25, 25, se, eng.X, eng.X, nd, ctx_len)
-        pre = eng.decode(nd, ctx_len, ctx_len, ctx=ctx, zb=zm, want_state=True)
         if decode_events is not None:
             from .hipevents import Event
             ev = (Event(), Event())
             eng.lib.vsv_profile_next_decode(ev[0].h, ev[1].h)
             decode_events.append((ev[0], ev[1], nd * n_samples))
-        r = eng.decode(nd * n_samples, horizon, 0, state_in=pre["state"], state_div=n_samples,
+        r = eng.decode(nd * n_samples, horizon, 0, state_in=state[d0:d0 + nd], state_div=n_samples,
                        seed=seed, S=n_samples, day0=day_index0 + d0, out_mode=1)
         smp = r["surf"]                                    # (nd, H, Q*25, S)
         if channel is None:

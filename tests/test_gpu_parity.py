@@ -102,6 +102,26 @@ def test_prior_mc_vs_oracle_ragged_tiles(L, X, D, S, C, H):
     assert torch.equal(s1, ref)
 
 
+def test_fused_mc_decode_many_rows_vs_oracle():
+    """> 32768 rows: the one-wave-per-tile schedule with the fused decoder head (the
+    MC production path), ragged last tile, tiles straddling days, both output layouts."""
+    from vsv import paths
+    for L, X, D, S, C, H in ((12, 3, 37, 1000, 4, 2), (5, 0, 67, 500, 3, 1)):
+        cfg = vo.make_config(L, X)
+        eng, W = _engine(cfg, 21, 2.0)
+        rng = np.random.default_rng(17)
+        surf = (0.2 + 0.1 * rng.standard_normal((D, C, 5, 5))).astype(np.float32)
+        ex = (0.01 * rng.standard_normal((D, C, X))).astype(np.float32) if X else None
+        eps = rng.standard_normal((D, S, H, L)).astype(np.float32)
+        want_s, want_e = vo.prior_mc_shared_prefix(W, cfg, surf, ex, eps)
+        s, e, _ = paths.prior_generate(eng, _t(surf), _t(ex), H, S, eps=_t(eps.reshape(D * S, H, L)))
+        assert err(_n(s).reshape(want_s.shape), want_s) <= TOL
+        if X:
+            assert err(_n(e).reshape(want_e.shape), want_e) <= TOL
+        s1, _, _ = paths.prior_generate(eng, _t(surf), _t(ex), H, S, eps=_t(eps.reshape(D * S, H, L)), out_mode=1)
+        assert torch.equal(s1, s.view(D, S, H, 75).permute(0, 2, 3, 1))
+
+
 def test_percentile_matches_numpy():
     cfg = vo.make_config(5, 0)
     eng, _ = _engine(cfg, 0, 1.0)

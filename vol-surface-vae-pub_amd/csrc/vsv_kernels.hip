@@ -1,13 +1,21 @@
 // gfx950 kernels of libvsv_hip.so and their launchers.
 //
-// Execution model: one wave owns a tile of 16 independent rows
-// (batch index m = lane & 15).  Every layer is y^T[N x 16] = W[N x K] . x^T[K x 16]
-// on v_mfma_f32_16x16x4_f32 (exact f32 FMA chain), with the WEIGHTS as the A
-// operand (pre-packed fragments, streamed from L2) and the ACTIVATIONS as the B
-// operand.  The D layout (lane (g,m) holds rows 4g..4g+3 of a tile for row m)
-// coincides with the B layout of the next layer (lane (g,m) supplies k = 4s+g),
-// so activations never move between lanes: each lane keeps its own slice of
-// every activation vector in a private column of LDS ("priv[k*64 + lane]").
+// Execution model: one wave owns a tile of 32 independent rows
+// (batch index m = lane & 31, lane half hh = lane >> 5).  Every layer is
+// y^T[N x 32] = W[N x K] . x^T[K x 32] on v_mfma_f32_32x32x2_f32 (exact f32 FMA
+// chain), with the WEIGHTS as the A operand (pre-packed fragments, streamed from
+// L2, prefetched one k-quad ahead) and the ACTIVATIONS as the B operand.  The D
+// layout of a layer coincides with the B layout of the next one (vsv_layout.h), so
+// activations never move between lanes: a lane keeps its slice of every
+// activation vector either in registers (decoder head chain, static indexing) or
+// in a private LDS column ("col[s*64 + lane]", one slot per k-step).
+//
+// Two schedules of the recurrent kernel:
+//   SPLIT = 1  many rows (MC decode, AR): a wave walks its own 32-row tile through
+//              all gate tiles, 4 independent waves per workgroup, 1 wave per SIMD;
+//   SPLIT = 4  few rows (context prefix, training batches): the 4 waves of a
+//              workgroup share ONE 32-row tile and split its gate tiles, h is
+//              exchanged through LDS with two barriers per layer and step.
 #include <hip/hip_runtime.h>
 #include <cmath>
 #include <cstdint>
@@ -17,60 +25,93 @@
 
 namespace vsv {
 
-typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-__device__ __forceinline__ f32x4 mfma4(float a, float b, f32x4 c) {
-    return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+__device__ __forceinline__ f32x16 mfma32(float a, float b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
 }
 
-// acc[t] += W[tile t] . B for nq k-quads.  w: this lane's float4 of quad 0, tile 0
-// (packed [nq][NT][64][4]); bsrc: this lane's column of the activation array at the
-// first k-step (LDS, stride 64 floats per k-step).
-// `nts` is the tile stride of the packed layer (its total tile count), so a caller can
-// compute a sub-range of NT tiles by offsetting w.
-template <int NT>
-__device__ __forceinline__ void tile_gemm(f32x4 (&acc)[NT], const float4* __restrict__ w,
-                                          const float* bsrc, int nq, int nts = NT) {
-    constexpr int G = (NT < 4) ? NT : 4;
+// feature index held by lane half hh in accumulator register reg of tile t (NAT32 out order)
+__device__ __forceinline__ int feat_of(int t, int reg, int hh) { return 32 * t + 8 * (reg >> 2) + 4 * hh + (reg & 3); }
+
+// acc[i] += W[tile toff[i]] . B over nq k-quads.  w: this lane's float4 at quad 0, tile 0 of
+// the segment; toff[i]: tile offset in float4 units (tile * 64); qstride: float4 per quad
+// (layer tiles * 64); b: this lane's activation column at the segment's first k-step
+// (LDS or global, 64 floats per k-step).  Weights and B values are fetched one quad ahead.
+template <int NC>
+__device__ __forceinline__ void gemm_seg(f32x16 (&acc)[NC], const float4* __restrict__ w, const int (&toff)[NC],
+                                         int qstride, const float* b, int nq) {
+    float4 a[NC];
+    float bb[4];
+#pragma unroll
+    for (int i = 0; i < NC; ++i) a[i] = w[toff[i]];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) bb[j] = b[j * 64];
 #pragma unroll 1
     for (int q = 0; q < nq; ++q) {
-        const float b0 = bsrc[(4 * q + 0) * 64];
-        const float b1 = bsrc[(4 * q + 1) * 64];
-        const float b2 = bsrc[(4 * q + 2) * 64];
-        const float b3 = bsrc[(4 * q + 3) * 64];
-        const float4* wq = w + (size_t)q * nts * 64;
+        const int qn = (q + 1 < nq) ? q + 1 : q;
+        float4 an[NC];
+        float bn[4];
+        const float4* wn = w + (size_t)qn * qstride;
 #pragma unroll
-        for (int t0 = 0; t0 < NT; t0 += G) {
-            float4 a[G];
+        for (int i = 0; i < NC; ++i) an[i] = wn[toff[i]];
 #pragma unroll
-            for (int i = 0; i < G; ++i)
-                if (t0 + i < NT) a[i] = wq[(t0 + i) * 64];
+        for (int j = 0; j < 4; ++j) bn[j] = b[(4 * qn + j) * 64];
 #pragma unroll
-            for (int i = 0; i < G; ++i)
-                if (t0 + i < NT) acc[t0 + i] = mfma4(a[i].x, b0, acc[t0 + i]);
+        for (int i = 0; i < NC; ++i) acc[i] = mfma32(a[i].x, bb[0], acc[i]);
 #pragma unroll
-            for (int i = 0; i < G; ++i)
-                if (t0 + i < NT) acc[t0 + i] = mfma4(a[i].y, b1, acc[t0 + i]);
+        for (int i = 0; i < NC; ++i) acc[i] = mfma32(a[i].y, bb[1], acc[i]);
 #pragma unroll
-            for (int i = 0; i < G; ++i)
-                if (t0 + i < NT) acc[t0 + i] = mfma4(a[i].z, b2, acc[t0 + i]);
+        for (int i = 0; i < NC; ++i) acc[i] = mfma32(a[i].z, bb[2], acc[i]);
 #pragma unroll
-            for (int i = 0; i < G; ++i)
-                if (t0 + i < NT) acc[t0 + i] = mfma4(a[i].w, b3, acc[t0 + i]);
+        for (int i = 0; i < NC; ++i) acc[i] = mfma32(a[i].w, bb[3], acc[i]);
+#pragma unroll
+        for (int i = 0; i < NC; ++i) a[i] = an[i];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) bb[j] = bn[j];
+    }
+}
+
+// acc[i] = bias of tile tile[i] (compact [nt][2][16] layout)
+template <int NC>
+__device__ __forceinline__ void load_bias(f32x16 (&acc)[NC], const float* __restrict__ b, const int (&toff)[NC], int hh) {
+#pragma unroll
+    for (int i = 0; i < NC; ++i) {
+        const float4* p = (const float4*)(b + (toff[i] >> 6) * 32 + hh * 16);
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+            const float4 x = p[v];
+            acc[i][4 * v + 0] = x.x; acc[i][4 * v + 1] = x.y; acc[i][4 * v + 2] = x.z; acc[i][4 * v + 3] = x.w;
         }
     }
 }
 
-template <int NT>
-__device__ __forceinline__ void load_bias(f32x4 (&acc)[NT], const float4* __restrict__ b) {
+// One dense layer whose input lives in registers: in[4] is the previous layer's
+// accumulator set (PERM32 order: k-step s = 16*t + reg).  16 quads, fully unrolled.
+template <int NTO>
+__device__ __forceinline__ void dense_reg(f32x16 (&out)[NTO], const f32x16 (&in)[kHeadTiles],
+                                          const float4* __restrict__ w /* lane-adjusted */) {
 #pragma unroll
-    for (int t = 0; t < NT; ++t) {
-        const float4 v = b[t * 64];
-        acc[t] = f32x4{v.x, v.y, v.z, v.w};
+    for (int q = 0; q < 4 * kHeadTiles; ++q) {
+        float4 a[NTO];
+#pragma unroll
+        for (int i = 0; i < NTO; ++i) a[i] = w[(q * NTO + i) * 64];
+#pragma unroll
+        for (int i = 0; i < NTO; ++i) out[i] = mfma32(a[i].x, in[q >> 2][4 * (q & 3) + 0], out[i]);
+#pragma unroll
+        for (int i = 0; i < NTO; ++i) out[i] = mfma32(a[i].y, in[q >> 2][4 * (q & 3) + 1], out[i]);
+#pragma unroll
+        for (int i = 0; i < NTO; ++i) out[i] = mfma32(a[i].z, in[q >> 2][4 * (q & 3) + 2], out[i]);
+#pragma unroll
+        for (int i = 0; i < NTO; ++i) out[i] = mfma32(a[i].w, in[q >> 2][4 * (q & 3) + 3], out[i]);
     }
 }
 
-__device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
+__device__ __forceinline__ float fast_sigmoid(float x) { return __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
+__device__ __forceinline__ float fast_tanh(float x) {
+    const float e = __expf(-2.0f * fabsf(x));
+    return copysignf((1.0f - e) * __builtin_amdgcn_rcpf(1.0f + e), x);
+}
 
 // ---------------------------------------------------------------------------
 // Philox4x32-10 + Box-Muller: one N(0,1) value per (sample, day, step, f).
@@ -96,8 +137,10 @@ __device__ __forceinline__ float philox_normal_elem(uint32_t k0, uint32_t k1, ui
 }
 
 // ---------------------------------------------------------------------------
-// dense_chain: a stack of dense layers (conv embeddings, decoder head) applied
-// to independent (row, t) instances.  One wave per (row tile, t).
+// dense_chain: a stack of dense layers (conv embeddings, linear heads, decoder
+// head) applied to independent (row tile, t) instances.  One wave per instance;
+// activations live in ONE private LDS column per wave, updated in place (a layer's
+// outputs stay in the accumulators until all of its inputs have been read).
 // ---------------------------------------------------------------------------
 struct DenseLayerArg {
     const float* w;
@@ -112,11 +155,11 @@ struct DenseChainArgs {
     long n_rowtiles;
     int T;
     // input
-    int in_mode;            // 0 row-major gather, 1 tile-B
+    int in_mode;            // 0 row-major gather (natural order), 1 tile-B
     const float* in;
     long in_rs, in_ts;      // row-major strides (floats)
     int in_f;               // row-major: real features
-    int in_ks;              // k-steps to fill (multiple of 4 for mode 0; = 4*nt_prev for mode 1)
+    int in_ks;              // k-steps to fill (mode 0: multiple of 4; mode 1: k-steps per instance in `in`)
     // injection into the LAST layer's output features [inj_f0, inj_f0+inj_n)
     const float* inj;
     long inj_rs, inj_ts;
@@ -132,92 +175,142 @@ struct DenseChainArgs {
     int aux_f0, aux_n;
 };
 
+constexpr int kDenseSlots = 16 * kHeadTiles;     // LDS k-step slots per wave
+
+// Per-(row, t) pointers of a chain's side effects, hoisted out of the per-register epilogue:
+// out + f*fstride is the final store (row-major or sample-minor), inj/aux are pre-offset by
+// their first feature so they are indexed by the feature number itself.  inj and aux features
+// always live in the LAST tile of their layer (make_layout checks c_last*25 >= 96 when X > 0).
+struct RowIo {
+    float* out;
+    long fstride;
+    const float* inj;
+    float* aux;
+};
+
+__device__ __forceinline__ RowIo make_rowio(const DenseChainArgs& a, long row, bool row_ok, int t) {
+    RowIo io = {nullptr, 1, nullptr, nullptr};
+    if (a.out_mode == 1 && row_ok) {
+        io.out = a.out + ((size_t)row * a.T + t) * a.out_f;
+    } else if (a.out_mode == 2 && row_ok) {
+        const long d = row / a.S;
+        io.out = a.out + ((size_t)d * a.T + t) * a.out_f * a.S + (row - d * a.S);
+        io.fstride = a.S;
+    }
+    if (a.inj) io.inj = a.inj + row * a.inj_rs + (long)t * a.inj_ts - a.inj_f0;
+    if (a.aux && row_ok) io.aux = a.aux + ((size_t)row * a.T + t) * a.aux_n - a.aux_f0;
+    return io;
+}
+
+// ReLU mask, injection and aux output for the NT tiles of layer li (in place)
 template <int NT>
-__device__ __forceinline__ void dense_layer(const DenseChainArgs& a, int li, const float* ibuf, float* obuf,
-                                            int lane, long row, bool row_ok, int t, long tile) {
-    const DenseLayerArg& ly = a.layer[li];
-    f32x4 acc[NT];
-    load_bias<NT>(acc, (const float4*)ly.b + lane);
-    tile_gemm<NT>(acc, (const float4*)ly.w + lane, ibuf, ly.nq);
-    const int g = lane >> 4;
-    const bool last = (li == a.n_layers - 1);
+__device__ __forceinline__ void dense_epilogue(const DenseChainArgs& a, const RowIo& io, int li, bool last,
+                                               f32x16 (&acc)[NT], int hh, int n_relu) {
 #pragma unroll
-    for (int tt = 0; tt < NT; ++tt) {
+    for (int tt = 0; tt < NT; ++tt)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int f = 16 * tt + 4 * g + r;
-            float v = acc[tt][r];
-            if (f < ly.n_relu) v = fmaxf(v, 0.0f);
-            if (last && a.inj && f >= a.inj_f0 && f < a.inj_f0 + a.inj_n)
-                v = a.inj[row * a.inj_rs + (long)t * a.inj_ts + (f - a.inj_f0)];
-            if (li == a.aux_layer && a.aux && row_ok && f >= a.aux_f0 && f < a.aux_f0 + a.aux_n)
-                a.aux[(row * a.T + t) * a.aux_n + (f - a.aux_f0)] = v;
-            if (!last) {
-                obuf[(4 * tt + r) * 64] = v;
-            } else if (a.out_mode == 0) {
-                a.out[((size_t)tile * (4 * NT) + 4 * tt + r) * 64 + lane] = v;
-            } else if (row_ok && f < a.out_f) {
-                if (a.out_mode == 1)
-                    a.out[((size_t)row * a.T + t) * a.out_f + f] = v;
-                else
-                    a.out[((((size_t)(row / a.S)) * a.T + t) * a.out_f + f) * a.S + (row % a.S)] = v;
-            }
+        for (int r = 0; r < 16; ++r) acc[tt][r] = (feat_of(tt, r, hh) < n_relu) ? fmaxf(acc[tt][r], 0.0f) : acc[tt][r];
+    const bool do_inj = last && io.inj != nullptr, do_aux = (li == a.aux_layer) && io.aux != nullptr;
+    if (do_inj || do_aux) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int f = feat_of(NT - 1, r, hh);
+            if (do_inj && f >= a.inj_f0 && f < a.inj_f0 + a.inj_n) acc[NT - 1][r] = io.inj[f];
+            if (do_aux && f >= a.aux_f0 && f < a.aux_f0 + a.aux_n) io.aux[f] = acc[NT - 1][r];
         }
     }
 }
 
-__global__ void __launch_bounds__(256, 2) dense_chain_kernel(DenseChainArgs a) {
+template <int NT>
+__device__ __forceinline__ void dense_store(const DenseChainArgs& a, const RowIo& io, const f32x16 (&acc)[NT], int hh) {
+    if (!io.out) return;
+#pragma unroll
+    for (int tt = 0; tt < NT; ++tt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int f = feat_of(tt, r, hh);
+            if (f < a.out_f) io.out[(size_t)f * io.fstride] = acc[tt][r];
+        }
+}
+
+template <int NT>
+__device__ __forceinline__ void dense_layer(const DenseChainArgs& a, const RowIo& io, int li, float* col, int lane,
+                                            long inst) {
+    const DenseLayerArg& ly = a.layer[li];
+    const int hh = lane >> 5;
+    f32x16 acc[NT];
+    int toff[NT];
+#pragma unroll
+    for (int i = 0; i < NT; ++i) toff[i] = i * 64;
+    load_bias<NT>(acc, ly.b, toff, hh);
+    gemm_seg<NT>(acc, (const float4*)ly.w + lane, toff, NT * 64, col, ly.nq);
+    const bool last = (li == a.n_layers - 1);
+    dense_epilogue<NT>(a, io, li, last, acc, hh, ly.n_relu);
+    if (!last) {
+#pragma unroll
+        for (int tt = 0; tt < NT; ++tt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) col[(16 * tt + r) * 64] = acc[tt][r];
+        // zero the slots a narrower layer leaves behind so the next layer's padded k-steps read 0
+        for (int s = 16 * NT; s < kDenseSlots; ++s) col[s * 64] = 0.0f;
+    } else if (a.out_mode == 0) {
+        float* o = a.out + ((size_t)inst * (16 * NT)) * 64 + lane;
+#pragma unroll
+        for (int tt = 0; tt < NT; ++tt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) o[(16 * tt + r) * 64] = acc[tt][r];
+    } else {
+        dense_store<NT>(a, io, acc, hh);
+    }
+}
+
+__global__ void __launch_bounds__(256, 2) dense_chain_kernel(const DenseChainArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const long tile = (long)blockIdx.x * 4 + wave;
-    if (tile >= a.n_rowtiles * a.T) return;
-    const long rowtile = tile / a.T;
-    const int t = (int)(tile % a.T);
-    const int g = lane >> 4, m = lane & 15;
-    long row = rowtile * 16 + m;
+    const long inst = (long)blockIdx.x * 4 + wave;
+    if (inst >= a.n_rowtiles * a.T) return;
+    const long rowtile = inst / a.T;
+    const int t = (int)(inst % a.T);
+    const int hh = lane >> 5, m = lane & 31;
+    long row = rowtile * 32 + m;
     const bool row_ok = row < a.n_rows;
     if (!row_ok) row = a.n_rows - 1;
-    float* buf0 = smem + (size_t)wave * (2 * 32 * 64) + lane;
-    float* buf1 = buf0 + 32 * 64;
+    float* col = smem + (size_t)wave * (kDenseSlots * 64) + lane;
 
     if (a.in_mode == 0) {
         const float* src = a.in + row * a.in_rs + (long)t * a.in_ts;
         for (int s = 0; s < a.in_ks; ++s) {
-            const int f = 4 * s + g;
-            buf0[s * 64] = (f < a.in_f) ? src[f] : 0.0f;
+            const int f = 2 * s + hh;
+            col[s * 64] = (f < a.in_f) ? src[f] : 0.0f;
         }
+        for (int s = a.in_ks; s < kDenseSlots; ++s) col[s * 64] = 0.0f;
     } else {
-        const float* src = a.in + (size_t)tile * a.in_ks * 64 + lane;
-        for (int s = 0; s < a.in_ks; ++s) buf0[s * 64] = src[s * 64];
-        for (int s = a.in_ks; s < 4 * a.layer[0].nq; ++s) buf0[s * 64] = 0.0f;   // zero the last quad's pad
+        const float* src = a.in + (size_t)inst * a.in_ks * 64 + lane;
+        for (int s = 0; s < a.in_ks; ++s) col[s * 64] = src[s * 64];
+        for (int s = a.in_ks; s < kDenseSlots; ++s) col[s * 64] = 0.0f;
     }
-    float* ib = buf0;
-    float* ob = buf1;
+    const RowIo io = make_rowio(a, row, row_ok, t);
+#pragma unroll 1
     for (int li = 0; li < a.n_layers; ++li) {
         switch (a.layer[li].nt) {
-            case 1: dense_layer<1>(a, li, ib, ob, lane, row, row_ok, t, tile); break;
-            case 2: dense_layer<2>(a, li, ib, ob, lane, row, row_ok, t, tile); break;
-            case 3: dense_layer<3>(a, li, ib, ob, lane, row, row_ok, t, tile); break;
-            case 4: dense_layer<4>(a, li, ib, ob, lane, row, row_ok, t, tile); break;
-            case 5: dense_layer<5>(a, li, ib, ob, lane, row, row_ok, t, tile); break;
-            case 6: dense_layer<6>(a, li, ib, ob, lane, row, row_ok, t, tile); break;
-            case 7: dense_layer<7>(a, li, ib, ob, lane, row, row_ok, t, tile); break;
-            default: dense_layer<8>(a, li, ib, ob, lane, row, row_ok, t, tile); break;
+            case 1: dense_layer<1>(a, io, li, col, lane, inst); break;
+            case 2: dense_layer<2>(a, io, li, col, lane, inst); break;
+            case 3: dense_layer<3>(a, io, li, col, lane, inst); break;
+            default: dense_layer<4>(a, io, li, col, lane, inst); break;
         }
-        float* tmp = ib; ib = ob; ob = tmp;
     }
 }
 
 // ---------------------------------------------------------------------------
-// lstm_seq: a 1- or 2-layer LSTM walked over T steps for a tile of 16 rows per
-// wave, with (XMODE 0) the x part read from a tile-B tensor written by
-// dense_chain (encoders) or (XMODE 1) assembled from ctx / z / noise (decoder).
+// lstm_kernel: a 1- or 2-layer LSTM walked over T steps for tiles of 32 rows,
+// with (XMODE 0) the x part read from a tile-B tensor written by dense_chain
+// (encoders) or (XMODE 1) assembled from ctx / z / noise (decoder); optionally
+// (HEAD, SPLIT = 1) followed at every output step by the decoder head chain.
 // ---------------------------------------------------------------------------
 struct LstmSeqArgs {
     const float* w[2];
     const float* b[2];
-    int nq[2];
-    int kx;                 // k-steps of the x part
+    int kx;                 // k-steps of the x part (multiple of 4)
     long n_rows, n_rowtiles;
     int T;
     // XMODE 0
@@ -227,28 +320,32 @@ struct LstmSeqArgs {
     vsv_decode_in din;
     float* z_out;           // (n_rows, T, L) or null
     // state
-    float* state_out;       // (n_rows, NL, 2, 4*NT) or null
-    // per-step top-layer h in tile-B layout for t >= t_out0: [(rowtile*(T-t_out0) + t-t_out0)*NT + s][64]
+    float* state_out;       // (n_rows, NL, 2, 8*NT) or null
+    // per-step top-layer h in tile-B layout for t >= t_out0: [(rowtile*(T-t_out0) + t-t_out0)*4*NT + s][64]
     float* hout;
     int t_out0;
-    // fused linear head on the top-layer h (encoders): out (n_rows, T, nh)
-    const float* head_w;
-    const float* head_b;
-    int head_nq, head_nt, nh;
-    float* head_out;
+    // fused decoder head (HEAD): layers, outputs and aux as in DenseChainArgs (in_* unused, T = T - t_out0)
+    DenseChainArgs head;
 };
 
-__device__ __forceinline__ float decoder_input(const LstmSeqArgs& a, long row, int t, int f) {
+// per-thread constants of the decoder input assembly
+struct DecIn {
+    const float* ctx;       // this row's ctx block or null
+    long z_idx;             // this row's offset into zb / lv
+    const float* eps;       // this row's eps block or null
+    uint32_t sample, day;
+};
+
+__device__ __forceinline__ float decoder_input(const LstmSeqArgs& a, const DecIn& di, long row, bool row_ok, bool writer,
+                                               int t, int f) {
     const vsv_decode_in& d = a.din;
     const int L = a.L;
-    if (f < L) {
-        return (t < d.ctx_T) ? d.ctx[(row / d.ctx_div) * d.ctx_rs + (long)t * L + f] : 0.0f;
-    }
+    if (f < L) return (t < d.ctx_T) ? di.ctx[(long)t * L + f] : 0.0f;
     f -= L;
     if (f >= L) return 0.0f;
     float base, scale;
     if (t < d.z_T) {
-        const long idx = (row / d.z_div) * d.z_rs + (long)t * L + f;
+        const long idx = di.z_idx + (long)t * L + f;
         base = d.zb[idx];
         scale = d.lv ? expf(0.5f * d.lv[idx]) : 0.0f;
     } else {
@@ -259,159 +356,231 @@ __device__ __forceinline__ float decoder_input(const LstmSeqArgs& a, long row, i
     if (scale != 0.0f) {
         const int te = t - d.eps_t0;
         float eps;
-        if (d.eps_in) {
-            eps = d.eps_in[((size_t)row * d.eps_T + te) * L + f];
-        } else {
-            eps = philox_normal_elem((uint32_t)d.seed, (uint32_t)(d.seed >> 32), (uint32_t)(row % d.S),
-                                     (uint32_t)(d.day0 + row / d.S), (uint32_t)(d.step0 + te), f);
-        }
+        if (d.eps_in)
+            eps = di.eps[(size_t)te * L + f];
+        else
+            eps = philox_normal_elem((uint32_t)d.seed, (uint32_t)(d.seed >> 32), di.sample, di.day,
+                                     (uint32_t)(d.step0 + te), f);
         v = base + scale * eps;
     }
-    if (a.z_out && row < a.n_rows) a.z_out[((size_t)row * a.T + t) * L + f] = v;
+    if (a.z_out && row_ok && writer) a.z_out[((size_t)row * a.T + t) * L + f] = v;
     return v;
 }
 
-// gates of tiles [t0, t0+NC) of layer l: bias already in acc
-template <int NC, int XMODE>
-__device__ __forceinline__ void lstm_gemm(f32x4 (&acc)[NC], const LstmSeqArgs& a, int l, int t0, int nts,
-                                          long rowtile, int t, int lane, const float* priv, const float* hbase) {
-    const float4* w = (const float4*)a.w[l] + (size_t)t0 * 64 + lane;
-    if (XMODE == 0 && l == 0) {
-        // x part straight from the tile-B tensor in global memory (kx is a multiple of 4)
-        const int kx = a.kx;
-        const float* xe = a.x_tileb + ((size_t)(rowtile * a.T + t) * kx) * 64 + lane;
-        tile_gemm<NC>(acc, w, xe, kx / 4, nts);
-        tile_gemm<NC>(acc, w + (size_t)(kx / 4) * nts * 64, hbase, a.nq[0] - kx / 4, nts);
+// gates of the NC tiles toff[] of layer l (bias already in acc)
+template <int NC, int NT, int XMODE>
+__device__ __forceinline__ void lstm_gates(f32x16 (&acc)[NC], const LstmSeqArgs& a, int l, const int (&toff)[NC],
+                                           long rowtile, int t, int lane, const float* xs, const float* hb) {
+    constexpr int HPK = 4 * NT;
+    const float4* w = (const float4*)a.w[l] + lane;
+    if (l == 0) {
+        const int kxq = a.kx >> 2;
+        const float* xsrc = (XMODE == 0) ? a.x_tileb + ((size_t)(rowtile * a.T + t) * a.kx) * 64 + lane : xs;
+        gemm_seg<NC>(acc, w, toff, NT * 64, xsrc, kxq);
+        gemm_seg<NC>(acc, w + (size_t)kxq * NT * 64, toff, NT * 64, hb, NT);
     } else {
-        tile_gemm<NC>(acc, w, (l == 0) ? priv : hbase, a.nq[l], nts);   // layer 1 reads [h0 | h1]
+        gemm_seg<NC>(acc, w, toff, NT * 64, hb, NT);                                   // h of layer 0 (this step)
+        gemm_seg<NC>(acc, w + (size_t)NT * NT * 64, toff, NT * 64, hb + HPK * 64, NT);   // own h (previous step)
     }
 }
 
-// LSTM cell for NC tiles (one unit per tile per lane): gates i,f,g,o in acc[s][0..3]
+// LSTM cell for NC tiles: lane holds gates (i,f,g,o) of unit 8t + 2jj + hh in acc[i][4jj .. 4jj+3]
 template <int NC>
-__device__ __forceinline__ void lstm_cell(const f32x4 (&acc)[NC], float* c, float (&hn)[NC]) {
+__device__ __forceinline__ void lstm_cell(const f32x16 (&acc)[NC], float (*c)[4], float (*hn)[4]) {
 #pragma unroll
-    for (int s = 0; s < NC; ++s) {
-        const float ig = sigmoidf_(acc[s][0]);
-        const float fg = sigmoidf_(acc[s][1]);
-        const float gg = tanhf(acc[s][2]);
-        const float og = sigmoidf_(acc[s][3]);
-        const float cn = fg * c[s] + ig * gg;
-        c[s] = cn;
-        hn[s] = og * tanhf(cn);
+    for (int i = 0; i < NC; ++i) {
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) {
+            const float ig = fast_sigmoid(acc[i][4 * jj + 0]);
+            const float fg = fast_sigmoid(acc[i][4 * jj + 1]);
+            const float gg = fast_tanh(acc[i][4 * jj + 2]);
+            const float og = fast_sigmoid(acc[i][4 * jj + 3]);
+            const float cn = fg * c[i][jj] + ig * gg;
+            c[i][jj] = cn;
+            hn[i][jj] = og * fast_tanh(cn);
+        }
     }
 }
 
-// fused linear head on the top-layer h (encoders): NTH output tiles, natural order
-template <int NTH>
-__device__ __forceinline__ void lstm_head(const LstmSeqArgs& a, const float* htop, int lane, long row,
-                                          bool row_ok, int t) {
-    f32x4 acc2[NTH];
-    load_bias<NTH>(acc2, (const float4*)a.head_b + lane);
-    tile_gemm<NTH>(acc2, (const float4*)a.head_w + lane, htop, a.head_nq);
-    if (!row_ok) return;
-    const int g = lane >> 4;
+template <int NC, int NT, int XMODE>
+__device__ __forceinline__ void lstm_chunk(const LstmSeqArgs& a, int l, int tile0, int tstride, long rowtile, int t,
+                                           int lane, const float* xs, const float* hb, float (*c)[4], float (*hn)[4]) {
+    f32x16 acc[NC];
+    int toff[NC];
 #pragma unroll
-    for (int tt = 0; tt < NTH; ++tt)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int f = 16 * tt + 4 * g + r;
-            if (f < a.nh) a.head_out[((size_t)row * a.T + t) * a.nh + f] = acc2[tt][r];
-        }
+    for (int i = 0; i < NC; ++i) {
+        int tl = tile0 + i * tstride;
+        if (tl > NT - 1) tl = NT - 1;            // out-of-range tiles of a split wave: computed, never stored
+        toff[i] = tl * 64;
+    }
+    load_bias<NC>(acc, a.b[l], toff, lane >> 5);
+    lstm_gates<NC, NT, XMODE>(acc, a, l, toff, rowtile, t, lane, xs, hb);
+    lstm_cell<NC>(acc, c, hn);
 }
 
-template <int NT, int NL, int XMODE>
-__global__ void __launch_bounds__(256, 2) lstm_seq_kernel(LstmSeqArgs a) {
+// fused decoder head on the top-layer h of this step (SPLIT = 1 only)
+template <int NT>
+__device__ __forceinline__ void fused_head(const LstmSeqArgs& a, const float* htop, int lane, long row, bool row_ok,
+                                           int to) {
+    const DenseChainArgs& hd = a.head;
+    const int hh = lane >> 5;
+    const RowIo io = make_rowio(hd, row, row_ok, to);
+    f32x16 cur[kHeadTiles];
+    int toff[kHeadTiles];
+#pragma unroll
+    for (int i = 0; i < kHeadTiles; ++i) toff[i] = i * 64;
+    load_bias<kHeadTiles>(cur, hd.layer[0].b, toff, hh);
+    gemm_seg<kHeadTiles>(cur, (const float4*)hd.layer[0].w + lane, toff, kHeadTiles * 64, htop, NT);
+    dense_epilogue<kHeadTiles>(hd, io, 0, false, cur, hh, hd.layer[0].n_relu);
+#pragma unroll 1
+    for (int li = 1; li < hd.n_layers - 1; ++li) {
+        f32x16 nxt[kHeadTiles];
+        load_bias<kHeadTiles>(nxt, hd.layer[li].b, toff, hh);
+        dense_reg<kHeadTiles>(nxt, cur, (const float4*)hd.layer[li].w + lane);
+        dense_epilogue<kHeadTiles>(hd, io, li, false, nxt, hh, hd.layer[li].n_relu);
+#pragma unroll
+        for (int tt = 0; tt < kHeadTiles; ++tt) cur[tt] = nxt[tt];
+    }
+    const int li = hd.n_layers - 1;
+    const float4* wl = (const float4*)hd.layer[li].w + lane;
+#define VSV_LAST(NTO)                                                       \
+    {                                                                       \
+        f32x16 o[NTO];                                                      \
+        int tf[NTO];                                                        \
+        _Pragma("unroll") for (int i = 0; i < NTO; ++i) tf[i] = i * 64;     \
+        load_bias<NTO>(o, hd.layer[li].b, tf, hh);                          \
+        dense_reg<NTO>(o, cur, wl);                                         \
+        dense_epilogue<NTO>(hd, io, li, true, o, hh, hd.layer[li].n_relu);  \
+        dense_store<NTO>(hd, io, o, hh);                                    \
+    }
+    switch (hd.layer[li].nt) {
+        case 1: VSV_LAST(1) break;
+        case 2: VSV_LAST(2) break;
+        case 3: VSV_LAST(3) break;
+        default: VSV_LAST(4) break;
+    }
+#undef VSV_LAST
+}
+
+template <int NT, int NL, int XMODE, int SPLIT, bool HEAD>
+__global__ void __launch_bounds__(256, (SPLIT == 1) ? 1 : 2) lstm_kernel(const LstmSeqArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
+    static_assert(SPLIT == 1 || SPLIT == 4, "SPLIT is 1 or 4");
+    static_assert(!HEAD || SPLIT == 1, "the fused head needs SPLIT = 1");
+    constexpr int HPK = 4 * NT;                                   // k-steps of one layer's h
+    constexpr int HP = 8 * NT;                                    // padded hidden units
+    constexpr int NOWN = (SPLIT == 1) ? NT : (NT + SPLIT - 1) / SPLIT;
+    constexpr int NC0 = (NOWN < 8) ? NOWN : 8;
+    constexpr int NC1 = NOWN - NC0;
+    static_assert(NC1 <= 8, "at most 16 gate tiles per wave");
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const long rowtile = (long)blockIdx.x * 4 + wave;
-    if (rowtile >= a.n_rowtiles) return;
-    const int g = lane >> 4, m = lane & 15;
-    const long row_raw = rowtile * 16 + m;
+    const long rowtile = (SPLIT == 1) ? (long)blockIdx.x * 4 + wave : (long)blockIdx.x;
+    if (SPLIT == 1 && rowtile >= a.n_rowtiles) return;            // no barriers in this schedule
+    const int hh = lane >> 5, m = lane & 31;
+    const long row_raw = rowtile * 32 + m;
     const bool row_ok = row_raw < a.n_rows;
     const long row = row_ok ? row_raw : a.n_rows - 1;
     const int kx = a.kx;
-    const int xk = (XMODE == 0) ? 0 : kx;                  // x k-steps staged in LDS (decoder only)
-    const int ks_total = xk + NL * NT + 4;                 // + zeroed pad for the last quad
-    float* priv = smem + (size_t)wave * ks_total * 64 + lane;
-    float* hbase = priv + (size_t)xk * 64;                 // h of layer l at hbase[(l*NT + s)*64]
-    constexpr int HP = 4 * NT;
+    const int xk = (XMODE == 0) ? 0 : kx;                         // x k-steps staged in LDS (decoder only)
+    const int slots = xk + NL * HPK;
+    float* xs = smem + ((SPLIT == 1) ? (size_t)wave * slots * 64 : 0) + lane;
+    float* hb = xs + (size_t)xk * 64;                             // h of layer l: hb + l*HPK*64
+    const int tile0 = (SPLIT == 1) ? 0 : wave;
+    constexpr int TS = (SPLIT == 1) ? 1 : SPLIT;
+    const bool writer = (SPLIT == 1) || wave == 0;
 
-    float c[NL][NT];
+    DecIn di = {};
+    if (XMODE == 1) {
+        const vsv_decode_in& d = a.din;
+        di.ctx = d.ctx ? d.ctx + (row / d.ctx_div) * d.ctx_rs : nullptr;
+        di.z_idx = (row / d.z_div) * d.z_rs;
+        di.eps = d.eps_in ? d.eps_in + (size_t)row * d.eps_T * a.L : nullptr;
+        di.sample = (uint32_t)(row % d.S);
+        di.day = (uint32_t)(d.day0 + row / d.S);
+    }
+
+    float c[NL][NOWN][4];
+    {
+        const float* st = nullptr;
+        if (XMODE == 1 && a.din.state_in) st = a.din.state_in + (size_t)(row / a.din.state_div) * NL * 2 * HP;
 #pragma unroll
-    for (int l = 0; l < NL; ++l) {
+        for (int l = 0; l < NL; ++l) {
 #pragma unroll
-        for (int s = 0; s < NT; ++s) {
-            float h0 = 0.0f, c0 = 0.0f;
-            if (XMODE == 1 && a.din.state_in) {
-                const float* st = a.din.state_in + ((size_t)(row / a.din.state_div) * NL + l) * 2 * HP;
-                h0 = st[4 * s + g];
-                c0 = st[HP + 4 * s + g];
+            for (int i = 0; i < NOWN; ++i) {
+                const int tl = tile0 + i * TS;
+#pragma unroll
+                for (int jj = 0; jj < 4; ++jj) {
+                    float h0 = 0.0f, c0 = 0.0f;
+                    if (st && tl < NT) {
+                        const int u = 8 * tl + 2 * jj + hh;
+                        h0 = st[(size_t)l * 2 * HP + u];
+                        c0 = st[(size_t)l * 2 * HP + HP + u];
+                    }
+                    if (tl < NT) hb[(l * HPK + 4 * tl + jj) * 64] = h0;
+                    c[l][i][jj] = c0;
+                }
             }
-            hbase[(l * NT + s) * 64] = h0;
-            c[l][s] = c0;
         }
     }
-    for (int s = 0; s < 4; ++s) hbase[(NL * NT + s) * 64] = 0.0f;
+    if (SPLIT > 1) __syncthreads();
 
     const int t_outs = a.T - a.t_out0;
     for (int t = 0; t < a.T; ++t) {
-        // ---- x part of layer 0 -> priv[0 .. kx)
+        // ---- x part of layer 0 -> xs[0 .. kx)   (split waves all write the same values)
         if (XMODE == 1) {
-            for (int s = 0; s < kx; ++s) priv[s * 64] = decoder_input(a, row, t, 4 * s + g);
+            for (int s = 0; s < kx; ++s) xs[s * 64] = decoder_input(a, di, row, row_ok, writer, t, 2 * s + hh);
         }
-        // ---- layers.  The gate tiles are computed in chunks of <= TC tiles so that the
-        // accumulators of one chunk (4 registers per tile) and both layers' cell states
-        // stay inside the 256-register budget of 2 waves per SIMD.  h of a layer is
-        // overwritten only after ALL of its chunks have accumulated (chunk 0's new h
-        // waits in registers meanwhile).
 #pragma unroll
         for (int l = 0; l < NL; ++l) {
-            constexpr int TC = 16;
-            constexpr int NC0 = (NT < TC) ? NT : TC;          // tiles in chunk 0
-            constexpr int NC1 = NT - NC0;                     // tiles in chunk 1 (0 if none)
-            float* hl = hbase + (size_t)l * NT * 64;
-            float hn0[NC0];
-            {
-                f32x4 acc[NC0];
-                load_bias<NC0>(acc, (const float4*)a.b[l] + lane);
-                lstm_gemm<NC0, XMODE>(acc, a, l, 0, NT, rowtile, t, lane, priv, hbase);
-                lstm_cell<NC0>(acc, &c[l][0], hn0);
-            }
+            float hn[NOWN][4];
+            lstm_chunk<NC0, NT, XMODE>(a, l, tile0, TS, rowtile, t, lane, xs, hb, &c[l][0], &hn[0]);
             if (NC1 > 0) {
                 constexpr int NC1s = NC1 > 0 ? NC1 : 1;
-                f32x4 acc[NC1s];
-                float hn1[NC1s];
-                load_bias<NC1s>(acc, (const float4*)a.b[l] + NC0 * 64 + lane);
-                lstm_gemm<NC1s, XMODE>(acc, a, l, NC0, NT, rowtile, t, lane, priv, hbase);
-                lstm_cell<NC1s>(acc, &c[l][NC0], hn1);
-#pragma unroll
-                for (int s = 0; s < NC1s; ++s) hl[(NC0 + s) * 64] = hn1[s];
+                lstm_chunk<NC1s, NT, XMODE>(a, l, tile0 + NC0 * TS, TS, rowtile, t, lane, xs, hb, &c[l][NC0], &hn[NC0]);
             }
+            // h of this layer is overwritten only after every wave has read the old one
+            if (SPLIT > 1) __syncthreads();
+            float* hl = hb + (size_t)l * HPK * 64;
 #pragma unroll
-            for (int s = 0; s < NC0; ++s) hl[s * 64] = hn0[s];
+            for (int i = 0; i < NOWN; ++i) {
+                const int tl = tile0 + i * TS;
+                if (tl < NT) {
+#pragma unroll
+                    for (int jj = 0; jj < 4; ++jj) hl[(4 * tl + jj) * 64] = hn[i][jj];
+                }
+            }
+            if (SPLIT > 1) __syncthreads();
         }
-        const float* htop = hbase + (size_t)(NL - 1) * NT * 64;
+        const float* htop = hb + (size_t)(NL - 1) * HPK * 64;
         // ---- outputs
         if (a.hout && t >= a.t_out0) {
-            float* ho = a.hout + ((size_t)(rowtile * t_outs + (t - a.t_out0)) * NT) * 64 + lane;
-            for (int s = 0; s < NT; ++s) ho[s * 64] = htop[s * 64];
+            float* ho = a.hout + ((size_t)(rowtile * t_outs + (t - a.t_out0)) * HPK) * 64 + lane;
+#pragma unroll
+            for (int i = 0; i < NOWN; ++i) {
+                const int tl = tile0 + i * TS;
+                if (tl < NT) {
+#pragma unroll
+                    for (int jj = 0; jj < 4; ++jj) ho[(4 * tl + jj) * 64] = htop[(4 * tl + jj) * 64];
+                }
+            }
         }
-        if (a.head_w) {
-            if (a.head_nt == 2)
-                lstm_head<2>(a, htop, lane, row, row_ok, t);
-            else
-                lstm_head<1>(a, htop, lane, row, row_ok, t);
-        }
+        if (HEAD && t >= a.t_out0) fused_head<NT>(a, htop, lane, row, row_ok, t - a.t_out0);
     }
     if (a.state_out && row_ok) {
 #pragma unroll
         for (int l = 0; l < NL; ++l) {
             float* st = a.state_out + ((size_t)row * NL + l) * 2 * HP;
 #pragma unroll
-            for (int s = 0; s < NT; ++s) {
-                st[4 * s + g] = hbase[(l * NT + s) * 64];
-                st[HP + 4 * s + g] = c[l][s];
+            for (int i = 0; i < NOWN; ++i) {
+                const int tl = tile0 + i * TS;
+                if (tl < NT) {
+#pragma unroll
+                    for (int jj = 0; jj < 4; ++jj) {
+                        const int u = 8 * tl + 2 * jj + hh;
+                        st[u] = hb[(l * HPK + 4 * tl + jj) * 64];
+                        st[HP + u] = c[l][i][jj];
+                    }
+                }
             }
         }
     }
@@ -502,40 +671,55 @@ static int set_lds(K kernel, size_t bytes) {
 }
 
 static int launch_dense_chain(const DenseChainArgs& a, hipStream_t st) {
-    const long tiles = a.n_rowtiles * a.T;
-    if (tiles <= 0) return 0;
-    const size_t lds = 4 * 2 * 32 * 64 * sizeof(float);
-    const long blocks = (tiles + 3) / 4;
+    const long insts = a.n_rowtiles * a.T;
+    if (insts <= 0) return 0;
+    for (int i = 0; i < a.n_layers; ++i) {
+        if (a.layer[i].nt < 1 || a.layer[i].nt > kHeadTiles || a.layer[i].nq > 4 * kHeadTiles) {
+            set_error("dense_chain: layer %d has an unsupported shape (nt %d, nq %d)", i, a.layer[i].nt, a.layer[i].nq);
+            return -4;
+        }
+    }
+    if (a.in_ks > kDenseSlots) { set_error("dense_chain: input wider than %d k-steps", kDenseSlots); return -4; }
+    const size_t lds = (size_t)4 * kDenseSlots * 64 * sizeof(float);
+    const long blocks = (insts + 3) / 4;
     if (blocks > 0x7fffffffL) { set_error("dense_chain: too many tiles"); return -2; }
     hipLaunchKernelGGL(dense_chain_kernel, dim3((unsigned)blocks), dim3(256), lds, st, a);
     return launch_check("dense_chain_kernel");
 }
 
-template <int NT, int NL, int XMODE>
+// rows at or below this many 32-row tiles use the split schedule (4 waves per tile)
+constexpr long kSplitMaxRowtiles = 1024;
+
+template <int NT, int NL, int XMODE, int SPLIT, bool HEAD>
 static int launch_lstm_t(const LstmSeqArgs& a, hipStream_t st) {
-    const size_t lds = (size_t)4 * ((XMODE == 0 ? 0 : a.kx) + NL * NT + 4) * 64 * sizeof(float);
-    int rc = set_lds(lstm_seq_kernel<NT, NL, XMODE>, lds);
+    const int slots = (XMODE == 0 ? 0 : a.kx) + NL * 4 * NT;
+    const size_t lds = (size_t)(SPLIT == 1 ? 4 : 1) * slots * 64 * sizeof(float);
+    int rc = set_lds(lstm_kernel<NT, NL, XMODE, SPLIT, HEAD>, lds);
     if (rc) return rc;
-    const long blocks = (a.n_rowtiles + 3) / 4;
-    if (blocks > 0x7fffffffL) { set_error("lstm_seq: too many rows"); return -2; }
-    hipLaunchKernelGGL((lstm_seq_kernel<NT, NL, XMODE>), dim3((unsigned)blocks), dim3(256), lds, st, a);
-    return launch_check("lstm_seq_kernel");
+    const long blocks = (SPLIT == 1) ? (a.n_rowtiles + 3) / 4 : a.n_rowtiles;
+    if (blocks > 0x7fffffffL) { set_error("lstm_kernel: too many rows"); return -2; }
+    hipLaunchKernelGGL((lstm_kernel<NT, NL, XMODE, SPLIT, HEAD>), dim3((unsigned)blocks), dim3(256), lds, st, a);
+    return launch_check("lstm_kernel");
+}
+
+template <int NT, int XMODE>
+static int launch_lstm_nt(const LstmSeqArgs& a, int NL, bool split, bool head, hipStream_t st) {
+    if (split) return NL == 2 ? launch_lstm_t<NT, 2, XMODE, 4, false>(a, st) : launch_lstm_t<NT, 1, XMODE, 4, false>(a, st);
+    if (XMODE == 1 && head)
+        return NL == 2 ? launch_lstm_t<NT, 2, XMODE, 1, (XMODE == 1)>(a, st) : launch_lstm_t<NT, 1, XMODE, 1, (XMODE == 1)>(a, st);
+    return NL == 2 ? launch_lstm_t<NT, 2, XMODE, 1, false>(a, st) : launch_lstm_t<NT, 1, XMODE, 1, false>(a, st);
 }
 
 template <int XMODE>
-static int launch_lstm(const LstmSeqArgs& a, int NT, int NL, hipStream_t st) {
+static int launch_lstm(const LstmSeqArgs& a, int NT, int NL, bool split, bool head, hipStream_t st) {
     if (a.n_rowtiles <= 0 || a.T <= 0) return 0;
-#define VSV_CASE(nt)                                                         \
-    case nt:                                                                  \
-        return NL == 2 ? launch_lstm_t<nt, 2, XMODE>(a, st) : launch_lstm_t<nt, 1, XMODE>(a, st);
     switch (NT) {
-        VSV_CASE(25)
-        VSV_CASE(32)
+        case 13: return launch_lstm_nt<13, XMODE>(a, NL, split, head, st);
+        case 16: return launch_lstm_nt<16, XMODE>(a, NL, split, head, st);
         default:
-            set_error("unsupported LSTM hidden size: %d tiles of 4 units (built: 25 = hidden 97..100, 32 = hidden 125..128)", NT);
+            set_error("unsupported LSTM hidden size: %d tiles of 8 units (built: 13 = hidden 97..104, 16 = hidden 121..128)", NT);
             return -4;
     }
-#undef VSV_CASE
 }
 
 static thread_local hipEvent_t g_prof_ev[2] = {nullptr, nullptr};
@@ -566,9 +750,9 @@ extern "C" size_t vsv_encode_ws_bytes(const vsv_dims* dims, long n_rows, int T) 
     Layout lay;
     const char* msg = nullptr;
     if (!dims || make_layout(*dims, lay, &msg) != 0 || n_rows < 0 || T < 0) return 0;
-    const long rt = (n_rows + 15) / 16;
+    const long rt = (n_rows + 31) / 32;
     const int kx = lay.enc[0].kx > lay.enc[1].kx ? lay.enc[0].kx : lay.enc[1].kx;
-    return align256((size_t)rt * T * kx * 64 * sizeof(float)) + 256;
+    return align256((size_t)rt * T * kx * 64 * sizeof(float)) + align256((size_t)rt * T * 4 * lay.NTm * 64 * sizeof(float)) + 256;
 }
 
 extern "C" int vsv_encode(const vsv_dims* dims, const float* packed, int which,
@@ -584,9 +768,11 @@ extern "C" int vsv_encode(const vsv_dims* dims, const float* packed, int which,
     if (ws_bytes < vsv_encode_ws_bytes(dims, n_rows, T)) { set_error("vsv_encode: workspace too small"); return -1; }
     hipStream_t st = (hipStream_t)stream;
     const EncLayout& e = lay.enc[which];
-    const long rt = (n_rows + 15) / 16;
+    const long rt = (n_rows + 31) / 32;
     float* xe = (float*)(((uintptr_t)ws + 255) & ~(uintptr_t)255);
+    float* hbuf = (float*)((char*)xe + align256((size_t)rt * T * e.kx * 64 * sizeof(float)));
 
+    // 1. conv embedding of every (row, t): surface -> [conv+ReLU]* -> [emb | ex] in tile-B layout
     DenseChainArgs a = {};
     a.n_layers = e.n_conv;
     for (int i = 0; i < e.n_conv; ++i) fill_dense(a, i, packed, e.conv[i]);
@@ -599,25 +785,34 @@ extern "C" int vsv_encode(const vsv_dims* dims, const float* packed, int which,
     int rc = launch_dense_chain(a, st);
     if (rc) return rc;
 
+    // 2. LSTM over time, top-layer h of every step -> hbuf (tile-B)
     LstmSeqArgs l = {};
-    for (int i = 0; i < lay.NL; ++i) {
-        l.w[i] = packed + e.lstm[i].w_off; l.b[i] = packed + e.lstm[i].b_off; l.nq[i] = e.lstm[i].nq;
-    }
+    for (int i = 0; i < lay.NL; ++i) { l.w[i] = packed + e.lstm[i].w_off; l.b[i] = packed + e.lstm[i].b_off; }
     l.kx = e.kx; l.n_rows = n_rows; l.n_rowtiles = rt; l.T = T;
     l.x_tileb = xe; l.L = lay.L;
-    l.t_out0 = T;
-    l.head_w = packed + e.head.w_off; l.head_b = packed + e.head.b_off; l.head_nq = e.head.nq; l.head_nt = e.head.nt; l.nh = e.nh;
-    l.head_out = out;
-    return launch_lstm<0>(l, lay.NTm, lay.NL, st);
+    l.hout = hbuf; l.t_out0 = 0;
+    rc = launch_lstm<0>(l, lay.NTm, lay.NL, rt <= kSplitMaxRowtiles, false, st);
+    if (rc) return rc;
+
+    // 3. linear head on every step
+    DenseChainArgs h = {};
+    h.n_layers = 1;
+    fill_dense(h, 0, packed, e.head);
+    h.n_rows = n_rows; h.n_rowtiles = rt; h.T = T;
+    h.in_mode = 1; h.in = hbuf; h.in_ks = 4 * lay.NTm;
+    h.out_mode = 1; h.out = out; h.out_f = e.nh; h.S = 1;
+    h.aux_layer = -1;
+    return launch_dense_chain(h, st);
 }
 
 extern "C" size_t vsv_decode_ws_bytes(const vsv_dims* dims, long n_rows, int T, int t_out0) {
     Layout lay;
     const char* msg = nullptr;
     if (!dims || make_layout(*dims, lay, &msg) != 0 || n_rows < 0 || T < 0) return 0;
-    const long rt = (n_rows + 15) / 16;
+    const long rt = (n_rows + 31) / 32;
     const int touts = T - t_out0 > 0 ? T - t_out0 : 0;
-    return align256((size_t)rt * touts * lay.NTd * 64 * sizeof(float)) + 256;
+    if (rt > kSplitMaxRowtiles) return 256;                    // fused head: no h buffer
+    return align256((size_t)rt * touts * 4 * lay.NTd * 64 * sizeof(float)) + 256;
 }
 
 extern "C" int vsv_decode(const vsv_dims* dims, const float* packed, const vsv_decode_in* in,
@@ -649,13 +844,12 @@ extern "C" int vsv_decode(const vsv_dims* dims, const float* packed, const vsv_d
     if (out_mode == 1 && touts > 0 && (in->S < 1 || n_rows % in->S != 0)) { set_error("vsv_decode: out_mode 1 needs n_rows %% S == 0"); return -1; }
     hipStream_t st = (hipStream_t)stream;
     const DecLayout& dc = lay.dec;
-    const long rt = (n_rows + 15) / 16;
+    const long rt = (n_rows + 31) / 32;
+    const bool split = rt <= kSplitMaxRowtiles;
     float* hbuf = ws ? (float*)(((uintptr_t)ws + 255) & ~(uintptr_t)255) : nullptr;
 
     LstmSeqArgs l = {};
-    for (int i = 0; i < lay.NL; ++i) {
-        l.w[i] = packed + dc.lstm[i].w_off; l.b[i] = packed + dc.lstm[i].b_off; l.nq[i] = dc.lstm[i].nq;
-    }
+    for (int i = 0; i < lay.NL; ++i) { l.w[i] = packed + dc.lstm[i].w_off; l.b[i] = packed + dc.lstm[i].b_off; }
     l.kx = dc.kx; l.n_rows = n_rows; l.n_rowtiles = rt; l.T = T;
     l.L = lay.L; l.din = *in; l.z_out = z_out;
     if (l.din.ctx_div < 1) l.din.ctx_div = 1;
@@ -663,23 +857,26 @@ extern "C" int vsv_decode(const vsv_dims* dims, const float* packed, const vsv_d
     if (l.din.S < 1) l.din.S = 1;
     if (l.din.state_div < 1) l.din.state_div = 1;
     l.state_out = state_out;
-    l.hout = touts > 0 ? hbuf : nullptr;
     l.t_out0 = t_out0;
-    hipEvent_t ev0 = g_prof_ev[0], ev1 = g_prof_ev[1];
-    g_prof_ev[0] = g_prof_ev[1] = nullptr;
-    if (ev0) (void)hipEventRecord(ev0, st);
-    int rc = launch_lstm<1>(l, lay.NTd, lay.NL, st);
-    if (ev1) (void)hipEventRecord(ev1, st);
-    if (rc || touts == 0) return rc;
 
-    DenseChainArgs a = {};
+    // the decoder head: Linear -> ConvT+ReLU x n -> Conv [, ex Linear x2 riding in spare features]
+    DenseChainArgs& a = l.head;
     a.n_layers = dc.n_head;
     for (int i = 0; i < dc.n_head; ++i) fill_dense(a, i, packed, dc.head[i]);
     a.n_rows = n_rows; a.n_rowtiles = rt; a.T = touts;
-    a.in_mode = 1; a.in = hbuf; a.in_ks = lay.NTd;
+    a.in_mode = 1; a.in = hbuf; a.in_ks = 4 * lay.NTd;
     a.out_mode = out_mode == 0 ? 1 : 2; a.out = surf_out; a.out_f = dc.n_surf; a.S = l.din.S;
     a.aux_layer = (lay.X > 0 && ex_out) ? dc.ex_layer : -1;
     a.aux = ex_out; a.aux_f0 = dc.ex_f0; a.aux_n = lay.X;
+
+    const bool fused = !split && touts > 0;
+    l.hout = (touts > 0 && !fused) ? hbuf : nullptr;
+    hipEvent_t ev0 = g_prof_ev[0], ev1 = g_prof_ev[1];
+    g_prof_ev[0] = g_prof_ev[1] = nullptr;
+    if (ev0) (void)hipEventRecord(ev0, st);
+    int rc = launch_lstm<1>(l, lay.NTd, lay.NL, split, fused, st);
+    if (ev1) (void)hipEventRecord(ev1, st);
+    if (rc || touts == 0 || fused) return rc;
     return launch_dense_chain(a, st);
 }
 

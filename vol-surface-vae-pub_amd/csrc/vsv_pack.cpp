@@ -30,7 +30,7 @@ static Sec alloc_sec(size_t& cur, int nq, int nt, int n_out, int n_relu) {
     s.w_off = cur;
     cur += (size_t)nq * nt * 256;
     s.b_off = cur;
-    cur += (size_t)nt * 256;
+    cur += (size_t)nt * 32;
     return s;
 }
 
@@ -60,10 +60,17 @@ int make_layout(const vsv_dims& d, Layout& lay, const char** msg) {
     for (int i = 0; i < d.n_ctx_conv; ++i)
         if (d.ctx_surface_hidden[i] < 1 || d.ctx_surface_hidden[i] * 25 + lay.X > kMaxFeat)
             return fail("ctx_surface_hidden[i]*25 + ex_feats_dim must be <= 128");
-    lay.NTm = cdiv(lay.Hm, 4);
+    lay.NTm = cdiv(lay.Hm, 8);
     const int c_last = d.surface_hidden[d.n_conv - 1];
+    if (lay.X > 0) {
+        // the kernels look for the ex-feature slots only in the last (4th) tile of a layer
+        const int cc = d.ctx_surface_hidden[d.n_ctx_conv - 1];
+        const int c0 = d.n_conv > 1 ? d.surface_hidden[d.n_conv - 2] : c_last;
+        if (c_last * 25 < 96 || cc * 25 < 96 || c0 * 25 < 96)
+            return fail("with ex_feats_dim > 0 the last conv layers need >= 4 channels (ex slots live in features 96..127)");
+    }
     lay.Hd = c_last * 25 + lay.X;
-    lay.NTd = cdiv(lay.Hd, 4);
+    lay.NTd = cdiv(lay.Hd, 8);
 
     size_t cur = 0;
     for (int which = 0; which < 2; ++which) {
@@ -74,28 +81,30 @@ int make_layout(const vsv_dims& d, Layout& lay, const char** msg) {
         for (int i = 0; i < e.n_conv; ++i) {
             const bool last = (i == e.n_conv - 1);
             const int n_out = ch[i] * 25 + (last ? lay.X : 0);
-            const int nt = cdiv(n_out, 16);
-            const int nq = (i == 0) ? cdiv(cdiv(25, 4), 4) : nt_prev;
+            const int nt = cdiv(n_out, 32);
+            const int nq = (i == 0) ? cdiv(cdiv(25, 2), 4) : 4 * nt_prev;
             e.conv[i] = alloc_sec(cur, nq, nt, n_out, ch[i] * 25);
             nt_prev = nt;
         }
         e.E = ch[e.n_conv - 1] * 25 + lay.X;
         e.ex_f0 = ch[e.n_conv - 1] * 25;
-        e.kx = 4 * nt_prev;
-        e.lstm[0] = alloc_sec(cur, cdiv(e.kx + lay.NTm, 4), lay.NTm, 4 * lay.Hm, 0);
-        if (lay.NL == 2) e.lstm[1] = alloc_sec(cur, cdiv(2 * lay.NTm, 4), lay.NTm, 4 * lay.Hm, 0);
+        e.kx = 16 * nt_prev;
+        e.lstm[0] = alloc_sec(cur, e.kx / 4 + lay.NTm, lay.NTm, 4 * lay.Hm, 0);
+        if (lay.NL == 2) e.lstm[1] = alloc_sec(cur, 2 * lay.NTm, lay.NTm, 4 * lay.Hm, 0);
         e.nh = which ? lay.L : 2 * lay.L;
-        e.head = alloc_sec(cur, cdiv(lay.NTm, 4), cdiv(e.nh, 16), e.nh, 0);
+        e.head = alloc_sec(cur, lay.NTm, cdiv(e.nh, 32), e.nh, 0);
     }
     DecLayout& dc = lay.dec;
-    dc.kx = cdiv(2 * lay.L, 4);
-    dc.lstm[0] = alloc_sec(cur, cdiv(dc.kx + lay.NTd, 4), lay.NTd, 4 * lay.Hd, 0);
-    if (lay.NL == 2) dc.lstm[1] = alloc_sec(cur, cdiv(2 * lay.NTd, 4), lay.NTd, 4 * lay.Hd, 0);
-    // head: Linear(Hd -> c_last*25 [+X]) ; ConvT x n_conv ; Conv -> Q*25
+    dc.kx = 4 * cdiv(lay.L, 4);                       // 2L features, 2 per k-step, rounded up to a quad
+    dc.lstm[0] = alloc_sec(cur, dc.kx / 4 + lay.NTd, lay.NTd, 4 * lay.Hd, 0);
+    if (lay.NL == 2) dc.lstm[1] = alloc_sec(cur, 2 * lay.NTd, lay.NTd, 4 * lay.Hd, 0);
+    // head: Linear(Hd -> c_last*25 [+X]) ; ConvT x n_conv ; Conv -> Q*25.
+    // All layers but the last are padded to kHeadTiles tiles (zero rows) so the fused
+    // decoder kernel can chain them through registers with compile-time shapes.
     int nh = 0;
     {
         const int n_out = c_last * 25 + lay.X;
-        dc.head[nh++] = alloc_sec(cur, cdiv(lay.NTd, 4), cdiv(n_out, 16), n_out, 0);
+        dc.head[nh++] = alloc_sec(cur, lay.NTd, kHeadTiles, n_out, 0);
     }
     int cin = c_last;
     for (int i = 0; i < d.n_conv; ++i) {
@@ -103,18 +112,14 @@ int make_layout(const vsv_dims& d, Layout& lay, const char** msg) {
         const int cout = (i < d.n_conv - 1) ? d.surface_hidden[d.n_conv - 2 - i] : cin;
         const bool carries_ex = (i == 0 && lay.X > 0);
         const int n_out = cout * 25 + (carries_ex ? lay.X : 0);
-        const int nt_prev = dc.head[nh - 1].nt;
         if (carries_ex) {
             dc.ex_layer = nh;
             dc.ex_f0 = cout * 25;
         }
-        dc.head[nh++] = alloc_sec(cur, nt_prev, cdiv(n_out, 16), n_out, cout * 25);
+        dc.head[nh++] = alloc_sec(cur, 4 * kHeadTiles, kHeadTiles, n_out, cout * 25);
         cin = cout;
     }
-    {
-        const int nt_prev = dc.head[nh - 1].nt;
-        dc.head[nh++] = alloc_sec(cur, nt_prev, cdiv(lay.Q * 25, 16), lay.Q * 25, 0);
-    }
+    dc.head[nh++] = alloc_sec(cur, 4 * kHeadTiles, cdiv(lay.Q * 25, 32), lay.Q * 25, 0);
     dc.n_head = nh;
     dc.n_surf = lay.Q * 25;
     lay.total = cur;
@@ -133,30 +138,33 @@ static void pack_sec(float* blob, const Sec& s, const OutMap& fo, const InMap& f
         for (int t = 0; t < s.nt; ++t)
             for (int l = 0; l < 64; ++l)
                 for (int j = 0; j < 4; ++j) {
-                    const int r = fo(t, l & 15), c = fi(4 * q + j, l >> 4);
+                    const int r = fo(t, l & 31), c = fi(4 * q + j, l >> 5);
                     w[(((size_t)q * s.nt + t) * 64 + l) * 4 + j] = (r >= 0 && c >= 0) ? W(r, c) : 0.0f;
                 }
     float* b = blob + s.b_off;
     for (int t = 0; t < s.nt; ++t)
-        for (int l = 0; l < 64; ++l)
-            for (int r4 = 0; r4 < 4; ++r4) {
-                const int r = fo(t, 4 * (l >> 4) + r4);
-                b[((size_t)t * 64 + l) * 4 + r4] = (r >= 0) ? B(r) : 0.0f;
+        for (int hh = 0; hh < 2; ++hh)
+            for (int reg = 0; reg < 16; ++reg) {
+                const int r = fo(t, 8 * (reg >> 2) + 4 * hh + (reg & 3));
+                b[((size_t)t * 2 + hh) * 16 + reg] = (r >= 0) ? B(r) : 0.0f;
             }
 }
 
-static OutMap out_nat16(int n_out) {
-    return [=](int t, int i) { const int f = 16 * t + i; return f < n_out ? f : -1; };
+static OutMap out_nat32(int n_out) {
+    return [=](int t, int i) { const int f = 32 * t + i; return f < n_out ? f : -1; };
 }
-// LSTM gates: tile t holds units 4t..4t+3; D row i = 4*unit_local + gate
+// LSTM gates: tile t holds units 8t..8t+7; D row i = 4*unit_local + gate
 static OutMap out_gate(int H) {
-    return [=](int t, int i) { const int u = 4 * t + (i >> 2); return u < H ? (i & 3) * H + u : -1; };
+    return [=](int t, int i) { const int u = 8 * t + (i >> 2); return u < H ? (i & 3) * H + u : -1; };
 }
 static InMap in_nat(int n_in) {
-    return [=](int s, int kg) { const int f = 4 * s + kg; return f < n_in ? f : -1; };
+    return [=](int s, int hh) { const int f = 2 * s + hh; return f < n_in ? f : -1; };
 }
 static InMap in_perm(int n_in) {
-    return [=](int s, int kg) { const int f = 16 * (s >> 2) + 4 * kg + (s & 3); return f < n_in ? f : -1; };
+    return [=](int s, int hh) {
+        const int f = 32 * (s >> 4) + 8 * ((s >> 2) & 3) + 4 * hh + (s & 3);
+        return f < n_in ? f : -1;
+    };
 }
 
 // Dense (Toeplitz) matrix of a 3x3, stride 1, pad 1 conv on a 5x5 grid.
@@ -181,17 +189,17 @@ static std::vector<float> conv_matrix(const float* w, int cin, int cout, bool tr
 
 static void pack_lstm(float* blob, const Sec* secs, const vsv_lstm_raw& raw, int NL, int H, int in0,
                       int kx, const InMap& x_map) {
-    const int NT = (H + 3) / 4;
+    const int NT = (H + 7) / 8;
     for (int l = 0; l < NL; ++l) {
         const float *wih = raw.w_ih[l], *whh = raw.w_hh[l], *bih = raw.b_ih[l], *bhh = raw.b_hh[l];
         const int n_in = (l == 0) ? in0 : H;
-        const int kin = (l == 0) ? kx : NT;            // k-steps of the input part
+        const int kin = (l == 0) ? kx : 4 * NT;        // k-steps of the input part
         const InMap imap = (l == 0) ? x_map : in_nat(H);
         const InMap hmap = in_nat(H);
         // combined column space: [0, n_in) -> w_ih, [n_in, n_in+H) -> w_hh
-        InMap fi = [=](int s, int kg) {
-            if (s < kin) return imap(s, kg);
-            const int c = hmap(s - kin, kg);
+        InMap fi = [=](int s, int hh) {
+            if (s < kin) return imap(s, hh);
+            const int c = hmap(s - kin, hh);
             return c < 0 ? -1 : n_in + c;
         };
         WFn W = [=](int r, int c) { return c < n_in ? wih[(size_t)r * n_in + c] : whh[(size_t)r * H + (c - n_in)]; };
@@ -224,7 +232,7 @@ extern "C" size_t vsv_state_floats(const vsv_dims* dims) {
         set_error("vsv_state_floats: %s", msg ? msg : "null dims");
         return 0;
     }
-    return (size_t)lay.NL * 2 * 4 * lay.NTd;
+    return (size_t)lay.NL * 2 * 8 * lay.NTd;
 }
 
 extern "C" int vsv_pack_weights(const vsv_dims* dims, const vsv_raw_weights* raw, float* out) {
@@ -257,7 +265,7 @@ extern "C" int vsv_pack_weights(const vsv_dims* dims, const vsv_raw_weights* raw
             WFn W = [&, n_in](int r, int c) { return M[(size_t)r * n_in + c]; };
             BFn B = [=](int r) { return bias[r / 25]; };
             // rows >= n_out (ex-feature slots of the last layer) stay zero: out map limited to n_out
-            pack_sec(out, e.conv[i], out_nat16(n_out), i == 0 ? in_nat(n_in) : in_perm(n_in), W, B);
+            pack_sec(out, e.conv[i], out_nat32(n_out), i == 0 ? in_nat(n_in) : in_perm(n_in), W, B);
             cin = cout;
         }
         const vsv_lstm_raw& mem = which ? raw->ctx_mem : raw->enc_mem;
@@ -266,12 +274,12 @@ extern "C" int vsv_pack_weights(const vsv_dims* dims, const vsv_raw_weights* raw
             const float *wm = raw->z_mean_w, *bm = raw->z_mean_b, *wv = raw->z_log_var_w, *bv = raw->z_log_var_b;
             WFn W = [=](int r, int c) { return r < L ? wm[(size_t)r * Hm + c] : wv[(size_t)(r - L) * Hm + c]; };
             BFn B = [=](int r) { return r < L ? bm[r] : bv[r - L]; };
-            pack_sec(out, e.head, out_nat16(2 * L), in_nat(Hm), W, B);
+            pack_sec(out, e.head, out_nat32(2 * L), in_nat(Hm), W, B);
         } else {
             const float *wc = raw->ctx_comp_w, *bc = raw->ctx_comp_b;
             WFn W = [=](int r, int c) { return wc[(size_t)r * Hm + c]; };
             BFn B = [=](int r) { return bc[r]; };
-            pack_sec(out, e.head, out_nat16(L), in_nat(Hm), W, B);
+            pack_sec(out, e.head, out_nat32(L), in_nat(Hm), W, B);
         }
     }
 
@@ -286,7 +294,7 @@ extern "C" int vsv_pack_weights(const vsv_dims* dims, const vsv_raw_weights* raw
         if (X > 0 && (!we || !be)) { set_error("vsv_pack_weights: missing ex_feats_decoder_input"); return -1; }
         WFn W = [=](int r, int c) { return r < ns ? ws[(size_t)r * Hd + c] : we[(size_t)(r - ns) * Hd + c]; };
         BFn B = [=](int r) { return r < ns ? bs[r] : be[r - ns]; };
-        pack_sec(out, dc.head[hi++], out_nat16(ns + X), in_nat(Hd), W, B);
+        pack_sec(out, dc.head[hi++], out_nat32(ns + X), in_nat(Hd), W, B);
     }
     int cin = c_last;
     for (int i = 0; i < d.n_conv; ++i) {
@@ -305,7 +313,7 @@ extern "C" int vsv_pack_weights(const vsv_dims* dims, const vsv_raw_weights* raw
         };
         BFn B = [=](int r) { return r < n_out ? bias[r / 25] : b2[r - n_out]; };
         const int n_in_tot = n_in + ((i == 0) ? X : 0);
-        pack_sec(out, dc.head[hi++], out_nat16(n_out + (carries_ex ? X : 0)), in_perm(n_in_tot), W, B);
+        pack_sec(out, dc.head[hi++], out_nat32(n_out + (carries_ex ? X : 0)), in_perm(n_in_tot), W, B);
         cin = cout;
     }
     {
@@ -314,7 +322,7 @@ extern "C" int vsv_pack_weights(const vsv_dims* dims, const vsv_raw_weights* raw
         const float* bias = raw->dec_out_b;
         WFn W = [&, n_in](int r, int c) { return M[(size_t)r * n_in + c]; };
         BFn B = [=](int r) { return bias[r / 25]; };
-        pack_sec(out, dc.head[hi++], out_nat16(lay.Q * 25), in_perm(n_in), W, B);
+        pack_sec(out, dc.head[hi++], out_nat32(lay.Q * 25), in_perm(n_in), W, B);
     }
     return 0;
 }

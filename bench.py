@@ -47,7 +47,13 @@ def flops_per_unit(L: int, X: int, Hm: int = 100, c_last: int = 5, Q: int = 3):
     f_dec_lstm = 2 * 4 * Hd * (2 * L + Hd) + 2 * 4 * Hd * (2 * Hd)
     conv_dec = 2 * 25 * 9 * (5 * 5 * 3 + 5 * Q)
     f_dec_head = 2 * 125 * Hd + conv_dec + (2 * X * Hd + 2 * X * X if X else 0)
-    return {"enc": f_enc, "ctx": f_ctx, "dec_lstm": f_dec_lstm, "dec_head": f_dec_head}
+    # first decode step of an MC sample: its (h, c) is the day's shared prefix state, so the
+    # recurrent products W_hh.h_prev are computed once per day, not per sample; only the
+    # z-dependent part of layer 0 (the context half of the input is the zero padding) and the
+    # layer-0 -> layer-1 product remain per sample
+    f_dec_lstm_first = 2 * 4 * Hd * L + 2 * 4 * Hd * Hd
+    return {"enc": f_enc, "ctx": f_ctx, "dec_lstm": f_dec_lstm, "dec_head": f_dec_head,
+            "dec_lstm_first": f_dec_lstm_first}
 
 
 def synthetic_calendar(n_days: int, C: int, X: int, seed: int = 1234):
@@ -165,7 +171,10 @@ def main():
     k_ms = [a.elapsed_ms(b) for a, b, _ in events]
     k_rows = [r for _, _, r in events]
     avg_ms = float(np.mean(k_ms))
-    flops_per_launch = float(np.mean(k_rows)) * H * fl["dec_lstm"]
+    # the timed launch is the fused MC decode kernel: per sample one de-duplicated first step,
+    # H-1 full LSTM steps and H decoder heads (DESIGN.md "Measurement")
+    per_row = fl["dec_lstm_first"] + (H - 1) * fl["dec_lstm"] + H * fl["dec_head"]
+    flops_per_launch = float(np.mean(k_rows)) * per_row
     achieved = flops_per_launch / (avg_ms * 1e-3) / 1e12
     traffic = None
     tpath = os.path.join(REPO, "profiles", "pmc_traffic.json")
@@ -195,7 +204,7 @@ def main():
                                f"generation, {N} days/GPU x {S} samples x horizon {H}, p05/p50/p95 reduced on device",
                    "days_per_gpu": N, "samples_per_day": S, "context_len": C, "horizon": H,
                    "chunk_days": args.chunk_days, "parallelism": f"date-range shards x{world}"},
-        "roofline": {"bound": "mfma", "kernel": "lstm_seq_kernel<decoder> (MC decode LSTM)",
+        "roofline": {"bound": "mfma", "kernel": "lstm_kernel<16,2,1,true> (fused MC decode: LSTM steps + decoder head)",
                      "achieved": achieved, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
                      "frac": achieved / PEAK_F32_MFMA_TFLOPS, "traffic": traffic,
                      "flops_per_launch": flops_per_launch, "avg_launch_ms": avg_ms, "launches": len(k_ms)},

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define VSV_ABI_VERSION 1
+#define VSV_ABI_VERSION 2
 #define VSV_MAX_CONV 4
 
 /* Model shape: the subset of the reference's config dict that fixes tensor
@@ -125,6 +125,11 @@ int vsv_encode(const vsv_dims *dims, const float *packed, int which,
  *               vsv_percentile reads (requires n_rows % S == 0);
  * and ex_out (n_rows, T-t_out0, X) when X > 0 and ex_out != NULL.
  * z_out, when not NULL, receives the z part that was fed in: (n_rows, T, L).
+ * gate_out, when not NULL, receives per row bias + W_hh . h_final of every layer (the
+ * part of the next step's gate pre-activations that depends only on the final state);
+ * a later call that continues MANY rows from that state (state_in + state_div, the MC
+ * samples of one day) passes it back as gate_in and its first step skips the
+ * recurrent matrix products -- same numbers up to float summation order.
  * Pass t_out0 = T to run the LSTM only (context prefix: state_out is the product). */
 typedef struct vsv_decode_in {
     const float *ctx;   long ctx_rs;  int ctx_T;  long ctx_div;
@@ -133,9 +138,12 @@ typedef struct vsv_decode_in {
     const float *eps_in; int eps_T; int eps_t0;
     uint64_t seed; long S; long day0; int step0;
     const float *state_in; long state_div;
+    const float *gate_in;   /* optional, with state_in: see below */
+    float *gate_out;        /* optional: (n_rows, vsv_gate_floats) */
 } vsv_decode_in;
 
 size_t vsv_state_floats(const vsv_dims *dims);   /* floats of decoder LSTM state per row */
+size_t vsv_gate_floats(const vsv_dims *dims);    /* floats of gate_in / gate_out per row */
 size_t vsv_decode_ws_bytes(const vsv_dims *dims, long n_rows, int T, int t_out0);
 int vsv_decode(const vsv_dims *dims, const float *packed, const vsv_decode_in *in,
                long n_rows, int T, int t_out0,

@@ -10,18 +10,22 @@
 // activation vector either in registers (decoder head chain, static indexing) or
 // in a private LDS column ("col[s*64 + lane]", one slot per k-step).
 //
-// Two schedules of the recurrent kernel:
-//   SPLIT = 1  many rows (MC decode, AR): a wave walks its own 32-row tile through
-//              all gate tiles, 4 independent waves per workgroup, 1 wave per SIMD;
-//   SPLIT = 4  few rows (context prefix, training batches): the 4 waves of a
-//              workgroup share ONE 32-row tile and split its gate tiles, h is
-//              exchanged through LDS with two barriers per layer and step.
+// Schedule of the recurrent kernel: a workgroup of 4 waves owns ONE 32-row tile and
+// splits every layer's output tiles between its waves (gate tiles w, w+4, ... of the
+// LSTM layers; one tile each of the decoder-head layers); h and the head activations
+// are exchanged through LDS with workgroup barriers.  Per wave that is 4 accumulator
+// tiles (64 registers), so two workgroups share a CU (2 waves per SIMD): one wave's
+// cell / epilogue VALU work overlaps the other's MFMAs.
 #include <hip/hip_runtime.h>
 #include <cmath>
 #include <cstdint>
 #include <cstdio>
 
 #include "vsv_layout.h"
+
+#ifndef VSV_HEAD_PREFETCH
+#define VSV_HEAD_PREFETCH 1
+#endif
 
 namespace vsv {
 
@@ -37,38 +41,58 @@ __device__ __forceinline__ int feat_of(int t, int reg, int hh) { return 32 * t +
 // acc[i] += W[tile toff[i]] . B over nq k-quads.  w: this lane's float4 at quad 0, tile 0 of
 // the segment; toff[i]: tile offset in float4 units (tile * 64); qstride: float4 per quad
 // (layer tiles * 64); b: this lane's activation column at the segment's first k-step
-// (LDS or global, 64 floats per k-step).  Weights and B values are fetched one quad ahead.
+// (LDS or global, 64 floats per k-step).  The weights of quad q+1 are in flight while
+// quad q is multiplied (two named buffers, loop unrolled by two).
+template <int NC>
+__device__ __forceinline__ void quad_mfma(f32x16 (&acc)[NC], const float4 (&a)[NC], const float* b, int q) {
+    const float b0 = b[(4 * q + 0) * 64], b1 = b[(4 * q + 1) * 64], b2 = b[(4 * q + 2) * 64], b3 = b[(4 * q + 3) * 64];
+#pragma unroll
+    for (int i = 0; i < NC; ++i) acc[i] = mfma32(a[i].x, b0, acc[i]);
+#pragma unroll
+    for (int i = 0; i < NC; ++i) acc[i] = mfma32(a[i].y, b1, acc[i]);
+#pragma unroll
+    for (int i = 0; i < NC; ++i) acc[i] = mfma32(a[i].z, b2, acc[i]);
+#pragma unroll
+    for (int i = 0; i < NC; ++i) acc[i] = mfma32(a[i].w, b3, acc[i]);
+}
+
 template <int NC>
 __device__ __forceinline__ void gemm_seg(f32x16 (&acc)[NC], const float4* __restrict__ w, const int (&toff)[NC],
                                          int qstride, const float* b, int nq) {
-    float4 a[NC];
-    float bb[4];
+    float4 a0[NC], a1[NC];
 #pragma unroll
-    for (int i = 0; i < NC; ++i) a[i] = w[toff[i]];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) bb[j] = b[j * 64];
+    for (int i = 0; i < NC; ++i) a0[i] = w[toff[i]];
+    int q = 0;
 #pragma unroll 1
-    for (int q = 0; q < nq; ++q) {
-        const int qn = (q + 1 < nq) ? q + 1 : q;
-        float4 an[NC];
-        float bn[4];
-        const float4* wn = w + (size_t)qn * qstride;
+    for (; q + 1 < nq; q += 2) {
+        const float4* w1 = w + (size_t)(q + 1) * qstride;
 #pragma unroll
-        for (int i = 0; i < NC; ++i) an[i] = wn[toff[i]];
+        for (int i = 0; i < NC; ++i) a1[i] = w1[toff[i]];
+        quad_mfma<NC>(acc, a0, b, q);
+        const float4* w2 = w + (size_t)((q + 2 < nq) ? q + 2 : q + 1) * qstride;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) bn[j] = b[(4 * qn + j) * 64];
+        for (int i = 0; i < NC; ++i) a0[i] = w2[toff[i]];
+        quad_mfma<NC>(acc, a1, b, q + 1);
+    }
+    if (q < nq) quad_mfma<NC>(acc, a0, b, q);
+}
+
+// One output tile over NQ k-quads with ALL its weights in registers (decoder head: one
+// tile per wave, so a one-quad prefetch distance would not cover the L2 latency; the
+// caller fetches the next layer's weights before it waits at the layer's barrier).
+template <int NQ>
+__device__ __forceinline__ void tile_load(float4 (&a)[4 * kHeadTiles], const float4* __restrict__ w, int qstride) {
 #pragma unroll
-        for (int i = 0; i < NC; ++i) acc[i] = mfma32(a[i].x, bb[0], acc[i]);
+    for (int q = 0; q < NQ; ++q) a[q] = w[(size_t)q * qstride];
+}
+template <int NQ>
+__device__ __forceinline__ void tile_mfma(f32x16& acc, const float4 (&a)[4 * kHeadTiles], const float* b) {
 #pragma unroll
-        for (int i = 0; i < NC; ++i) acc[i] = mfma32(a[i].y, bb[1], acc[i]);
-#pragma unroll
-        for (int i = 0; i < NC; ++i) acc[i] = mfma32(a[i].z, bb[2], acc[i]);
-#pragma unroll
-        for (int i = 0; i < NC; ++i) acc[i] = mfma32(a[i].w, bb[3], acc[i]);
-#pragma unroll
-        for (int i = 0; i < NC; ++i) a[i] = an[i];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) bb[j] = bn[j];
+    for (int q = 0; q < NQ; ++q) {
+        acc = mfma32(a[q].x, b[(4 * q + 0) * 64], acc);
+        acc = mfma32(a[q].y, b[(4 * q + 1) * 64], acc);
+        acc = mfma32(a[q].z, b[(4 * q + 2) * 64], acc);
+        acc = mfma32(a[q].w, b[(4 * q + 3) * 64], acc);
     }
 }
 
@@ -83,27 +107,6 @@ __device__ __forceinline__ void load_bias(f32x16 (&acc)[NC], const float* __rest
             const float4 x = p[v];
             acc[i][4 * v + 0] = x.x; acc[i][4 * v + 1] = x.y; acc[i][4 * v + 2] = x.z; acc[i][4 * v + 3] = x.w;
         }
-    }
-}
-
-// One dense layer whose input lives in registers: in[4] is the previous layer's
-// accumulator set (PERM32 order: k-step s = 16*t + reg).  16 quads, fully unrolled.
-template <int NTO>
-__device__ __forceinline__ void dense_reg(f32x16 (&out)[NTO], const f32x16 (&in)[kHeadTiles],
-                                          const float4* __restrict__ w /* lane-adjusted */) {
-#pragma unroll
-    for (int q = 0; q < 4 * kHeadTiles; ++q) {
-        float4 a[NTO];
-#pragma unroll
-        for (int i = 0; i < NTO; ++i) a[i] = w[(q * NTO + i) * 64];
-#pragma unroll
-        for (int i = 0; i < NTO; ++i) out[i] = mfma32(a[i].x, in[q >> 2][4 * (q & 3) + 0], out[i]);
-#pragma unroll
-        for (int i = 0; i < NTO; ++i) out[i] = mfma32(a[i].y, in[q >> 2][4 * (q & 3) + 1], out[i]);
-#pragma unroll
-        for (int i = 0; i < NTO; ++i) out[i] = mfma32(a[i].z, in[q >> 2][4 * (q & 3) + 2], out[i]);
-#pragma unroll
-        for (int i = 0; i < NTO; ++i) out[i] = mfma32(a[i].w, in[q >> 2][4 * (q & 3) + 3], out[i]);
     }
 }
 
@@ -302,10 +305,10 @@ __global__ void __launch_bounds__(256, 2) dense_chain_kernel(const DenseChainArg
 }
 
 // ---------------------------------------------------------------------------
-// lstm_kernel: a 1- or 2-layer LSTM walked over T steps for tiles of 32 rows,
-// with (XMODE 0) the x part read from a tile-B tensor written by dense_chain
-// (encoders) or (XMODE 1) assembled from ctx / z / noise (decoder); optionally
-// (HEAD, SPLIT = 1) followed at every output step by the decoder head chain.
+// lstm_kernel: a 1- or 2-layer LSTM walked over T steps for a tile of 32 rows
+// per workgroup, with (XMODE 0) the x part read from a tile-B tensor written by
+// dense_chain (encoders) or (XMODE 1) assembled from ctx / z / noise (decoder);
+// optionally (HEAD) followed at every output step by the decoder head chain.
 // ---------------------------------------------------------------------------
 struct LstmSeqArgs {
     const float* w[2];
@@ -367,28 +370,12 @@ __device__ __forceinline__ float decoder_input(const LstmSeqArgs& a, const DecIn
     return v;
 }
 
-// gates of the NC tiles toff[] of layer l (bias already in acc)
-template <int NC, int NT, int XMODE>
-__device__ __forceinline__ void lstm_gates(f32x16 (&acc)[NC], const LstmSeqArgs& a, int l, const int (&toff)[NC],
-                                           long rowtile, int t, int lane, const float* xs, const float* hb) {
-    constexpr int HPK = 4 * NT;
-    const float4* w = (const float4*)a.w[l] + lane;
-    if (l == 0) {
-        const int kxq = a.kx >> 2;
-        const float* xsrc = (XMODE == 0) ? a.x_tileb + ((size_t)(rowtile * a.T + t) * a.kx) * 64 + lane : xs;
-        gemm_seg<NC>(acc, w, toff, NT * 64, xsrc, kxq);
-        gemm_seg<NC>(acc, w + (size_t)kxq * NT * 64, toff, NT * 64, hb, NT);
-    } else {
-        gemm_seg<NC>(acc, w, toff, NT * 64, hb, NT);                                   // h of layer 0 (this step)
-        gemm_seg<NC>(acc, w + (size_t)NT * NT * 64, toff, NT * 64, hb + HPK * 64, NT);   // own h (previous step)
-    }
-}
+constexpr int kOwn = 4;      // gate tiles per wave (tiles w, w+4, w+8, w+12): hidden size <= 128
 
-// LSTM cell for NC tiles: lane holds gates (i,f,g,o) of unit 8t + 2jj + hh in acc[i][4jj .. 4jj+3]
-template <int NC>
-__device__ __forceinline__ void lstm_cell(const f32x16 (&acc)[NC], float (*c)[4], float (*hn)[4]) {
+// LSTM cell: lane holds gates (i,f,g,o) of unit 8t + 2jj + hh in acc[i][4jj .. 4jj+3]
+__device__ __forceinline__ void lstm_cell(const f32x16 (&acc)[kOwn], float (&c)[kOwn][4], float (&hn)[kOwn][4]) {
 #pragma unroll
-    for (int i = 0; i < NC; ++i) {
+    for (int i = 0; i < kOwn; ++i) {
 #pragma unroll
         for (int jj = 0; jj < 4; ++jj) {
             const float ig = fast_sigmoid(acc[i][4 * jj + 0]);
@@ -402,94 +389,102 @@ __device__ __forceinline__ void lstm_cell(const f32x16 (&acc)[NC], float (*c)[4]
     }
 }
 
-template <int NC, int NT, int XMODE>
-__device__ __forceinline__ void lstm_chunk(const LstmSeqArgs& a, int l, int tile0, int tstride, long rowtile, int t,
-                                           int lane, const float* xs, const float* hb, float (*c)[4], float (*hn)[4]) {
-    f32x16 acc[NC];
-    int toff[NC];
-#pragma unroll
-    for (int i = 0; i < NC; ++i) {
-        int tl = tile0 + i * tstride;
-        if (tl > NT - 1) tl = NT - 1;            // out-of-range tiles of a split wave: computed, never stored
-        toff[i] = tl * 64;
-    }
-    load_bias<NC>(acc, a.b[l], toff, lane >> 5);
-    lstm_gates<NC, NT, XMODE>(acc, a, l, toff, rowtile, t, lane, xs, hb);
-    lstm_cell<NC>(acc, c, hn);
-}
-
-// fused decoder head on the top-layer h of this step (SPLIT = 1 only)
+// Decoder head on the top-layer h of this step: layer li's output tile `wave` is computed by
+// wave `wave`; activations ping-pong between two LDS buffers (64 slots each) with one barrier
+// per layer; the next layer's weights are fetched before that barrier.  Every wave of the
+// workgroup must call this.
 template <int NT>
-__device__ __forceinline__ void fused_head(const LstmSeqArgs& a, const float* htop, int lane, long row, bool row_ok,
-                                           int to) {
+__device__ __forceinline__ void fused_head(const LstmSeqArgs& a, const float* htop, float* ha, int lane, int wave,
+                                           long row, bool row_ok, int to) {
     const DenseChainArgs& hd = a.head;
     const int hh = lane >> 5;
     const RowIo io = make_rowio(hd, row, row_ok, to);
-    f32x16 cur[kHeadTiles];
-    int toff[kHeadTiles];
-#pragma unroll
-    for (int i = 0; i < kHeadTiles; ++i) toff[i] = i * 64;
-    load_bias<kHeadTiles>(cur, hd.layer[0].b, toff, hh);
-    gemm_seg<kHeadTiles>(cur, (const float4*)hd.layer[0].w + lane, toff, kHeadTiles * 64, htop, NT);
-    dense_epilogue<kHeadTiles>(hd, io, 0, false, cur, hh, hd.layer[0].n_relu);
+    const int nl = hd.n_layers;
+    float4 wq[4 * kHeadTiles];
+    {
+        const int tw = wave < hd.layer[0].nt ? wave : hd.layer[0].nt - 1;
+        tile_load<NT>(wq, (const float4*)hd.layer[0].w + tw * 64 + lane, hd.layer[0].nt * 64);
+    }
+    const float* src = htop;
 #pragma unroll 1
-    for (int li = 1; li < hd.n_layers - 1; ++li) {
-        f32x16 nxt[kHeadTiles];
-        load_bias<kHeadTiles>(nxt, hd.layer[li].b, toff, hh);
-        dense_reg<kHeadTiles>(nxt, cur, (const float4*)hd.layer[li].w + lane);
-        dense_epilogue<kHeadTiles>(hd, io, li, false, nxt, hh, hd.layer[li].n_relu);
+    for (int li = 0; li < nl; ++li) {
+        const DenseLayerArg& ly = hd.layer[li];
+        const bool last = (li == nl - 1);
+        const bool mine = wave < ly.nt;
+        float* dst = ha + (size_t)(li & 1) * kDenseSlots * 64;
+        f32x16 acc[1];
+        const int toff[1] = {(mine ? wave : ly.nt - 1) * 64};
+        load_bias<1>(acc, ly.b, toff, hh);
+        if (mine) {
+            if (li == 0) tile_mfma<NT>(acc[0], wq, src);
+            else tile_mfma<4 * kHeadTiles>(acc[0], wq, src);
+        }
+#if VSV_HEAD_PREFETCH
+        if (!last) {
+            const DenseLayerArg& nx = hd.layer[li + 1];
+            const int tw = wave < nx.nt ? wave : nx.nt - 1;
+            tile_load<4 * kHeadTiles>(wq, (const float4*)nx.w + tw * 64 + lane, nx.nt * 64);
+        }
+#endif
+        if (mine) {
 #pragma unroll
-        for (int tt = 0; tt < kHeadTiles; ++tt) cur[tt] = nxt[tt];
+            for (int r = 0; r < 16; ++r) {
+                const int f = feat_of(wave, r, hh);
+                float v = acc[0][r];
+                if (f < ly.n_relu) v = fmaxf(v, 0.0f);
+                if (li == hd.aux_layer && io.aux && f >= hd.aux_f0 && f < hd.aux_f0 + hd.aux_n) io.aux[f] = v;
+                if (!last) dst[(16 * wave + r) * 64] = v;
+                else if (io.out && f < hd.out_f) io.out[(size_t)f * io.fstride] = v;
+            }
+        }
+        if (!last) __syncthreads();
+        src = dst;
+#if !VSV_HEAD_PREFETCH
+        if (!last) {
+            const DenseLayerArg& nx = hd.layer[li + 1];
+            const int tw = wave < nx.nt ? wave : nx.nt - 1;
+            tile_load<4 * kHeadTiles>(wq, (const float4*)nx.w + tw * 64 + lane, nx.nt * 64);
+        }
+#endif
     }
-    const int li = hd.n_layers - 1;
-    const float4* wl = (const float4*)hd.layer[li].w + lane;
-#define VSV_LAST(NTO)                                                       \
-    {                                                                       \
-        f32x16 o[NTO];                                                      \
-        int tf[NTO];                                                        \
-        _Pragma("unroll") for (int i = 0; i < NTO; ++i) tf[i] = i * 64;     \
-        load_bias<NTO>(o, hd.layer[li].b, tf, hh);                          \
-        dense_reg<NTO>(o, cur, wl);                                         \
-        dense_epilogue<NTO>(hd, io, li, true, o, hh, hd.layer[li].n_relu);  \
-        dense_store<NTO>(hd, io, o, hh);                                    \
-    }
-    switch (hd.layer[li].nt) {
-        case 1: VSV_LAST(1) break;
-        case 2: VSV_LAST(2) break;
-        case 3: VSV_LAST(3) break;
-        default: VSV_LAST(4) break;
-    }
-#undef VSV_LAST
 }
 
-template <int NT, int NL, int XMODE, int SPLIT, bool HEAD>
-__global__ void __launch_bounds__(256, (SPLIT == 1) ? 1 : 2) lstm_kernel(const LstmSeqArgs a) {
+#ifndef VSV_X_AHEAD
+#define VSV_X_AHEAD 1
+#endif
+#ifndef VSV_LSTM_OCC
+#define VSV_LSTM_OCC 2
+#endif
+template <int NT, int NL, int XMODE, bool HEAD>
+__global__ void __launch_bounds__(256, VSV_LSTM_OCC) lstm_kernel(const LstmSeqArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    static_assert(SPLIT == 1 || SPLIT == 4, "SPLIT is 1 or 4");
-    static_assert(!HEAD || SPLIT == 1, "the fused head needs SPLIT = 1");
+    static_assert(NT <= 4 * kOwn, "hidden size <= 128");
     constexpr int HPK = 4 * NT;                                   // k-steps of one layer's h
     constexpr int HP = 8 * NT;                                    // padded hidden units
-    constexpr int NOWN = (SPLIT == 1) ? NT : (NT + SPLIT - 1) / SPLIT;
-    constexpr int NC0 = (NOWN < 8) ? NOWN : 8;
-    constexpr int NC1 = NOWN - NC0;
-    static_assert(NC1 <= 8, "at most 16 gate tiles per wave");
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const long rowtile = (SPLIT == 1) ? (long)blockIdx.x * 4 + wave : (long)blockIdx.x;
-    if (SPLIT == 1 && rowtile >= a.n_rowtiles) return;            // no barriers in this schedule
+    const long rowtile = (long)blockIdx.x;
     const int hh = lane >> 5, m = lane & 31;
     const long row_raw = rowtile * 32 + m;
     const bool row_ok = row_raw < a.n_rows;
     const long row = row_ok ? row_raw : a.n_rows - 1;
     const int kx = a.kx;
     const int xk = (XMODE == 0) ? 0 : kx;                         // x k-steps staged in LDS (decoder only)
-    const int slots = xk + NL * HPK;
-    float* xs = smem + ((SPLIT == 1) ? (size_t)wave * slots * 64 : 0) + lane;
+    float* xs = smem + lane;
     float* hb = xs + (size_t)xk * 64;                             // h of layer l: hb + l*HPK*64
-    const int tile0 = (SPLIT == 1) ? 0 : wave;
-    constexpr int TS = (SPLIT == 1) ? 1 : SPLIT;
-    const bool writer = (SPLIT == 1) || wave == 0;
+    float* ha = hb + (size_t)NL * HPK * 64;                       // head activations (HEAD only)
+
+    // gate tiles of this wave; out-of-range ones are computed on a clamped tile and never stored
+    int toff[kOwn];
+    bool tval[kOwn];
+#pragma unroll
+    for (int i = 0; i < kOwn; ++i) {
+        const int tl = wave + 4 * i;
+        tval[i] = tl < NT;
+        toff[i] = (tval[i] ? tl : NT - 1) * 64;
+    }
 
     DecIn di = {};
+    const float* gate_in = nullptr;
     if (XMODE == 1) {
         const vsv_decode_in& d = a.din;
         di.ctx = d.ctx ? d.ctx + (row / d.ctx_div) * d.ctx_rs : nullptr;
@@ -497,88 +492,136 @@ __global__ void __launch_bounds__(256, (SPLIT == 1) ? 1 : 2) lstm_kernel(const L
         di.eps = d.eps_in ? d.eps_in + (size_t)row * d.eps_T * a.L : nullptr;
         di.sample = (uint32_t)(row % d.S);
         di.day = (uint32_t)(d.day0 + row / d.S);
+        if (d.gate_in) gate_in = d.gate_in + (size_t)(row / d.state_div) * NL * NT * 32;
     }
 
-    float c[NL][NOWN][4];
+    float c[NL][kOwn][4];
     {
         const float* st = nullptr;
         if (XMODE == 1 && a.din.state_in) st = a.din.state_in + (size_t)(row / a.din.state_div) * NL * 2 * HP;
 #pragma unroll
         for (int l = 0; l < NL; ++l) {
 #pragma unroll
-            for (int i = 0; i < NOWN; ++i) {
-                const int tl = tile0 + i * TS;
+            for (int i = 0; i < kOwn; ++i) {
+                const int tl = wave + 4 * i;
 #pragma unroll
                 for (int jj = 0; jj < 4; ++jj) {
                     float h0 = 0.0f, c0 = 0.0f;
-                    if (st && tl < NT) {
+                    if (st && tval[i]) {
                         const int u = 8 * tl + 2 * jj + hh;
-                        h0 = st[(size_t)l * 2 * HP + u];
+                        if (!gate_in) h0 = st[(size_t)l * 2 * HP + u];   // with gate_in the old h is never read
                         c0 = st[(size_t)l * 2 * HP + HP + u];
                     }
-                    if (tl < NT) hb[(l * HPK + 4 * tl + jj) * 64] = h0;
+                    if (tval[i]) hb[(l * HPK + 4 * tl + jj) * 64] = h0;
                     c[l][i][jj] = c0;
                 }
             }
         }
     }
-    if (SPLIT > 1) __syncthreads();
+    // x part of layer 0 for step 0 (slots wave, wave+4, ...: the waves share the assembly)
+    if (XMODE == 1 && VSV_X_AHEAD) {
+        for (int s = wave; s < kx; s += 4) xs[s * 64] = decoder_input(a, di, row, row_ok, true, 0, 2 * s + hh);
+    }
+    __syncthreads();
 
     const int t_outs = a.T - a.t_out0;
     for (int t = 0; t < a.T; ++t) {
-        // ---- x part of layer 0 -> xs[0 .. kx)   (split waves all write the same values)
-        if (XMODE == 1) {
-            for (int s = 0; s < kx; ++s) xs[s * 64] = decoder_input(a, di, row, row_ok, writer, t, 2 * s + hh);
+        if (XMODE == 1 && !VSV_X_AHEAD) {
+            // the 4 waves write the same values; xs was last read before layer 0's first barrier of step t-1
+            for (int s = 0; s < kx; ++s) xs[s * 64] = decoder_input(a, di, row, row_ok, wave == 0, t, 2 * s + hh);
         }
 #pragma unroll
         for (int l = 0; l < NL; ++l) {
-            float hn[NOWN][4];
-            lstm_chunk<NC0, NT, XMODE>(a, l, tile0, TS, rowtile, t, lane, xs, hb, &c[l][0], &hn[0]);
-            if (NC1 > 0) {
-                constexpr int NC1s = NC1 > 0 ? NC1 : 1;
-                lstm_chunk<NC1s, NT, XMODE>(a, l, tile0 + NC0 * TS, TS, rowtile, t, lane, xs, hb, &c[l][NC0], &hn[NC0]);
-            }
-            // h of this layer is overwritten only after every wave has read the old one
-            if (SPLIT > 1) __syncthreads();
+            f32x16 acc[kOwn];
+            float hn[kOwn][4];
+            const float4* w = (const float4*)a.w[l] + lane;
+            const int nq_in = (l == 0) ? (kx >> 2) : NT;          // quads of the input segment
+            const float* bin;
+            if (l == 0) bin = (XMODE == 0) ? a.x_tileb + ((size_t)(rowtile * a.T + t) * kx) * 64 + lane : xs;
+            else bin = hb + (size_t)(l - 1) * HPK * 64;
             float* hl = hb + (size_t)l * HPK * 64;
+            if (XMODE == 1 && t == 0 && gate_in) {
+                // first step from a shared state: bias + W_hh . h_prev was computed once per state row
 #pragma unroll
-            for (int i = 0; i < NOWN; ++i) {
-                const int tl = tile0 + i * TS;
-                if (tl < NT) {
+                for (int i = 0; i < kOwn; ++i) {
+                    const float4* p = (const float4*)(gate_in + ((size_t)l * NT + (toff[i] >> 6)) * 32 + hh * 16);
 #pragma unroll
-                    for (int jj = 0; jj < 4; ++jj) hl[(4 * tl + jj) * 64] = hn[i][jj];
+                    for (int v = 0; v < 4; ++v) {
+                        const float4 x = p[v];
+                        acc[i][4 * v + 0] = x.x; acc[i][4 * v + 1] = x.y; acc[i][4 * v + 2] = x.z; acc[i][4 * v + 3] = x.w;
+                    }
+                }
+                gemm_seg<kOwn>(acc, w, toff, NT * 64, bin, nq_in);
+            } else {
+                load_bias<kOwn>(acc, a.b[l], toff, hh);
+                gemm_seg<kOwn>(acc, w, toff, NT * 64, bin, nq_in);
+                gemm_seg<kOwn>(acc, w + (size_t)nq_in * NT * 64, toff, NT * 64, hl, NT);
+            }
+            lstm_cell(acc, c[l], hn);
+            // h of this layer is overwritten only after every wave has read the old one
+            __syncthreads();
+#pragma unroll
+            for (int i = 0; i < kOwn; ++i) {
+                if (tval[i]) {
+#pragma unroll
+                    for (int jj = 0; jj < 4; ++jj) hl[((toff[i] >> 4) + jj) * 64] = hn[i][jj];
                 }
             }
-            if (SPLIT > 1) __syncthreads();
+            if (XMODE == 1 && VSV_X_AHEAD && l == NL - 1 && t + 1 < a.T) {
+                // x part of the NEXT step: xs was last read before this layer's first barrier
+                for (int s = wave; s < kx; s += 4) xs[s * 64] = decoder_input(a, di, row, row_ok, true, t + 1, 2 * s + hh);
+            }
+            __syncthreads();
         }
         const float* htop = hb + (size_t)(NL - 1) * HPK * 64;
         // ---- outputs
         if (a.hout && t >= a.t_out0) {
             float* ho = a.hout + ((size_t)(rowtile * t_outs + (t - a.t_out0)) * HPK) * 64 + lane;
 #pragma unroll
-            for (int i = 0; i < NOWN; ++i) {
-                const int tl = tile0 + i * TS;
-                if (tl < NT) {
+            for (int i = 0; i < kOwn; ++i) {
+                if (tval[i]) {
 #pragma unroll
-                    for (int jj = 0; jj < 4; ++jj) ho[(4 * tl + jj) * 64] = htop[(4 * tl + jj) * 64];
+                    for (int jj = 0; jj < 4; ++jj) ho[((toff[i] >> 4) + jj) * 64] = htop[((toff[i] >> 4) + jj) * 64];
                 }
             }
         }
-        if (HEAD && t >= a.t_out0) fused_head<NT>(a, htop, lane, row, row_ok, t - a.t_out0);
+        if (HEAD && t >= a.t_out0) fused_head<NT>(a, htop, ha, lane, wave, row, row_ok, t - a.t_out0);
     }
     if (a.state_out && row_ok) {
 #pragma unroll
         for (int l = 0; l < NL; ++l) {
             float* st = a.state_out + ((size_t)row * NL + l) * 2 * HP;
 #pragma unroll
-            for (int i = 0; i < NOWN; ++i) {
-                const int tl = tile0 + i * TS;
-                if (tl < NT) {
+            for (int i = 0; i < kOwn; ++i) {
+                if (tval[i]) {
 #pragma unroll
                     for (int jj = 0; jj < 4; ++jj) {
-                        const int u = 8 * tl + 2 * jj + hh;
-                        st[u] = hb[(l * HPK + 4 * tl + jj) * 64];
+                        const int u = 2 * ((toff[i] >> 4) + jj) + hh;
+                        st[u] = hb[(l * HPK + (toff[i] >> 4) + jj) * 64];
                         st[HP + u] = c[l][i][jj];
+                    }
+                }
+            }
+        }
+    }
+    if (XMODE == 1 && a.din.gate_out) {
+        // bias + W_hh . h_final of every layer: the part of the NEXT step's gates that all rows
+        // continuing from this state share (consumed through gate_in)
+#pragma unroll
+        for (int l = 0; l < NL; ++l) {
+            f32x16 acc[kOwn];
+            const int nq_in = (l == 0) ? (kx >> 2) : NT;
+            load_bias<kOwn>(acc, a.b[l], toff, hh);
+            gemm_seg<kOwn>(acc, (const float4*)a.w[l] + lane + (size_t)nq_in * NT * 64, toff, NT * 64,
+                           hb + (size_t)l * HPK * 64, NT);
+            if (row_ok) {
+#pragma unroll
+                for (int i = 0; i < kOwn; ++i) {
+                    if (tval[i]) {
+                        float4* p = (float4*)(a.din.gate_out + (((size_t)row * NL + l) * NT + (toff[i] >> 6)) * 32 + hh * 16);
+#pragma unroll
+                        for (int v = 0; v < 4; ++v)
+                            p[v] = make_float4(acc[i][4 * v + 0], acc[i][4 * v + 1], acc[i][4 * v + 2], acc[i][4 * v + 3]);
                     }
                 }
             }
@@ -687,35 +730,30 @@ static int launch_dense_chain(const DenseChainArgs& a, hipStream_t st) {
     return launch_check("dense_chain_kernel");
 }
 
-// rows at or below this many 32-row tiles use the split schedule (4 waves per tile)
-constexpr long kSplitMaxRowtiles = 1024;
-
-template <int NT, int NL, int XMODE, int SPLIT, bool HEAD>
+template <int NT, int NL, int XMODE, bool HEAD>
 static int launch_lstm_t(const LstmSeqArgs& a, hipStream_t st) {
-    const int slots = (XMODE == 0 ? 0 : a.kx) + NL * 4 * NT;
-    const size_t lds = (size_t)(SPLIT == 1 ? 4 : 1) * slots * 64 * sizeof(float);
-    int rc = set_lds(lstm_kernel<NT, NL, XMODE, SPLIT, HEAD>, lds);
+    const int slots = (XMODE == 0 ? 0 : a.kx) + NL * 4 * NT + (HEAD ? 2 * kDenseSlots : 0);
+    const size_t lds = (size_t)slots * 64 * sizeof(float);
+    int rc = set_lds(lstm_kernel<NT, NL, XMODE, HEAD>, lds);
     if (rc) return rc;
-    const long blocks = (SPLIT == 1) ? (a.n_rowtiles + 3) / 4 : a.n_rowtiles;
-    if (blocks > 0x7fffffffL) { set_error("lstm_kernel: too many rows"); return -2; }
-    hipLaunchKernelGGL((lstm_kernel<NT, NL, XMODE, SPLIT, HEAD>), dim3((unsigned)blocks), dim3(256), lds, st, a);
+    if (a.n_rowtiles > 0x7fffffffL) { set_error("lstm_kernel: too many rows"); return -2; }
+    hipLaunchKernelGGL((lstm_kernel<NT, NL, XMODE, HEAD>), dim3((unsigned)a.n_rowtiles), dim3(256), lds, st, a);
     return launch_check("lstm_kernel");
 }
 
 template <int NT, int XMODE>
-static int launch_lstm_nt(const LstmSeqArgs& a, int NL, bool split, bool head, hipStream_t st) {
-    if (split) return NL == 2 ? launch_lstm_t<NT, 2, XMODE, 4, false>(a, st) : launch_lstm_t<NT, 1, XMODE, 4, false>(a, st);
+static int launch_lstm_nt(const LstmSeqArgs& a, int NL, bool head, hipStream_t st) {
     if (XMODE == 1 && head)
-        return NL == 2 ? launch_lstm_t<NT, 2, XMODE, 1, (XMODE == 1)>(a, st) : launch_lstm_t<NT, 1, XMODE, 1, (XMODE == 1)>(a, st);
-    return NL == 2 ? launch_lstm_t<NT, 2, XMODE, 1, false>(a, st) : launch_lstm_t<NT, 1, XMODE, 1, false>(a, st);
+        return NL == 2 ? launch_lstm_t<NT, 2, XMODE, (XMODE == 1)>(a, st) : launch_lstm_t<NT, 1, XMODE, (XMODE == 1)>(a, st);
+    return NL == 2 ? launch_lstm_t<NT, 2, XMODE, false>(a, st) : launch_lstm_t<NT, 1, XMODE, false>(a, st);
 }
 
 template <int XMODE>
-static int launch_lstm(const LstmSeqArgs& a, int NT, int NL, bool split, bool head, hipStream_t st) {
+static int launch_lstm(const LstmSeqArgs& a, int NT, int NL, bool head, hipStream_t st) {
     if (a.n_rowtiles <= 0 || a.T <= 0) return 0;
     switch (NT) {
-        case 13: return launch_lstm_nt<13, XMODE>(a, NL, split, head, st);
-        case 16: return launch_lstm_nt<16, XMODE>(a, NL, split, head, st);
+        case 13: return launch_lstm_nt<13, XMODE>(a, NL, head, st);
+        case 16: return launch_lstm_nt<16, XMODE>(a, NL, head, st);
         default:
             set_error("unsupported LSTM hidden size: %d tiles of 8 units (built: 13 = hidden 97..104, 16 = hidden 121..128)", NT);
             return -4;
@@ -791,7 +829,7 @@ extern "C" int vsv_encode(const vsv_dims* dims, const float* packed, int which,
     l.kx = e.kx; l.n_rows = n_rows; l.n_rowtiles = rt; l.T = T;
     l.x_tileb = xe; l.L = lay.L;
     l.hout = hbuf; l.t_out0 = 0;
-    rc = launch_lstm<0>(l, lay.NTm, lay.NL, rt <= kSplitMaxRowtiles, false, st);
+    rc = launch_lstm<0>(l, lay.NTm, lay.NL, false, st);
     if (rc) return rc;
 
     // 3. linear head on every step
@@ -808,11 +846,8 @@ extern "C" int vsv_encode(const vsv_dims* dims, const float* packed, int which,
 extern "C" size_t vsv_decode_ws_bytes(const vsv_dims* dims, long n_rows, int T, int t_out0) {
     Layout lay;
     const char* msg = nullptr;
-    if (!dims || make_layout(*dims, lay, &msg) != 0 || n_rows < 0 || T < 0) return 0;
-    const long rt = (n_rows + 31) / 32;
-    const int touts = T - t_out0 > 0 ? T - t_out0 : 0;
-    if (rt > kSplitMaxRowtiles) return 256;                    // fused head: no h buffer
-    return align256((size_t)rt * touts * 4 * lay.NTd * 64 * sizeof(float)) + 256;
+    if (!dims || make_layout(*dims, lay, &msg) != 0 || n_rows < 0 || T < 0 || t_out0 < 0) return 0;
+    return 256;                                                // the head is fused: no intermediate buffer
 }
 
 extern "C" int vsv_decode(const vsv_dims* dims, const float* packed, const vsv_decode_in* in,
@@ -840,13 +875,12 @@ extern "C" int vsv_decode(const vsv_dims* dims, const float* packed, const vsv_d
         }
     }
     if (in->state_in && in->state_div < 1) { set_error("vsv_decode: state_div must be >= 1"); return -1; }
+    if (in->gate_in && !in->state_in) { set_error("vsv_decode: gate_in comes with the state_in it was computed from"); return -1; }
     if (out_mode < 0 || out_mode > 1) { set_error("vsv_decode: out_mode must be 0 or 1"); return -1; }
     if (out_mode == 1 && touts > 0 && (in->S < 1 || n_rows % in->S != 0)) { set_error("vsv_decode: out_mode 1 needs n_rows %% S == 0"); return -1; }
     hipStream_t st = (hipStream_t)stream;
     const DecLayout& dc = lay.dec;
     const long rt = (n_rows + 31) / 32;
-    const bool split = rt <= kSplitMaxRowtiles;
-    float* hbuf = ws ? (float*)(((uintptr_t)ws + 255) & ~(uintptr_t)255) : nullptr;
 
     LstmSeqArgs l = {};
     for (int i = 0; i < lay.NL; ++i) { l.w[i] = packed + dc.lstm[i].w_off; l.b[i] = packed + dc.lstm[i].b_off; }
@@ -864,20 +898,17 @@ extern "C" int vsv_decode(const vsv_dims* dims, const float* packed, const vsv_d
     a.n_layers = dc.n_head;
     for (int i = 0; i < dc.n_head; ++i) fill_dense(a, i, packed, dc.head[i]);
     a.n_rows = n_rows; a.n_rowtiles = rt; a.T = touts;
-    a.in_mode = 1; a.in = hbuf; a.in_ks = 4 * lay.NTd;
     a.out_mode = out_mode == 0 ? 1 : 2; a.out = surf_out; a.out_f = dc.n_surf; a.S = l.din.S;
     a.aux_layer = (lay.X > 0 && ex_out) ? dc.ex_layer : -1;
     a.aux = ex_out; a.aux_f0 = dc.ex_f0; a.aux_n = lay.X;
 
-    const bool fused = !split && touts > 0;
-    l.hout = (touts > 0 && !fused) ? hbuf : nullptr;
+    if (a.n_layers < 2 || dc.head[0].nq != lay.NTd) { set_error("vsv_decode: unexpected head layout"); return -4; }
     hipEvent_t ev0 = g_prof_ev[0], ev1 = g_prof_ev[1];
     g_prof_ev[0] = g_prof_ev[1] = nullptr;
     if (ev0) (void)hipEventRecord(ev0, st);
-    int rc = launch_lstm<1>(l, lay.NTd, lay.NL, split, fused, st);
+    const int rc = launch_lstm<1>(l, lay.NTd, lay.NL, touts > 0, st);
     if (ev1) (void)hipEventRecord(ev1, st);
-    if (rc || touts == 0 || fused) return rc;
-    return launch_dense_chain(a, st);
+    return rc;
 }
 
 extern "C" void vsv_profile_next_decode(void* ev_start, void* ev_stop) {

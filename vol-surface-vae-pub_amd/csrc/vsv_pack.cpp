@@ -235,6 +235,16 @@ extern "C" size_t vsv_state_floats(const vsv_dims* dims) {
     return (size_t)lay.NL * 2 * 8 * lay.NTd;
 }
 
+extern "C" size_t vsv_gate_floats(const vsv_dims* dims) {
+    Layout lay;
+    const char* msg = nullptr;
+    if (!dims || make_layout(*dims, lay, &msg) != 0) {
+        set_error("vsv_gate_floats: %s", msg ? msg : "null dims");
+        return 0;
+    }
+    return (size_t)lay.NL * lay.NTd * 32;
+}
+
 extern "C" int vsv_pack_weights(const vsv_dims* dims, const vsv_raw_weights* raw, float* out) {
     Layout lay;
     const char* msg = nullptr;

@@ -132,6 +132,7 @@ class Engine:
         self.X = self.dims.ex_feats_dim
         self.Q = self.dims.n_quantiles
         self.state_floats = int(self.lib.vsv_state_floats(C.byref(self.dims)))
+        self.gate_floats = int(self.lib.vsv_gate_floats(C.byref(self.dims)))
         self.packed = None
         self._maps = None
         if state_dict is not None:
@@ -196,9 +197,10 @@ class Engine:
                eps: Optional[torch.Tensor] = None, eps_t0: int = 0,
                seed: int = 0, S: int = 1, day0: int = 0, step0: int = 0,
                state_in: Optional[torch.Tensor] = None, state_div: int = 1,
+               gate_in: Optional[torch.Tensor] = None, want_gates: bool = False,
                want_state: bool = False, want_z: bool = False, out_mode: int = 0):
         """See vsv_decode in include/vsv_hip.h.  ctx (n,ctx_T,L); zb/lv (n,z_T,L);
-        eps (n_rows,eps_T,L).  Returns dict(surf, ex, state, z)."""
+        eps (n_rows,eps_T,L).  Returns dict(surf, ex, state, z, gates)."""
         din = _lib.VsvDecodeIn()
         if ctx is not None:
             ctx = _f32c(ctx, self.device)
@@ -226,8 +228,15 @@ class Engine:
             din.state_in, din.state_div = state_in.data_ptr(), state_div
         else:
             din.state_div = 1
-        touts = T - t_out0
         dev = self.device
+        if gate_in is not None:
+            gate_in = _f32c(gate_in, dev)
+            assert state_in is not None and gate_in.shape == (state_in.shape[0], self.gate_floats)
+            din.gate_in = gate_in.data_ptr()
+        gates = torch.empty((n_rows, self.gate_floats), dtype=torch.float32, device=dev) if want_gates else None
+        if gates is not None:
+            din.gate_out = gates.data_ptr()
+        touts = T - t_out0
         state = torch.empty((n_rows, self.state_floats), dtype=torch.float32, device=dev) if want_state else None
         z = torch.empty((n_rows, T, self.L), dtype=torch.float32, device=dev) if want_z else None
         surf = ex = None
@@ -244,7 +253,7 @@ class Engine:
                                      _ptr(state), _ptr(z), _ptr(surf), out_mode, _ptr(ex),
                                      _ptr(ws), ws.numel(), self._stream())
         _lib.check(rc, "vsv_decode")
-        return {"surf": surf, "ex": ex, "state": state, "z": z}
+        return {"surf": surf, "ex": ex, "state": state, "z": z, "gates": gates}
 
     # -- reduction / noise ---------------------------------------------------
     def percentile(self, samples: torch.Tensor, qs: Sequence[float] = (5, 50, 95), inner: int = 25) -> torch.Tensor:

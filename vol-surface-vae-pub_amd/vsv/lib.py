@@ -11,7 +11,7 @@ import os
 from typing import Optional
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(os.path.dirname(_HERE), "lib", "libvsv_hip.so")
+LIB_PATH = os.environ.get("VSV_LIB") or os.path.join(os.path.dirname(_HERE), "lib", "libvsv_hip.so")   # VSV_LIB: A/B builds
 
 VSV_MAX_CONV = 4
 
@@ -56,6 +56,7 @@ class VsvDecodeIn(C.Structure):
         ("eps_in", C.c_void_p), ("eps_T", C.c_int), ("eps_t0", C.c_int),
         ("seed", C.c_uint64), ("S", C.c_long), ("day0", C.c_long), ("step0", C.c_int),
         ("state_in", C.c_void_p), ("state_div", C.c_long),
+        ("gate_in", C.c_void_p), ("gate_out", C.c_void_p),
     ]
 
 
@@ -70,6 +71,7 @@ SIGNATURES = {
                              C.c_void_p, C.c_long, C.c_long, C.c_void_p, C.c_long, C.c_long,
                              C.c_long, C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     "vsv_state_floats": (C.c_size_t, [C.POINTER(VsvDims)]),
+    "vsv_gate_floats": (C.c_size_t, [C.POINTER(VsvDims)]),
     "vsv_decode_ws_bytes": (C.c_size_t, [C.POINTER(VsvDims), C.c_long, C.c_int, C.c_int]),
     "vsv_decode": (C.c_int, [C.POINTER(VsvDims), C.c_void_p, C.POINTER(VsvDecodeIn),
                              C.c_long, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
@@ -104,7 +106,7 @@ def load() -> C.CDLL:
             fn = getattr(lib, name)
             fn.restype = res
             fn.argtypes = args
-        if lib.vsv_abi_version() != 1:
+        if lib.vsv_abi_version() != 2:
             raise RuntimeError("libvsv_hip.so ABI version mismatch")
         _lib = lib
     return _lib

@@ -48,8 +48,8 @@ def prior_generate(eng: Engine, surf_ctx: torch.Tensor, ex_ctx: Optional[torch.T
     D, C = surf_ctx.shape[:2]
     zm, _ = encode_both(eng, surf_ctx, ex_ctx)
     ctx = eng.encode(1, surf_ctx, ex_ctx)
-    pre = eng.decode(D, C, C, ctx=ctx, zb=zm, want_state=True)
-    r = eng.decode(D * n_samples, horizon, 0, state_in=pre["state"], state_div=n_samples,
+    pre = eng.decode(D, C, C, ctx=ctx, zb=zm, want_state=True, want_gates=n_samples > 1)
+    r = eng.decode(D * n_samples, horizon, 0, state_in=pre["state"], state_div=n_samples, gate_in=pre["gates"],
                    eps=eps, mu0=mu, std0=std, seed=seed, S=n_samples, day0=day0, step0=step0,
                    out_mode=out_mode)
     return r["surf"], r["ex"], zm
@@ -85,7 +85,8 @@ def prior_mc_windows(eng: Engine, vol: torch.Tensor, ex: Optional[torch.Tensor],
     enc = eng.encode_strided(0, sv, 25, 25, se, eng.X, eng.X, n_days, ctx_len)
     zm = enc[..., :L].contiguous()
     ctx = eng.encode_strided(1, sv, 25, 25, se, eng.X, eng.X, n_days, ctx_len)
-    state = eng.decode(n_days, ctx_len, ctx_len, ctx=ctx, zb=zm, want_state=True)["state"]
+    pre = eng.decode(n_days, ctx_len, ctx_len, ctx=ctx, zb=zm, want_state=True, want_gates=True)
+    state, gates = pre["state"], pre["gates"]
     outs = []
     for d0 in range(0, n_days, chunk_days):
         nd = min(chunk_days, n_days - d0)
@@ -95,7 +96,7 @@ def prior_mc_windows(eng: Engine, vol: torch.Tensor, ex: Optional[torch.Tensor],
             eng.lib.vsv_profile_next_decode(ev[0].h, ev[1].h)
             decode_events.append((ev[0], ev[1], nd * n_samples))
         r = eng.decode(nd * n_samples, horizon, 0, state_in=state[d0:d0 + nd], state_div=n_samples,
-                       seed=seed, S=n_samples, day0=day_index0 + d0, out_mode=1)
+                       gate_in=gates[d0:d0 + nd], seed=seed, S=n_samples, day0=day_index0 + d0, out_mode=1)
         smp = r["surf"]                                    # (nd, H, Q*25, S)
         if channel is None:
             q = eng.percentile(smp, qs, inner=Q * 25).view(nd, horizon, len(qs), Q, 5, 5)

@@ -186,3 +186,82 @@ def test_prior_mc_windows_reduction_vs_oracle():
     assert err(_n(q), want) <= TOL
     q1 = paths.prior_mc_windows(eng, _t(vol), _t(ex), C, N, C, H, S, seed=5, chunk_days=256, channel=1)
     assert err(_n(q1), want[:, :, :, 1]) <= TOL
+
+
+@pytest.mark.parametrize("name", golden_names("g6_"))
+def test_autoregressive_sequence_vs_reference(name):
+    """generate_autoregressive_sequence: 30 one-day steps with p50 feedback; the golden is the
+    reference's float64 run, the HIP path computes in float32 (errors compound over the steps)."""
+    from vsv import paths
+    g = load_golden(name)
+    cfg = cfg_of(g)
+    eng, _ = _engine(cfg, int(g["seed"]), float(g["scale"]))
+    surf, ex = _t(g["surface"]), _t(g.get("ex_feats"))
+    C = g["surface"].shape[1]
+    eps = _t(np.ascontiguousarray(g["z_steps"][:, :, C].transpose(1, 0, 2)))     # (B, H, L)
+    s, e = paths.ar_generate(eng, surf, ex, int(g["horizon"]), 1, eps=eps)
+    assert s.shape == g["surf_out"].shape
+    assert err(_n(s), g["surf_out"]) <= TOL
+    if ex is not None:
+        assert err(_n(e), g["ex_out"]) <= TOL
+
+
+@pytest.mark.parametrize("name", golden_names("g7_"))
+def test_autoregressive_offset_vs_reference(name):
+    from vsv import paths
+    g = load_golden(name)
+    cfg = cfg_of(g)
+    eng, _ = _engine(cfg, int(g["seed"]), float(g["scale"]))
+    surf, ex = _t(g["surface"]), _t(g.get("ex_feats"))
+    C, H = g["surface"].shape[1], int(g["horizon"])
+    zs = g["z_steps"]                                                            # (steps, B, C+H, L)
+    eps = _t(np.concatenate([zs[k][:, C:] for k in range(zs.shape[0])], axis=1))
+    s, e = paths.ar_offset_generate(eng, surf, ex, zs.shape[0], H, eps=eps)
+    assert s.shape == g["surf_out"].shape
+    assert err(_n(s), g["surf_out"]) <= TOL
+    if ex is not None:
+        assert err(_n(e), g["ex_out"]) <= TOL
+
+
+def test_ar_mc_windows_vs_oracle():
+    """AR MC backfill with on-device reduction: Philox noise materialised and fed to the oracle."""
+    from vsv import paths
+    L, X, C, H, S, N = 5, 0, 6, 3, 40, 3
+    cfg = vo.make_config(L, X)
+    eng, W = _engine(cfg, 31, 2.0)
+    rng = np.random.default_rng(3)
+    vol = (0.2 + 0.1 * rng.standard_normal((N + C, 5, 5))).astype(np.float32)
+    q = paths.ar_mc_windows(eng, _t(vol), None, C, N, C, H, S, seed=9, chunk_days=2, channel=None)
+    assert q.shape == (N, H, 3, 3, 5, 5)
+    W64 = {k: v.astype(np.float64) for k, v in W.items()}
+    want = np.zeros((N, S, H, 3, 5, 5))
+    for d in range(N):
+        noise = _n(eng.philox_normal(9, C + d, 1, S, 0, H))                      # (S, H, L)
+        zs = np.zeros((H, S, C + 1, L))
+        zs[:, :, C] = noise.transpose(1, 0, 2)
+        win = np.broadcast_to(vol[d:d + C][None].astype(np.float64), (S, C, 5, 5)).copy()
+        want[d], _ = vo.generate_autoregressive_sequence(W64, cfg, win, None, zs)
+    wq = np.percentile(want, [5, 50, 95], axis=1).transpose(1, 2, 0, 3, 4, 5)
+    assert err(_n(q), wq) <= TOL
+
+
+def test_oracle_mc_windows_vs_oracle():
+    """Posterior-sampled (oracle) MC: z ~ q(z | context + target) at every position."""
+    from vsv import paths
+    L, X, C, H, S, N = 5, 3, 5, 3, 48, 5
+    cfg = vo.make_config(L, X)
+    eng, W = _engine(cfg, 13, 2.0)
+    rng = np.random.default_rng(4)
+    vol = (0.2 + 0.1 * rng.standard_normal((N + C + H, 5, 5))).astype(np.float32)
+    ex = (0.01 * rng.standard_normal((N + C + H, X))).astype(np.float32)
+    q = paths.oracle_mc_windows(eng, _t(vol), _t(ex), C, N, C, H, S, seed=3, chunk_days=2, channel=None)
+    assert q.shape == (N, H, 3, 3, 5, 5)
+    W64 = {k: v.astype(np.float64) for k, v in W.items()}
+    want = np.zeros((N, S, H, 3, 5, 5))
+    for d in range(N):
+        eps = _n(eng.philox_normal(3, C + d, 1, S, 0, C + H))                 # (S, T, L)
+        win = np.broadcast_to(vol[d:d + C + H][None].astype(np.float64), (S, C + H, 5, 5))
+        wex = np.broadcast_to(ex[d:d + C + H][None].astype(np.float64), (S, C + H, X))
+        want[d] = vo.forward(W64, cfg, win, wex, eps, H)[0]
+    wq = np.percentile(want, [5, 50, 95], axis=1).transpose(1, 2, 0, 3, 4, 5)
+    assert err(_n(q), wq) <= TOL

@@ -426,17 +426,12 @@ class CVAEMemRand(BaseVAE):
         has_ex = "ex_feats" in initial_context
         if has_ex and initial_context["ex_feats"].dim() not in (2, 3):
             raise ValueError(f"ex_feats must be (C, D) or (B, C, D), got shape {initial_context['ex_feats'].shape}")
-        context = {k: v.clone() if torch.is_tensor(v) else v for k, v in initial_context.items()}
-        surfaces, exs = [], []
-        for _ in range(horizon):
-            result = self.get_surface_given_conditions(context, z=None)
-            pred_s, pred_e = result if has_ex else (result, None)
-            surfaces.append(pred_s)
-            if has_ex:
-                exs.append(pred_e)
-            context = self._update_context(context, pred_s[:, 0, 1, :, :], pred_e[:, 0, :] if has_ex else None)
-        out = torch.cat(surfaces, dim=1)
-        return (out, torch.cat(exs, dim=1)) if has_ex else out
+        from vsv import paths
+        surf, ex = self._batched(initial_context)
+        eng = self._engine()
+        dt = self._param_dtype()
+        s_out, e_out = paths.ar_generate(eng, surf, ex if has_ex else None, horizon, 1, seed=self._draw_seed())
+        return (s_out.to(dt), e_out.to(dt)) if has_ex else s_out.to(dt)
 
     def generate_autoregressive_offset(self, initial_context: Dict[str, torch.Tensor], ar_steps: int = 3,
                                        horizon: int = 60, offset: int = 60, z: Optional[torch.Tensor] = None
@@ -449,26 +444,13 @@ class CVAEMemRand(BaseVAE):
         has_ex = "ex_feats" in initial_context
         if initial_context["surface"].shape[1] != C:
             raise ValueError(f"Context length must be {C}, got {initial_context['surface'].shape[1]}")
-        context = {k: v.clone() if torch.is_tensor(v) else v for k, v in initial_context.items()}
-        all_s, all_e, med_s, med_e = [], [], [], []
-        for step in range(ar_steps):
-            saved, self.horizon = self.horizon, horizon
-            try:
-                result = self.get_surface_given_conditions(context, z=None)
-            finally:
-                self.horizon = saved
-            pred_s, pred_e = result if has_ex else (result, None)
-            all_s.append(pred_s)
-            med_s.append(pred_s[:, :, 1, :, :])
-            if has_ex:
-                all_e.append(pred_e)
-                med_e.append(pred_e)
-            if step < ar_steps - 1:
-                context["surface"] = torch.cat(med_s, dim=1)[:, -C:, :, :]
-                if has_ex:
-                    context["ex_feats"] = torch.cat(med_e, dim=1)[:, -C:, :]
-        out = torch.cat(all_s, dim=1)
-        return (out, torch.cat(all_e, dim=1)) if has_ex else out
+        from vsv import paths
+        surf, ex = self._batched(initial_context)
+        eng = self._engine()
+        dt = self._param_dtype()
+        s_out, e_out = paths.ar_offset_generate(eng, surf, ex if has_ex else None, ar_steps, horizon,
+                                                seed=self._draw_seed())
+        return (s_out.to(dt), e_out.to(dt)) if has_ex else s_out.to(dt)
 
     def _update_context(self, context: Dict[str, torch.Tensor], new_surface: torch.Tensor,
                         new_ex_feat: Optional[torch.Tensor] = None) -> Dict[str, torch.Tensor]:

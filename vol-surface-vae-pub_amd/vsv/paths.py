@@ -105,3 +105,144 @@ def prior_mc_windows(eng: Engine, vol: torch.Tensor, ex: Optional[torch.Tensor],
             q = eng.percentile(sel, qs, inner=25).view(nd, horizon, len(qs), 5, 5)
         outs.append(q)
     return torch.cat(outs, dim=0)
+
+
+def ar_generate(eng: Engine, surf_ctx: torch.Tensor, ex_ctx: Optional[torch.Tensor], horizon: int,
+                n_samples: int = 1, eps: Optional[torch.Tensor] = None, seed: int = 0, day0: int = 0):
+    """generate_autoregressive_sequence (cvae_with_mem_randomized.py:717-807) for D
+    context windows x S samples: every row rolls its OWN window -- each step is a
+    one-day prior generation (:776), whose p50 channel (:786/:794) and predicted
+    ex-features (:788) slide into the row's context (_update_context, :925-967).
+    The windows live in one (rows, C+horizon, 25) ring so a step reads its context
+    in place (time stride = one day) and the kernels write the feedback day behind it.
+    eps: (D*S, horizon, L) injected future latents, or None -> Philox keyed by
+    (seed; sample, day0 + day, step).  Returns (D*S, horizon, Q, 5, 5)[, (D*S, horizon, X)]."""
+    D, C = surf_ctx.shape[:2]
+    S, R, L, X, Q = n_samples, D * n_samples, eng.L, eng.X, eng.Q
+    dev = eng.device
+    TT = C + horizon
+    buf = torch.empty((R, TT, 25), dtype=torch.float32, device=dev)
+    buf[:, :C] = surf_ctx.to(dev, torch.float32).reshape(D, 1, C, 25).expand(D, S, C, 25).reshape(R, C, 25)
+    exb = None
+    if X > 0:
+        exb = torch.empty((R, TT, X), dtype=torch.float32, device=dev)
+        exb[:, :C] = ex_ctx.to(dev, torch.float32).reshape(D, 1, C, X).expand(D, S, C, X).reshape(R, C, X)
+    out_s = torch.empty((R, horizon, Q, 5, 5), dtype=torch.float32, device=dev)
+    out_e = torch.empty((R, horizon, X), dtype=torch.float32, device=dev) if X > 0 else None
+    if eps is not None:
+        eps = eps.to(dev, torch.float32).contiguous()
+        assert eps.shape == (R, horizon, L)
+    for k in range(horizon):
+        win = buf[:, k:]
+        wex = exb[:, k:] if X > 0 else None
+        enc = eng.encode_strided(0, win, TT * 25, 25, wex, TT * X, X, R, C)
+        zm = enc[..., :L].contiguous()
+        ctx = eng.encode_strided(1, win, TT * 25, 25, wex, TT * X, X, R, C)
+        r = eng.decode(R, C + 1, C, ctx=ctx, zb=zm,
+                       eps=None if eps is None else eps[:, k:k + 1].contiguous(), eps_t0=C,
+                       seed=seed, S=S, day0=day0, step0=k)
+        out_s[:, k] = r["surf"][:, 0]
+        buf[:, C + k] = r["surf"][:, 0, 1].reshape(R, 25)
+        if X > 0:
+            out_e[:, k] = r["ex"][:, 0]
+            exb[:, C + k] = r["ex"][:, 0]
+    return out_s, out_e
+
+
+def ar_offset_generate(eng: Engine, surf_ctx: torch.Tensor, ex_ctx: Optional[torch.Tensor], ar_steps: int,
+                       horizon: int, eps: Optional[torch.Tensor] = None, seed: int = 0, day0: int = 0):
+    """generate_autoregressive_offset (cvae_with_mem_randomized.py:809-923): ar_steps
+    prior generations of `horizon` days each; the next context is the last C days of
+    the concatenated p50 medians (:905-914).  eps: (rows, ar_steps*horizon, L) or None."""
+    B, C = surf_ctx.shape[:2]
+    X = eng.X
+    surf = surf_ctx.to(eng.device, torch.float32).reshape(B, C, 5, 5)
+    ex = ex_ctx.to(eng.device, torch.float32) if X > 0 else None
+    all_s, all_e, med_s, med_e = [], [], [], []
+    for k in range(ar_steps):
+        e = None if eps is None else eps[:, k * horizon:(k + 1) * horizon].contiguous()
+        s, ee, _ = prior_generate(eng, surf, ex, horizon, 1, eps=e, seed=seed, day0=day0, step0=k * horizon)
+        all_s.append(s)
+        med_s.append(s[:, :, 1])
+        if X > 0:
+            all_e.append(ee)
+            med_e.append(ee)
+        if k < ar_steps - 1:
+            surf = torch.cat(med_s, dim=1)[:, -C:].contiguous()
+            if X > 0:
+                ex = torch.cat(med_e, dim=1)[:, -C:].contiguous()
+    return torch.cat(all_s, dim=1), (torch.cat(all_e, dim=1) if X > 0 else None)
+
+
+def ar_mc_windows(eng: Engine, vol: torch.Tensor, ex: Optional[torch.Tensor], first_day: int, n_days: int,
+                  ctx_len: int, horizon: int, n_samples: int, seed: int = 0,
+                  qs: Sequence[float] = (5, 50, 95), channel: Optional[int] = 1, chunk_days: int = 8,
+                  day_index0: Optional[int] = None):
+    """Autoregressive MC backfill with on-device quantile reduction (BASELINE configs[4]):
+    for every day, S independent `horizon`-day rollouts from the window vol[day-C:day],
+    reduced to np.percentile-style quantiles -> (n_days, horizon, nq, 5, 5) for one decoder
+    channel (default p50) or (n_days, horizon, nq, Q, 5, 5) when channel is None."""
+    assert first_day >= ctx_len and first_day + n_days <= vol.shape[0]
+    vol = vol.to(device=eng.device, dtype=torch.float32).contiguous()
+    if eng.X > 0:
+        ex = ex.to(device=eng.device, dtype=torch.float32).contiguous()
+    if day_index0 is None:
+        day_index0 = first_day
+    Q, S = eng.Q, n_samples
+    outs = []
+    for d0 in range(0, n_days, chunk_days):
+        nd = min(chunk_days, n_days - d0)
+        w0 = first_day + d0 - ctx_len
+        win = vol[w0:w0 + nd + ctx_len - 1].reshape(-1, 25).unfold(0, ctx_len, 1).permute(0, 2, 1)   # (nd, C, 25)
+        wex = ex[w0:w0 + nd + ctx_len - 1].unfold(0, ctx_len, 1).permute(0, 2, 1) if eng.X > 0 else None
+        s, _ = ar_generate(eng, win.reshape(nd, ctx_len, 5, 5), wex, horizon, S, seed=seed, day0=day_index0 + d0)
+        smp = s.view(nd, S, horizon, Q, 25)
+        if channel is None:
+            sm = smp.permute(0, 2, 3, 4, 1).contiguous()                       # (nd, H, Q, 25, S)
+            q = eng.percentile(sm, qs, inner=Q * 25).view(nd, horizon, len(qs), Q, 5, 5)
+        else:
+            sm = smp[:, :, :, channel].permute(0, 2, 3, 1).contiguous()        # (nd, H, 25, S)
+            q = eng.percentile(sm, qs, inner=25).view(nd, horizon, len(qs), 5, 5)
+        outs.append(q)
+    return torch.cat(outs, dim=0)
+
+
+def oracle_mc_windows(eng: Engine, vol: torch.Tensor, ex: Optional[torch.Tensor], first_day: int, n_days: int,
+                      ctx_len: int, horizon: int, n_samples: int, seed: int = 0,
+                      qs: Sequence[float] = (5, 50, 95), channel: Optional[int] = 1, chunk_days: int = 64,
+                      day_index0: Optional[int] = None):
+    """Oracle (posterior) MC generation over a date range (the teacher-forcing generators,
+    experiments/backfill/context20/generate_vae_tf_sequences.py:109-123): for every day the
+    model sees context AND target, vol[day-C : day+H], and z is SAMPLED from the posterior at
+    all C+H positions (cvae_with_mem_randomized.py:198-199, :1064), so every sample decodes the
+    whole sequence.  The two encoders run once per day; the decoder runs per (day, sample) with
+    Philox noise keyed by (seed; sample, global day, position).  Reduced on device like
+    prior_mc_windows.  Returns (n_days, horizon, nq, 5, 5) or (n_days, horizon, nq, Q, 5, 5)."""
+    T = ctx_len + horizon
+    assert first_day >= ctx_len and first_day + n_days + horizon <= vol.shape[0] + 0
+    vol = vol.to(device=eng.device, dtype=torch.float32).contiguous()
+    if eng.X > 0:
+        ex = ex.to(device=eng.device, dtype=torch.float32).contiguous()
+    if day_index0 is None:
+        day_index0 = first_day
+    L, Q, X = eng.L, eng.Q, eng.X
+    w0 = first_day - ctx_len
+    sv = vol[w0:]
+    se = ex[w0:] if X > 0 else None
+    enc = eng.encode_strided(0, sv, 25, 25, se, X, X, n_days, T)            # posterior on context + target
+    zm, zl = enc[..., :L].contiguous(), enc[..., L:].contiguous()
+    ctx = eng.encode_strided(1, sv, 25, 25, se, X, X, n_days, ctx_len)
+    outs = []
+    for d0 in range(0, n_days, chunk_days):
+        nd = min(chunk_days, n_days - d0)
+        r = eng.decode(nd * n_samples, T, ctx_len, ctx=ctx[d0:d0 + nd], ctx_div=n_samples,
+                       zb=zm[d0:d0 + nd], lv=zl[d0:d0 + nd], z_div=n_samples,
+                       seed=seed, S=n_samples, day0=day_index0 + d0, out_mode=1)
+        smp = r["surf"]                                                       # (nd, H, Q*25, S)
+        if channel is None:
+            q = eng.percentile(smp, qs, inner=Q * 25).view(nd, horizon, len(qs), Q, 5, 5)
+        else:
+            sel = smp.view(nd, horizon, Q, 25, n_samples)[:, :, channel]
+            q = eng.percentile(sel, qs, inner=25).view(nd, horizon, len(qs), 5, 5)
+        outs.append(q)
+    return torch.cat(outs, dim=0)

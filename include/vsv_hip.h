@@ -29,8 +29,9 @@
 extern "C" {
 #endif
 
-#define VSV_ABI_VERSION 2
+#define VSV_ABI_VERSION 3
 #define VSV_MAX_CONV 4
+#define VSV_MAX_CHAIN 6
 
 /* Model shape: the subset of the reference's config dict that fixes tensor
  * shapes (cvae_with_mem_randomized.py:969-1020; state_dict layout SURVEY.md
@@ -165,6 +166,99 @@ int vsv_percentile(const float *in, long n_vec, int S, const double *q_host, int
  * Stands in for torch.randn at cvae_with_mem_randomized.py:693-694. */
 int vsv_philox_normal(uint64_t seed, long day0, long n_days, long S, int step0, int n_steps,
                       int L, float *out, void *stream);
+
+/* ---- training ---------------------------------------------------------------------
+ * CVAEMemRand.train_step / train_step_multihorizon / test_step
+ * (cvae_with_mem_randomized.py:1076-1308) split into: forward passes that keep the
+ * activations BPTT needs, the loss terms with their gradients, and backward kernels that
+ * turn output gradients into gate / pre-activation gradients.  Weight gradients are the
+ * plain matrix products  dW = G^T . X  of tensors these calls leave in memory (the caller
+ * runs them as library GEMMs and scatters them onto the parameters through the packing
+ * map); the recurrent and element-wise work is here.
+ *
+ * Tile layouts.  rt = ceil(n_rows/32) row tiles; an instance is (row tile, t),
+ * inst = tile*T + t.  A "tile-B" tensor is [inst][slots][64]: slot s, lane (hh = l>>5,
+ * m = l&31) holds one feature of row 32*tile + m -- feature 2s+hh in NATURAL order
+ * (LSTM h / c, decoder x part, first conv input) or 32*(s>>4) + 8*((s>>2)&3) + 4*hh + (s&3)
+ * in SLOT order (outputs of dense layers and gate rows; gate row = 32*tile' + 4*unit%8 + gate).
+ * NTm/NTd = ceil(hidden/8) gate tiles.  Buffers of the vsv_train_save struct, all caller-owned:
+ *   emb_acts  encoders: [n_conv][inst][64][64]  input of every conv layer
+ *   xe        [inst][kx][64]                    LSTM x part (encoders: conv embedding, slot
+ *                                               order, kx = 64; decoder: [ctx | z], natural)
+ *   gates     [inst][layers][16*NT][64]         activated gates i,f,g,o (slot 16*tile+4*jj+gate)
+ *   c, h      [inst][layers][4*NT][64]          cell / hidden state after the step (natural)
+ *   hout      [tile*(T-t_out0) + t-t_out0][4*NT][64]  top-layer h of the output steps
+ *   head_acts decoder: [n_head][out inst][64][64]     input of every head layer */
+typedef struct vsv_train_save {
+    float *emb_acts, *xe, *gates, *c, *h, *hout, *head_acts;
+} vsv_train_save;
+
+/* vsv_encode / vsv_decode (out_mode 0, zero initial state, head not fused) that also fill `sv`. */
+int vsv_train_encode(const vsv_dims *dims, const float *packed, int which,
+                     const float *surf, long surf_row_stride, long surf_t_stride,
+                     const float *ex, long ex_row_stride, long ex_t_stride,
+                     long n_rows, int T, float *out, const vsv_train_save *sv, void *stream);
+int vsv_train_decode(const vsv_dims *dims, const float *packed, const vsv_decode_in *in,
+                     long n_rows, int T, int t_out0, float *z_out, float *surf_out, float *ex_out,
+                     const vsv_train_save *sv, void *stream);
+
+/* Backward of a chain of dense layers (conv embeddings, linear heads, decoder head), one
+ * layer per entry, LAST forward layer first.  Per layer: g = (incoming + add) masked by the
+ * forward output's ReLU -> g_out (tile-B, slot order; dW = g^T . layer input); then
+ * incoming = W^T . g through the transposed fragments wT (built by the caller from the
+ * packed blob; their output order is the previous layer's slot order). */
+typedef struct vsv_dense_bwd_layer {
+    const float *wT; int nqT, ntT;          /* ntT = 0: stop, no input gradient wanted */
+    const float *act_out; int n_relu;       /* forward output of the layer (tile-B [inst][64][64]) or NULL */
+    float *g_out;                           /* [inst][64][64] or NULL */
+    const float *add; int add_f0, add_n;    /* row-major (row, T, add_n) extra gradient on output features */
+} vsv_dense_bwd_layer;
+typedef struct vsv_dense_bwd {
+    int n_layers;
+    vsv_dense_bwd_layer layer[VSV_MAX_CHAIN];
+    long n_rows, n_rowtiles;
+    int T;
+    int in_mode;                            /* 0: row-major (row, T, in_f); 1: tile-B [inst][64][64], slot order */
+    const float *in; int in_f;
+    float *dx_out;                          /* [inst][64][64] gradient w.r.t. the chain input, or NULL */
+} vsv_dense_bwd;
+int vsv_dense_backward(const vsv_dense_bwd *d, void *stream);
+
+/* BPTT of nn.LSTM (the autograd of cvae_with_mem_randomized.py:193, :342, :491).  wT_hh[l],
+ * wT_in[l]: transposed fragments with K = the layer's gate rows (slot order, 16*NT k-steps) and
+ * output = "unit tiles" (tile w, register 4*jj'+r' <-> unit 8*(4*jj'+w) + 2*r' + hh), 4 tiles;
+ * wT_in[0] maps to the x features instead (nt_x tiles).  dh_top: gradient w.r.t. the top
+ * layer's h at the output steps, [out inst][64][64] with slot 16*w + register.  dgates
+ * receives the gate pre-activation gradients in the layout of sv->gates; the x gradient is
+ * written as tile-B (dx_tile, slot order) and/or row-major (dx_rows). */
+typedef struct vsv_lstm_bwd {
+    const float *wT_hh[2], *wT_in[2];
+    int nt_x;
+    long n_rows, n_rowtiles;
+    int T, t_out0;
+    const float *sv_gates, *sv_c, *dh_top;
+    float *dgates, *dx_tile, *dx_rows;
+    int dx_f;
+} vsv_lstm_bwd;
+int vsv_lstm_backward(const vsv_lstm_bwd *d, int hidden, int layers, void *stream);
+
+/* Loss terms of train_step (:1113-1125) and their gradients: pinball over the quantile
+ * channels (QuantileLoss, :28-45; qw = weights / sum(weights)), ex-feature MSE ("l2") or L1
+ * on the first ex_n features (:1115-1118), KL over all T positions (:1123-1124).
+ * sums (3 doubles, zeroed by the caller) receive re_surface, re_ex_feats, kl; the gradients
+ * are those of  re_surface + ex_weight*re_ex_feats + kl_weight*kl. */
+typedef struct vsv_loss {
+    const float *pred, *target;             /* (B,H,Q,25); surface (B,T,25), last H steps are the targets */
+    int B, H, T, Q;
+    float q[8], qw[8];
+    const float *ex_pred, *ex_target;       /* (B,H,X) or NULL; (B,T,X) */
+    int X, ex_n, ex_l2;
+    float ex_weight, kl_weight;
+    const float *zm, *zl; int L;            /* (B,T,L) */
+    float *d_pred, *d_ex, *d_zm, *d_zl;
+    double *sums;
+} vsv_loss;
+int vsv_loss_grad(const vsv_loss *d, void *stream);
 
 /* ---- profiling aid -----------------------------------------------------------------
  * Arms the NEXT vsv_decode call made by this thread: it records the two hipEvent_t

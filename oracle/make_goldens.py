@@ -198,6 +198,90 @@ def case_ar_offset(name, cfg, seed, scale, B, C, H, steps):
     save(name, cfg, d)
 
 
+def case_grads(name, cfg, seed, scale, B, T, horizon, full=True):
+    """G4: gradients of the train_step loss (cvae_with_mem_randomized.py:1113-1127) w.r.t. every
+    parameter, float64, dropout 0, injected eps.  test_step builds the same loss graph as
+    train_step (:1265-1308 vs :1105-1125); backward() here gives the un-clipped gradients, then
+    train_step itself (SGD, lr 0) gives the clipped ones (clip_grad_norm_ 1.0, :1128)."""
+    np_dtype = np.float64
+    model, _ = build_reference(cfg, seed, scale, np_dtype)
+    model.train()                                   # dropout is 0 in cfg, so train == eval numerically
+    rng = np.random.Generator(np.random.PCG64(6000 + seed))
+    X, L = cfg["ex_feats_dim"], cfg["latent_dim"]
+    surf, ex = synth(rng, B, T, X, np_dtype)
+    eps = rng.standard_normal((B, T, L)).astype(np_dtype)
+    x = {"surface": torch.from_numpy(surf)}
+    if X:
+        x["ex_feats"] = torch.from_numpy(ex)
+    model.horizon = horizon
+    model.zero_grad()
+    with NoiseQueue() as nq:
+        nq.push(eps)
+        losses = model.test_step(x)
+    losses["loss"].backward()
+    d = dict(surface=surf, eps=eps, horizon=horizon, seed=seed, scale=scale)
+    if X:
+        d["ex_feats"] = ex
+    for k, v in losses.items():
+        d["loss_" + k] = np.float64(t2n(v).reshape(-1)[0])
+    grads = {n: t2n(p.grad).copy() for n, p in model.named_parameters()}
+    total = float(np.sqrt(sum(float((g ** 2).sum()) for g in grads.values())))
+    d["grad_total_norm"] = np.float64(total)
+    for n, g in grads.items():
+        d["gnorm/" + n] = np.float64(np.sqrt((g ** 2).sum()))
+        if full:
+            d["grad/" + n] = g.astype(np.float32)
+        else:
+            flat = g.ravel()
+            idx = np.linspace(0, flat.size - 1, num=min(flat.size, 64)).astype(np.int64)
+            d["gidx/" + n] = idx
+            d["gval/" + n] = flat[idx]
+    # the real train_step: clipped gradients left in .grad (lr = 0 keeps the weights)
+    opt = torch.optim.SGD(model.parameters(), lr=0.0)
+    with NoiseQueue() as nq:
+        nq.push(eps)
+        out = model.train_step(x, opt)
+    d["train_loss"] = np.float64(t2n(out["loss"]).reshape(-1)[0])
+    cl = float(np.sqrt(sum(float((t2n(p.grad) ** 2).sum()) for p in model.parameters())))
+    d["clipped_total_norm"] = np.float64(cl)
+    save(name, cfg, d)
+
+
+def case_multihorizon(name, cfg, seed, scale, B, T, horizons):
+    """G5: train_step_multihorizon (:1139-1263) with one injected eps per horizon."""
+    np_dtype = np.float64
+    model, _ = build_reference(cfg, seed, scale, np_dtype)
+    model.train()
+    rng = np.random.Generator(np.random.PCG64(7000 + seed))
+    X, L = cfg["ex_feats_dim"], cfg["latent_dim"]
+    surf, ex = synth(rng, B, T, X, np_dtype)
+    eps = rng.standard_normal((len(horizons), B, T, L)).astype(np_dtype)
+    x = {"surface": torch.from_numpy(surf)}
+    if X:
+        x["ex_feats"] = torch.from_numpy(ex)
+    opt = torch.optim.SGD(model.parameters(), lr=0.0)
+    with NoiseQueue() as nq:
+        for i in range(len(horizons)):
+            nq.push(eps[i])
+        out = model.train_step_multihorizon(x, opt, horizons=list(horizons))
+    d = dict(surface=surf, eps=eps, horizons=np.asarray(horizons), seed=seed, scale=scale)
+    if X:
+        d["ex_feats"] = ex
+    d["loss"] = np.float64(out["loss"])
+    d["reconstruction_loss"] = np.float64(out["reconstruction_loss"])
+    d["kl_loss"] = np.float64(out["kl_loss"])
+    d["horizon_losses"] = np.asarray([out["horizon_losses"][h] for h in horizons], dtype=np.float64)
+    grads = {n: t2n(p.grad).copy() for n, p in model.named_parameters()}
+    d["grad_total_norm"] = np.float64(np.sqrt(sum(float((g ** 2).sum()) for g in grads.values())))
+    for n, g in grads.items():
+        d["gnorm/" + n] = np.float64(np.sqrt((g ** 2).sum()))
+        flat = g.ravel()
+        idx = np.linspace(0, flat.size - 1, num=min(flat.size, 64)).astype(np.int64)
+        d["gidx/" + n] = idx
+        d["gval/" + n] = flat[idx]
+    save(name, cfg, d)
+
+
 def case_losses():
     """G3: QuantileLoss on small tensors incl. the reference's own KATs
     (test_code/test_quantile_decoder.py:58-66, 70-94)."""
@@ -224,6 +308,8 @@ def save(name, cfg, d):
     d["cfg_ex_feats_dim"] = cfg["ex_feats_dim"]
     d["cfg_mem_layers"] = cfg["mem_layers"]
     d["cfg_quantile_loss_weights"] = np.asarray(cfg.get("quantile_loss_weights") or [1.0, 1.0, 1.0])
+    for k in ("ex_loss_on_ret_only", "ex_feats_loss_type", "kl_weight", "re_feat_weight"):
+        d["cfg_" + k] = np.asarray(cfg[k])
     path = os.path.join(OUT, name + ".npz")
     np.savez_compressed(path, **d)
     print("wrote", name, os.path.getsize(path) // 1024, "KiB")
@@ -257,7 +343,25 @@ def main():
     case_ar("g6_ar_ex5_C20_H30", ex5, 21, 2.0, 4, 20, 30)
     case_ar_offset("g7_aroff_ex12_C60_H60x3", ex12, 22, 2.0, 2, 60, 60, 3)
     case_losses()
+    main_training()
+
+
+def main_training():
+    """G4 / G5: gradients (float64 reference)."""
+    ex5 = vo.make_config(5, 3)
+    no_ex = vo.make_config(5, 0)
+    ex12w = vo.make_config(12, 3, quantile_loss_weights=[5.0, 1.0, 5.0], ex_loss_on_ret_only=False,
+                           ex_feats_loss_type="l1", kl_weight=1e-3, re_feat_weight=0.5)
+    case_grads("g4_grads_ex5_B8_T21_h1", ex5, 30, 2.0, 8, 21, 1, full=True)
+    case_grads("g4_grads_noex_B5_T9_h3", no_ex, 31, 2.0, 5, 9, 3, full=False)
+    case_grads("g4_grads_ex12_B4_T40_h7", ex12w, 32, 2.0, 4, 40, 7, full=False)
+    case_multihorizon("g5_multih_ex5_B4_T50", vo.make_config(5, 3, quantile_loss_weights=[5.0, 1.0, 5.0]),
+                      33, 2.0, 4, 50, [1, 7, 14, 30])
 
 
 if __name__ == "__main__":
-    main()
+    if len(sys.argv) > 1 and sys.argv[1] == "training":
+        os.makedirs(OUT, exist_ok=True)
+        main_training()
+    else:
+        main()

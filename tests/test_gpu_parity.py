@@ -265,3 +265,58 @@ def test_oracle_mc_windows_vs_oracle():
         want[d] = vo.forward(W64, cfg, win, wex, eps, H)[0]
     wq = np.percentile(want, [5, 50, 95], axis=1).transpose(1, 2, 0, 3, 4, 5)
     assert err(_n(q), wq) <= TOL
+
+
+# ---- training: losses and gradients against the reference's autograd (goldens g4 / g5) ----
+
+def _train_setup(g):
+    from vsv.engine import Engine
+    from vsv.train import TrainEngine
+    cfg = cfg_of(g)
+    W = vo.init_weights(cfg, int(g["seed"]), float(g["scale"]), np.float32)
+    eng = Engine(cfg, W, "cuda:0")
+    te = TrainEngine(eng, vo.state_dict_spec(cfg))
+    return cfg, eng, te
+
+
+def _loss_cfg(cfg, g):
+    X = cfg["ex_feats_dim"]
+    return dict(quantiles=cfg["quantiles"], quantile_weights=[float(x) for x in g["cfg_quantile_loss_weights"]],
+                ex_n=(1 if cfg["ex_loss_on_ret_only"] else max(X, 1)), ex_l2=int(cfg["ex_feats_loss_type"] == "l2"),
+                ex_weight=cfg["re_feat_weight"], kl_weight=cfg["kl_weight"])
+
+
+def _check_grads(g, names, grads, rtol=1e-3):
+    total = 0.0
+    for n, gr in zip(names, grads):
+        gr = _n(gr)
+        total += float((gr ** 2).sum())
+        want_norm = float(g["gnorm/" + n])
+        scale = max(want_norm / np.sqrt(gr.size), 1e-12)            # RMS magnitude of the tensor's gradient
+        if "grad/" + n in g:
+            want = g["grad/" + n].astype(np.float64)
+            assert np.max(np.abs(gr - want)) <= rtol * max(np.max(np.abs(want)), scale) + 1e-9, n
+        else:
+            idx = g["gidx/" + n]
+            want = g["gval/" + n]
+            assert np.max(np.abs(gr.ravel()[idx] - want)) <= rtol * max(np.max(np.abs(want)), 10 * scale) + 1e-9, n
+        assert abs(np.sqrt((gr ** 2).sum()) - want_norm) <= rtol * want_norm + 1e-9, n
+    assert abs(np.sqrt(total) - float(g["grad_total_norm"])) <= rtol * float(g["grad_total_norm"])
+
+
+@pytest.mark.parametrize("name", golden_names("g4_"))
+def test_train_losses_and_gradients_vs_reference(name):
+    g = load_golden(name)
+    cfg, eng, te = _train_setup(g)
+    # goldens that pass extra loss settings store them in the file name's config: rebuild from the golden keys
+    for k in ("ex_loss_on_ret_only", "ex_feats_loss_type", "kl_weight", "re_feat_weight"):
+        if "cfg_" + k in g:
+            v = g["cfg_" + k]
+            cfg[k] = v.item() if v.dtype.kind != "U" else str(v)
+    losses, gp, _ = te.loss_and_grads(_t(g["surface"]), _t(g.get("ex_feats")), int(g["horizon"]), _loss_cfg(cfg, g),
+                                      eps=_t(g["eps"]))
+    for k in ("loss", "re_surface", "re_ex_feats", "reconstruction_loss", "kl_loss"):
+        want = float(g["loss_" + k])
+        assert abs(float(losses[k]) - want) <= 1e-3 * abs(want) + 1e-9, (k, float(losses[k]), want)
+    grads = te.param_grads(gp)
+    _check_grads(g, [n for n, _ in vo.state_dict_spec(cfg)], grads)

@@ -23,10 +23,6 @@
 
 #include "vsv_layout.h"
 
-#ifndef VSV_HEAD_PREFETCH
-#define VSV_HEAD_PREFETCH 1
-#endif
-
 namespace vsv {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -176,6 +172,8 @@ struct DenseChainArgs {
     int aux_layer;
     float* aux;
     int aux_f0, aux_n;
+    // training: the INPUT of every layer (64 slots) -> save[(li*n_inst + inst)*64 + s][64]
+    float* save;
 };
 
 constexpr int kDenseSlots = 16 * kHeadTiles;     // LDS k-step slots per wave
@@ -295,6 +293,10 @@ __global__ void __launch_bounds__(256, 2) dense_chain_kernel(const DenseChainArg
     const RowIo io = make_rowio(a, row, row_ok, t);
 #pragma unroll 1
     for (int li = 0; li < a.n_layers; ++li) {
+        if (a.save) {
+            float* sv = a.save + ((size_t)li * (a.n_rowtiles * a.T) + inst) * kDenseSlots * 64 + lane;
+            for (int s = 0; s < kDenseSlots; ++s) sv[s * 64] = col[s * 64];
+        }
         switch (a.layer[li].nt) {
             case 1: dense_layer<1>(a, io, li, col, lane, inst); break;
             case 2: dense_layer<2>(a, io, li, col, lane, inst); break;
@@ -329,6 +331,9 @@ struct LstmSeqArgs {
     int t_out0;
     // fused decoder head (HEAD): layers, outputs and aux as in DenseChainArgs (in_* unused, T = T - t_out0)
     DenseChainArgs head;
+    // training (SAVE): activated gates [inst][l][16*NT][64] (slot 16*tile + 4*jj + gate), cell and hidden
+    // state after the step [inst][l][4*NT][64], decoder x part [inst][kx][64]; inst = rowtile*T + t
+    float *sv_gates, *sv_c, *sv_h, *sv_x;
 };
 
 // per-thread constants of the decoder input assembly
@@ -373,7 +378,8 @@ __device__ __forceinline__ float decoder_input(const LstmSeqArgs& a, const DecIn
 constexpr int kOwn = 4;      // gate tiles per wave (tiles w, w+4, w+8, w+12): hidden size <= 128
 
 // LSTM cell: lane holds gates (i,f,g,o) of unit 8t + 2jj + hh in acc[i][4jj .. 4jj+3]
-__device__ __forceinline__ void lstm_cell(const f32x16 (&acc)[kOwn], float (&c)[kOwn][4], float (&hn)[kOwn][4]) {
+template <bool KEEP>
+__device__ __forceinline__ void lstm_cell(f32x16 (&acc)[kOwn], float (&c)[kOwn][4], float (&hn)[kOwn][4]) {
 #pragma unroll
     for (int i = 0; i < kOwn; ++i) {
 #pragma unroll
@@ -385,6 +391,9 @@ __device__ __forceinline__ void lstm_cell(const f32x16 (&acc)[kOwn], float (&c)[
             const float cn = fg * c[i][jj] + ig * gg;
             c[i][jj] = cn;
             hn[i][jj] = og * fast_tanh(cn);
+            if (KEEP) {
+                acc[i][4 * jj + 0] = ig; acc[i][4 * jj + 1] = fg; acc[i][4 * jj + 2] = gg; acc[i][4 * jj + 3] = og;
+            }
         }
     }
 }
@@ -419,13 +428,11 @@ __device__ __forceinline__ void fused_head(const LstmSeqArgs& a, const float* ht
             if (li == 0) tile_mfma<NT>(acc[0], wq, src);
             else tile_mfma<4 * kHeadTiles>(acc[0], wq, src);
         }
-#if VSV_HEAD_PREFETCH
         if (!last) {
             const DenseLayerArg& nx = hd.layer[li + 1];
             const int tw = wave < nx.nt ? wave : nx.nt - 1;
             tile_load<4 * kHeadTiles>(wq, (const float4*)nx.w + tw * 64 + lane, nx.nt * 64);
         }
-#endif
         if (mine) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
@@ -439,23 +446,13 @@ __device__ __forceinline__ void fused_head(const LstmSeqArgs& a, const float* ht
         }
         if (!last) __syncthreads();
         src = dst;
-#if !VSV_HEAD_PREFETCH
-        if (!last) {
-            const DenseLayerArg& nx = hd.layer[li + 1];
-            const int tw = wave < nx.nt ? wave : nx.nt - 1;
-            tile_load<4 * kHeadTiles>(wq, (const float4*)nx.w + tw * 64 + lane, nx.nt * 64);
-        }
-#endif
     }
 }
 
-#ifndef VSV_X_AHEAD
-#define VSV_X_AHEAD 1
-#endif
 #ifndef VSV_LSTM_OCC
 #define VSV_LSTM_OCC 2
 #endif
-template <int NT, int NL, int XMODE, bool HEAD>
+template <int NT, int NL, int XMODE, bool HEAD, bool SAVE>
 __global__ void __launch_bounds__(256, VSV_LSTM_OCC) lstm_kernel(const LstmSeqArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     static_assert(NT <= 4 * kOwn, "hidden size <= 128");
@@ -519,17 +516,17 @@ __global__ void __launch_bounds__(256, VSV_LSTM_OCC) lstm_kernel(const LstmSeqAr
         }
     }
     // x part of layer 0 for step 0 (slots wave, wave+4, ...: the waves share the assembly)
-    if (XMODE == 1 && VSV_X_AHEAD) {
-        for (int s = wave; s < kx; s += 4) xs[s * 64] = decoder_input(a, di, row, row_ok, true, 0, 2 * s + hh);
+    if (XMODE == 1) {
+        for (int s = wave; s < kx; s += 4) {
+            const float v = decoder_input(a, di, row, row_ok, true, 0, 2 * s + hh);
+            xs[s * 64] = v;
+            if (SAVE) a.sv_x[((size_t)(rowtile * a.T) * kx + s) * 64 + lane] = v;
+        }
     }
     __syncthreads();
 
     const int t_outs = a.T - a.t_out0;
     for (int t = 0; t < a.T; ++t) {
-        if (XMODE == 1 && !VSV_X_AHEAD) {
-            // the 4 waves write the same values; xs was last read before layer 0's first barrier of step t-1
-            for (int s = 0; s < kx; ++s) xs[s * 64] = decoder_input(a, di, row, row_ok, wave == 0, t, 2 * s + hh);
-        }
 #pragma unroll
         for (int l = 0; l < NL; ++l) {
             f32x16 acc[kOwn];
@@ -557,7 +554,25 @@ __global__ void __launch_bounds__(256, VSV_LSTM_OCC) lstm_kernel(const LstmSeqAr
                 gemm_seg<kOwn>(acc, w, toff, NT * 64, bin, nq_in);
                 gemm_seg<kOwn>(acc, w + (size_t)nq_in * NT * 64, toff, NT * 64, hl, NT);
             }
-            lstm_cell(acc, c[l], hn);
+            lstm_cell<SAVE>(acc, c[l], hn);
+            if (SAVE) {
+                const size_t il = (size_t)(rowtile * a.T + t) * NL + l;
+                float* sg = a.sv_gates + il * (16 * NT) * 64 + lane;
+                float* sc = a.sv_c + il * HPK * 64 + lane;
+                float* sh = a.sv_h + il * HPK * 64 + lane;
+#pragma unroll
+                for (int i = 0; i < kOwn; ++i) {
+                    if (tval[i]) {
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) sg[((toff[i] >> 2) + r) * 64] = acc[i][r];
+#pragma unroll
+                        for (int jj = 0; jj < 4; ++jj) {
+                            sc[((toff[i] >> 4) + jj) * 64] = c[l][i][jj];
+                            sh[((toff[i] >> 4) + jj) * 64] = hn[i][jj];
+                        }
+                    }
+                }
+            }
             // h of this layer is overwritten only after every wave has read the old one
             __syncthreads();
 #pragma unroll
@@ -567,9 +582,13 @@ __global__ void __launch_bounds__(256, VSV_LSTM_OCC) lstm_kernel(const LstmSeqAr
                     for (int jj = 0; jj < 4; ++jj) hl[((toff[i] >> 4) + jj) * 64] = hn[i][jj];
                 }
             }
-            if (XMODE == 1 && VSV_X_AHEAD && l == NL - 1 && t + 1 < a.T) {
+            if (XMODE == 1 && l == NL - 1 && t + 1 < a.T) {
                 // x part of the NEXT step: xs was last read before this layer's first barrier
-                for (int s = wave; s < kx; s += 4) xs[s * 64] = decoder_input(a, di, row, row_ok, true, t + 1, 2 * s + hh);
+                for (int s = wave; s < kx; s += 4) {
+                    const float v = decoder_input(a, di, row, row_ok, true, t + 1, 2 * s + hh);
+                    xs[s * 64] = v;
+                    if (SAVE) a.sv_x[((size_t)(rowtile * a.T + t + 1) * kx + s) * 64 + lane] = v;
+                }
             }
             __syncthreads();
         }
@@ -627,6 +646,276 @@ __global__ void __launch_bounds__(256, VSV_LSTM_OCC) lstm_kernel(const LstmSeqAr
             }
         }
     }
+}
+
+// ---------------------------------------------------------------------------
+// dense_bwd_kernel: backward of a dense chain for independent (row tile, t)
+// instances, one wave per instance.  col holds the gradient w.r.t. a forward
+// layer's OUTPUT in that layer's slot order (slot 16t + reg <-> feature
+// 32t + 8(reg>>2) + 4hh + (reg&3)); per layer, last forward layer first:
+//   g = (col + add) * [forward output > 0 where the layer has a ReLU]   -> g_out (for dW = g^T . input)
+//   col = W^T . g   (transposed fragments whose output order is the previous layer's slot order)
+// ---------------------------------------------------------------------------
+typedef vsv_dense_bwd_layer DenseBwdLayer;
+typedef vsv_dense_bwd DenseBwdArgs;
+
+template <int NT>
+__device__ __forceinline__ void dense_bwd_layer(const DenseBwdLayer& ly, float* col, int lane) {
+    f32x16 acc[NT];
+    int toff[NT];
+#pragma unroll
+    for (int i = 0; i < NT; ++i) {
+        toff[i] = i * 64;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][r] = 0.0f;
+    }
+    gemm_seg<NT>(acc, (const float4*)ly.wT + lane, toff, NT * 64, col, ly.nqT);
+#pragma unroll
+    for (int tt = 0; tt < NT; ++tt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) col[(16 * tt + r) * 64] = acc[tt][r];
+    for (int s = 16 * NT; s < kDenseSlots; ++s) col[s * 64] = 0.0f;
+}
+
+__global__ void __launch_bounds__(256, 2) dense_bwd_kernel(const DenseBwdArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const long inst = (long)blockIdx.x * 4 + wave;
+    if (inst >= a.n_rowtiles * a.T) return;
+    const long rowtile = inst / a.T;
+    const int t = (int)(inst % a.T);
+    const int hh = lane >> 5, m = lane & 31;
+    long row = rowtile * 32 + m;
+    const bool row_ok = row < a.n_rows;
+    if (!row_ok) row = a.n_rows - 1;
+    float* col = smem + (size_t)wave * (kDenseSlots * 64) + lane;
+    if (a.in_mode == 0) {
+        const float* src = a.in + ((size_t)row * a.T + t) * a.in_f;
+        for (int s = 0; s < kDenseSlots; ++s) {
+            const int f = feat_of(s >> 4, s & 15, hh);
+            col[s * 64] = (row_ok && f < a.in_f) ? src[f] : 0.0f;
+        }
+    } else {
+        const float* src = a.in + (size_t)inst * kDenseSlots * 64 + lane;
+        for (int s = 0; s < kDenseSlots; ++s) col[s * 64] = row_ok ? src[s * 64] : 0.0f;
+    }
+#pragma unroll 1
+    for (int li = 0; li < a.n_layers; ++li) {
+        const DenseBwdLayer& ly = a.layer[li];
+        const float* act = ly.act_out ? ly.act_out + (size_t)inst * kDenseSlots * 64 + lane : nullptr;
+        const float* add = (ly.add && row_ok) ? ly.add + ((size_t)row * a.T + t) * ly.add_n - ly.add_f0 : nullptr;
+        float* go = ly.g_out ? ly.g_out + (size_t)inst * kDenseSlots * 64 + lane : nullptr;
+        for (int s = 0; s < kDenseSlots; ++s) {
+            const int f = feat_of(s >> 4, s & 15, hh);
+            float g = col[s * 64];
+            if (add && f >= ly.add_f0 && f < ly.add_f0 + ly.add_n) g += add[f];
+            if (act && f < ly.n_relu && !(act[s * 64] > 0.0f)) g = 0.0f;
+            col[s * 64] = g;
+            if (go) go[s * 64] = g;
+        }
+        switch (ly.ntT) {
+            case 0: break;
+            case 1: dense_bwd_layer<1>(ly, col, lane); break;
+            case 2: dense_bwd_layer<2>(ly, col, lane); break;
+            case 3: dense_bwd_layer<3>(ly, col, lane); break;
+            default: dense_bwd_layer<4>(ly, col, lane); break;
+        }
+    }
+    if (a.dx_out) {
+        float* o = a.dx_out + (size_t)inst * kDenseSlots * 64 + lane;
+        for (int s = 0; s < kDenseSlots; ++s) o[s * 64] = col[s * 64];
+    }
+}
+
+// ---------------------------------------------------------------------------
+// lstm_bwd_kernel: BPTT of a 1- or 2-layer LSTM for a tile of 32 rows per
+// workgroup (4 waves).  Wave w owns the hidden units of gate tiles w, w+4, ...,
+// i.e. "unit tile" w: accumulator register 4*jj' + r' of that tile holds unit
+// 8*(4*jj' + w) + 2*r' + hh -- the unit whose gates the same lane produced in the
+// forward kernel, so saved gates / cell states are read back lane-for-lane.
+// Per step (t = T-1 .. 0) and layer (top first):
+//   dh  = [dh_top(t) | W_in(l+1)^T . dgates(l+1, t)] + W_hh(l)^T . dgates(l, t+1)
+//   dgates(l, t) from dh, dc, the saved gates and cell states  -> LDS (B operand) + global (for dW)
+//   dx(t) = W_in(0)^T . dgates(0, t)
+// ---------------------------------------------------------------------------
+typedef vsv_lstm_bwd LstmBwdArgs;
+
+template <int NT, int NL>
+__global__ void __launch_bounds__(256, 1) lstm_bwd_kernel(const LstmBwdArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    constexpr int GK = 16 * NT;                                   // k-steps of one layer's gate rows
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const long rowtile = (long)blockIdx.x;
+    const int hh = lane >> 5, m = lane & 31;
+    const long row_raw = rowtile * 32 + m;
+    const bool row_ok = row_raw < a.n_rows;
+    float* dg = smem + lane;                                      // dgates of layer l: dg + l*GK*64
+    for (int s = wave; s < NL * GK; s += 4) dg[s * 64] = 0.0f;
+    float dc[NL][16];
+#pragma unroll
+    for (int l = 0; l < NL; ++l)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) dc[l][r] = 0.0f;
+    const int toff1[1] = {wave * 64};
+    const int t_outs = a.T - a.t_out0;
+    __syncthreads();
+
+    for (int t = a.T - 1; t >= 0; --t) {
+        const size_t inst = (size_t)(rowtile * a.T + t);
+#pragma unroll
+        for (int l = NL - 1; l >= 0; --l) {
+            f32x16 acc[1];
+            if (l == NL - 1) {
+                if (t >= a.t_out0 && a.dh_top) {
+                    const float* p = a.dh_top + ((size_t)(rowtile * t_outs + (t - a.t_out0)) * 64 + 16 * wave) * 64 + lane;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[0][r] = p[r * 64];
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[0][r] = 0.0f;
+                }
+            } else {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[0][r] = 0.0f;
+                gemm_seg<1>(acc, (const float4*)a.wT_in[l + 1] + lane, toff1, 4 * 64, dg + (size_t)(l + 1) * GK * 64, 4 * NT);
+            }
+            if (t + 1 < a.T)
+                gemm_seg<1>(acc, (const float4*)a.wT_hh[l] + lane, toff1, 4 * 64, dg + (size_t)l * GK * 64, 4 * NT);
+            // cell backward for the 16 units of this lane
+            float dgv[16][4];
+            const float* sg = a.sv_gates + (inst * NL + l) * GK * 64 + lane;
+            const float* sc = a.sv_c + (inst * NL + l) * (4 * NT) * 64 + lane;
+            const float* scp = (t > 0) ? a.sv_c + ((inst - 1) * NL + l) * (4 * NT) * 64 + lane : nullptr;
+#pragma unroll
+            for (int jq = 0; jq < 4; ++jq) {
+                const int tg = 4 * jq + wave;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int reg = 4 * jq + r;
+                    float di = 0.0f, df = 0.0f, dgg = 0.0f, dog = 0.0f;
+                    if (tg < NT) {
+                        const int gs = 16 * tg + 4 * r, cs = 4 * tg + r;
+                        const float ig = sg[(gs + 0) * 64], fg = sg[(gs + 1) * 64], gg = sg[(gs + 2) * 64], og = sg[(gs + 3) * 64];
+                        const float cn = sc[cs * 64];
+                        const float cp = scp ? scp[cs * 64] : 0.0f;
+                        const float th = fast_tanh(cn);
+                        const float dh = acc[0][reg];
+                        const float dct = dc[l][reg] + dh * og * (1.0f - th * th);
+                        dog = dh * th * og * (1.0f - og);
+                        di = dct * gg * ig * (1.0f - ig);
+                        df = dct * cp * fg * (1.0f - fg);
+                        dgg = dct * ig * (1.0f - gg * gg);
+                        dc[l][reg] = dct * fg;
+                    }
+                    dgv[reg][0] = di; dgv[reg][1] = df; dgv[reg][2] = dgg; dgv[reg][3] = dog;
+                }
+            }
+            __syncthreads();                                       // every wave has read dgates(l, t+1)
+            float* dgl = dg + (size_t)l * GK * 64;
+            float* dgo = a.dgates + (inst * NL + l) * GK * 64 + lane;
+#pragma unroll
+            for (int jq = 0; jq < 4; ++jq) {
+                const int tg = 4 * jq + wave;
+                if (tg < NT) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+#pragma unroll
+                        for (int g = 0; g < 4; ++g) {
+                            const float v = row_ok ? dgv[4 * jq + r][g] : 0.0f;
+                            dgl[(16 * tg + 4 * r + g) * 64] = v;
+                            dgo[(16 * tg + 4 * r + g) * 64] = v;
+                        }
+                }
+            }
+            __syncthreads();                                       // dgates(l, t) complete
+        }
+        if (a.nt_x > 0 && wave < a.nt_x) {
+            f32x16 acc[1];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[0][r] = 0.0f;
+            gemm_seg<1>(acc, (const float4*)a.wT_in[0] + lane, toff1, a.nt_x * 64, dg, 4 * NT);
+            if (a.dx_tile) {
+                float* o = a.dx_tile + (inst * 64 + 16 * wave) * 64 + lane;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) o[r * 64] = acc[0][r];
+            }
+            if (a.dx_rows && row_ok) {
+                float* o = a.dx_rows + ((size_t)row_raw * a.T + t) * a.dx_f;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int f = feat_of(wave, r, hh);
+                    if (f < a.dx_f) o[f] = acc[0][r];
+                }
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// loss_grad_kernel: the loss terms of train_step (pinball over the quantile
+// channels, ex-feature MSE/L1, KL over all T positions) and their gradients.
+// sums[0..2] (double, zeroed by the caller) receive the three MEANS.
+// ---------------------------------------------------------------------------
+typedef vsv_loss LossArgs;
+
+__global__ void __launch_bounds__(256) loss_grad_kernel(const LossArgs a) {
+    __shared__ double red[3][256];
+    const int tid = threadIdx.x;
+    double s0 = 0.0, s1 = 0.0, s2 = 0.0;
+    const long n_s = (long)a.B * a.H * a.Q * 25;
+    const double inv_s = 1.0 / ((double)a.B * a.H * 25);
+    for (long i = (long)blockIdx.x * 256 + tid; i < n_s; i += (long)gridDim.x * 256) {
+        const int p = (int)(i % 25);
+        const int qi = (int)((i / 25) % a.Q);
+        const long bh = i / (25L * a.Q);
+        const int h = (int)(bh % a.H);
+        const long b = bh / a.H;
+        const float tg = a.target[((size_t)b * a.T + (a.T - a.H + h)) * 25 + p];
+        const float e = tg - a.pred[i];
+        const float qq = a.q[qi];
+        const float lo = (qq - 1.0f) * e, hi = qq * e;
+        s0 += (double)a.qw[qi] * (double)fmaxf(lo, hi) * inv_s;
+        const float d = (e > 0.0f) ? -qq : ((e < 0.0f) ? (1.0f - qq) : (0.5f - qq));
+        a.d_pred[i] = (float)((double)a.qw[qi] * d * inv_s);
+    }
+    if (a.ex_pred) {
+        const long n_e = (long)a.B * a.H * a.X;
+        const double inv_e = 1.0 / ((double)a.B * a.H * a.ex_n);
+        for (long i = (long)blockIdx.x * 256 + tid; i < n_e; i += (long)gridDim.x * 256) {
+            const int f = (int)(i % a.X);
+            const long bh = i / a.X;
+            const int h = (int)(bh % a.H);
+            const long b = bh / a.H;
+            float g = 0.0f;
+            if (f < a.ex_n) {
+                const float d = a.ex_pred[i] - a.ex_target[((size_t)b * a.T + (a.T - a.H + h)) * a.X + f];
+                if (a.ex_l2) {
+                    s1 += (double)d * d * inv_e;
+                    g = (float)(2.0 * d * inv_e * a.ex_weight);
+                } else {
+                    s1 += (double)fabsf(d) * inv_e;
+                    g = (float)(((d > 0.0f) - (d < 0.0f)) * inv_e * a.ex_weight);
+                }
+            }
+            a.d_ex[i] = g;
+        }
+    }
+    const long n_z = (long)a.B * a.T * a.L;
+    const double inv_z = 1.0 / ((double)a.B * a.T);
+    for (long i = (long)blockIdx.x * 256 + tid; i < n_z; i += (long)gridDim.x * 256) {
+        const float mu = a.zm[i], lv = a.zl[i];
+        const float ev = expf(lv);
+        s2 += -0.5 * (1.0 + (double)lv - (double)ev - (double)mu * mu) * inv_z;
+        a.d_zm[i] = (float)((double)mu * inv_z * a.kl_weight);
+        a.d_zl[i] = (float)(-0.5 * (1.0 - (double)ev) * inv_z * a.kl_weight);
+    }
+    red[0][tid] = s0; red[1][tid] = s1; red[2][tid] = s2;
+    __syncthreads();
+    for (int k = 128; k > 0; k >>= 1) {
+        if (tid < k) { red[0][tid] += red[0][tid + k]; red[1][tid] += red[1][tid + k]; red[2][tid] += red[2][tid + k]; }
+        __syncthreads();
+    }
+    if (tid < 3) atomicAdd(&a.sums[tid], red[tid][0]);
 }
 
 // ---------------------------------------------------------------------------
@@ -730,19 +1019,21 @@ static int launch_dense_chain(const DenseChainArgs& a, hipStream_t st) {
     return launch_check("dense_chain_kernel");
 }
 
-template <int NT, int NL, int XMODE, bool HEAD>
+template <int NT, int NL, int XMODE, bool HEAD, bool SAVE = false>
 static int launch_lstm_t(const LstmSeqArgs& a, hipStream_t st) {
     const int slots = (XMODE == 0 ? 0 : a.kx) + NL * 4 * NT + (HEAD ? 2 * kDenseSlots : 0);
     const size_t lds = (size_t)slots * 64 * sizeof(float);
-    int rc = set_lds(lstm_kernel<NT, NL, XMODE, HEAD>, lds);
+    int rc = set_lds(lstm_kernel<NT, NL, XMODE, HEAD, SAVE>, lds);
     if (rc) return rc;
     if (a.n_rowtiles > 0x7fffffffL) { set_error("lstm_kernel: too many rows"); return -2; }
-    hipLaunchKernelGGL((lstm_kernel<NT, NL, XMODE, HEAD>), dim3((unsigned)a.n_rowtiles), dim3(256), lds, st, a);
+    hipLaunchKernelGGL((lstm_kernel<NT, NL, XMODE, HEAD, SAVE>), dim3((unsigned)a.n_rowtiles), dim3(256), lds, st, a);
     return launch_check("lstm_kernel");
 }
 
 template <int NT, int XMODE>
 static int launch_lstm_nt(const LstmSeqArgs& a, int NL, bool head, hipStream_t st) {
+    if (a.sv_gates)
+        return NL == 2 ? launch_lstm_t<NT, 2, XMODE, false, true>(a, st) : launch_lstm_t<NT, 1, XMODE, false, true>(a, st);
     if (XMODE == 1 && head)
         return NL == 2 ? launch_lstm_t<NT, 2, XMODE, (XMODE == 1)>(a, st) : launch_lstm_t<NT, 1, XMODE, (XMODE == 1)>(a, st);
     return NL == 2 ? launch_lstm_t<NT, 2, XMODE, false>(a, st) : launch_lstm_t<NT, 1, XMODE, false>(a, st);
@@ -955,4 +1246,145 @@ extern "C" int vsv_philox_normal(uint64_t seed, long day0, long n_days, long S, 
     hipLaunchKernelGGL(philox_normal_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream,
                        seed, day0, S, step0, n_steps, L, total, out);
     return launch_check("philox_normal_kernel");
+}
+
+// ---------------------------------------------------------------------------
+// training entry points
+// ---------------------------------------------------------------------------
+extern "C" int vsv_train_encode(const vsv_dims* dims, const float* packed, int which,
+                                const float* surf, long surf_row_stride, long surf_t_stride,
+                                const float* ex, long ex_row_stride, long ex_t_stride,
+                                long n_rows, int T, float* out, const vsv_train_save* sv, void* stream) {
+    VSV_LAYOUT_OR_FAIL("vsv_train_encode")
+    if (!packed || !surf || !out || !sv) { set_error("vsv_train_encode: null pointer"); return -1; }
+    if (!sv->emb_acts || !sv->xe || !sv->gates || !sv->c || !sv->h || !sv->hout) { set_error("vsv_train_encode: incomplete save set"); return -1; }
+    if (which < 0 || which > 1) { set_error("vsv_train_encode: which must be 0 or 1"); return -1; }
+    if (n_rows < 1 || T < 1) { set_error("vsv_train_encode: empty batch"); return -1; }
+    if (lay.X > 0 && !ex) { set_error("vsv_train_encode: ex_feats_dim > 0 but ex is null"); return -1; }
+    hipStream_t st = (hipStream_t)stream;
+    const EncLayout& e = lay.enc[which];
+    const long rt = (n_rows + 31) / 32;
+
+    DenseChainArgs a = {};
+    a.n_layers = e.n_conv;
+    for (int i = 0; i < e.n_conv; ++i) fill_dense(a, i, packed, e.conv[i]);
+    a.n_rows = n_rows; a.n_rowtiles = rt; a.T = T;
+    a.in_mode = 0; a.in = surf; a.in_rs = surf_row_stride; a.in_ts = surf_t_stride; a.in_f = 25;
+    a.in_ks = 4 * e.conv[0].nq;
+    if (lay.X > 0) { a.inj = ex; a.inj_rs = ex_row_stride; a.inj_ts = ex_t_stride; a.inj_f0 = e.ex_f0; a.inj_n = lay.X; }
+    a.out_mode = 0; a.out = sv->xe; a.out_f = e.E; a.S = 1;
+    a.aux_layer = -1;
+    a.save = sv->emb_acts;
+    int rc = launch_dense_chain(a, st);
+    if (rc) return rc;
+
+    LstmSeqArgs l = {};
+    for (int i = 0; i < lay.NL; ++i) { l.w[i] = packed + e.lstm[i].w_off; l.b[i] = packed + e.lstm[i].b_off; }
+    l.kx = e.kx; l.n_rows = n_rows; l.n_rowtiles = rt; l.T = T;
+    l.x_tileb = sv->xe; l.L = lay.L;
+    l.hout = sv->hout; l.t_out0 = 0;
+    l.sv_gates = sv->gates; l.sv_c = sv->c; l.sv_h = sv->h;
+    rc = launch_lstm<0>(l, lay.NTm, lay.NL, false, st);
+    if (rc) return rc;
+
+    DenseChainArgs h = {};
+    h.n_layers = 1;
+    fill_dense(h, 0, packed, e.head);
+    h.n_rows = n_rows; h.n_rowtiles = rt; h.T = T;
+    h.in_mode = 1; h.in = sv->hout; h.in_ks = 4 * lay.NTm;
+    h.out_mode = 1; h.out = out; h.out_f = e.nh; h.S = 1;
+    h.aux_layer = -1;
+    return launch_dense_chain(h, st);
+}
+
+extern "C" int vsv_train_decode(const vsv_dims* dims, const float* packed, const vsv_decode_in* in,
+                                long n_rows, int T, int t_out0, float* z_out, float* surf_out, float* ex_out,
+                                const vsv_train_save* sv, void* stream) {
+    VSV_LAYOUT_OR_FAIL("vsv_train_decode")
+    if (!packed || !in || !sv || !surf_out) { set_error("vsv_train_decode: null pointer"); return -1; }
+    if (!sv->xe || !sv->gates || !sv->c || !sv->h || !sv->hout || !sv->head_acts) { set_error("vsv_train_decode: incomplete save set"); return -1; }
+    if (n_rows < 1 || T < 1 || t_out0 < 0 || t_out0 >= T) { set_error("vsv_train_decode: bad sizes"); return -1; }
+    if (in->ctx_T > 0 && (!in->ctx || in->ctx_div < 1)) { set_error("vsv_train_decode: ctx missing"); return -1; }
+    if (in->z_T > 0 && (!in->zb || in->z_div < 1)) { set_error("vsv_train_decode: zb missing"); return -1; }
+    if (in->ctx_T > T || in->z_T > T) { set_error("vsv_train_decode: ctx_T/z_T exceed T"); return -1; }
+    if (in->state_in || in->gate_in || in->gate_out) { set_error("vsv_train_decode: training starts from the zero state"); return -1; }
+    hipStream_t st = (hipStream_t)stream;
+    const DecLayout& dc = lay.dec;
+    const long rt = (n_rows + 31) / 32;
+    const int touts = T - t_out0;
+
+    LstmSeqArgs l = {};
+    for (int i = 0; i < lay.NL; ++i) { l.w[i] = packed + dc.lstm[i].w_off; l.b[i] = packed + dc.lstm[i].b_off; }
+    l.kx = dc.kx; l.n_rows = n_rows; l.n_rowtiles = rt; l.T = T;
+    l.L = lay.L; l.din = *in; l.z_out = z_out;
+    if (l.din.ctx_div < 1) l.din.ctx_div = 1;
+    if (l.din.z_div < 1) l.din.z_div = 1;
+    if (l.din.S < 1) l.din.S = 1;
+    l.din.state_div = 1;
+    l.hout = sv->hout; l.t_out0 = t_out0;
+    l.sv_gates = sv->gates; l.sv_c = sv->c; l.sv_h = sv->h; l.sv_x = sv->xe;
+    int rc = launch_lstm<1>(l, lay.NTd, lay.NL, false, st);
+    if (rc) return rc;
+
+    DenseChainArgs a = {};
+    a.n_layers = dc.n_head;
+    for (int i = 0; i < dc.n_head; ++i) fill_dense(a, i, packed, dc.head[i]);
+    a.n_rows = n_rows; a.n_rowtiles = rt; a.T = touts;
+    a.in_mode = 1; a.in = sv->hout; a.in_ks = 4 * lay.NTd;
+    a.out_mode = 1; a.out = surf_out; a.out_f = dc.n_surf; a.S = 1;
+    a.aux_layer = (lay.X > 0 && ex_out) ? dc.ex_layer : -1;
+    a.aux = ex_out; a.aux_f0 = dc.ex_f0; a.aux_n = lay.X;
+    a.save = sv->head_acts;
+    return launch_dense_chain(a, st);
+}
+
+extern "C" int vsv_dense_backward(const vsv_dense_bwd* d, void* stream) {
+    if (!d || !d->in) { set_error("vsv_dense_backward: null pointer"); return -1; }
+    if (d->n_layers < 1 || d->n_layers > VSV_MAX_CHAIN) { set_error("vsv_dense_backward: 1..%d layers", VSV_MAX_CHAIN); return -1; }
+    if (d->n_rows < 1 || d->T < 1 || d->n_rowtiles != (d->n_rows + 31) / 32) { set_error("vsv_dense_backward: bad sizes"); return -1; }
+    for (int i = 0; i < d->n_layers; ++i) {
+        const vsv_dense_bwd_layer& ly = d->layer[i];
+        if (ly.ntT < 0 || ly.ntT > kHeadTiles || (ly.ntT > 0 && (!ly.wT || ly.nqT < 1 || ly.nqT > 4 * kHeadTiles))) {
+            set_error("vsv_dense_backward: layer %d has an unsupported shape", i); return -1;
+        }
+    }
+    const long insts = d->n_rowtiles * d->T;
+    const long blocks = (insts + 3) / 4;
+    if (blocks > 0x7fffffffL) { set_error("vsv_dense_backward: too many tiles"); return -2; }
+    const size_t lds = (size_t)4 * kDenseSlots * 64 * sizeof(float);
+    hipLaunchKernelGGL(dense_bwd_kernel, dim3((unsigned)blocks), dim3(256), lds, (hipStream_t)stream, *d);
+    return launch_check("dense_bwd_kernel");
+}
+
+template <int NT, int NL>
+static int launch_lstm_bwd(const vsv_lstm_bwd& a, hipStream_t st) {
+    const size_t lds = (size_t)NL * 16 * NT * 64 * sizeof(float);
+    int rc = set_lds(lstm_bwd_kernel<NT, NL>, lds);
+    if (rc) return rc;
+    hipLaunchKernelGGL((lstm_bwd_kernel<NT, NL>), dim3((unsigned)a.n_rowtiles), dim3(256), lds, st, a);
+    return launch_check("lstm_bwd_kernel");
+}
+
+extern "C" int vsv_lstm_backward(const vsv_lstm_bwd* d, int hidden, int layers, void* stream) {
+    if (!d || !d->sv_gates || !d->sv_c || !d->dgates || !d->wT_hh[0]) { set_error("vsv_lstm_backward: null pointer"); return -1; }
+    if (d->n_rows < 1 || d->T < 1 || d->t_out0 < 0 || d->t_out0 > d->T || d->n_rowtiles != (d->n_rows + 31) / 32 ||
+        d->n_rowtiles > 0x7fffffffL) { set_error("vsv_lstm_backward: bad sizes"); return -1; }
+    if (d->nt_x < 0 || d->nt_x > 4 || (d->nt_x > 0 && !d->wT_in[0])) { set_error("vsv_lstm_backward: bad nt_x"); return -1; }
+    if (layers == 2 && (!d->wT_hh[1] || !d->wT_in[1])) { set_error("vsv_lstm_backward: layer 1 weights missing"); return -1; }
+    const int NT = (hidden + 7) / 8;
+    hipStream_t st = (hipStream_t)stream;
+    if (NT == 13) return layers == 2 ? launch_lstm_bwd<13, 2>(*d, st) : launch_lstm_bwd<13, 1>(*d, st);
+    if (NT == 16) return layers == 2 ? launch_lstm_bwd<16, 2>(*d, st) : launch_lstm_bwd<16, 1>(*d, st);
+    set_error("vsv_lstm_backward: unsupported hidden size %d", hidden);
+    return -4;
+}
+
+extern "C" int vsv_loss_grad(const vsv_loss* d, void* stream) {
+    if (!d || !d->pred || !d->target || !d->zm || !d->zl || !d->d_pred || !d->d_zm || !d->d_zl || !d->sums) {
+        set_error("vsv_loss_grad: null pointer"); return -1;
+    }
+    if (d->B < 1 || d->H < 1 || d->T < d->H || d->Q < 1 || d->Q > 8 || d->L < 1) { set_error("vsv_loss_grad: bad sizes"); return -1; }
+    if (d->ex_pred && (!d->ex_target || !d->d_ex || d->X < 1 || d->ex_n < 1 || d->ex_n > d->X)) { set_error("vsv_loss_grad: bad ex arguments"); return -1; }
+    hipLaunchKernelGGL(loss_grad_kernel, dim3(64), dim3(256), 0, (hipStream_t)stream, *d);
+    return launch_check("loss_grad_kernel");
 }

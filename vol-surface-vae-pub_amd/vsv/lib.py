@@ -60,6 +60,45 @@ class VsvDecodeIn(C.Structure):
     ]
 
 
+VSV_MAX_CHAIN = 6
+
+
+class VsvTrainSave(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in ("emb_acts", "xe", "gates", "c", "h", "hout", "head_acts")]
+
+
+class VsvDenseBwdLayer(C.Structure):
+    _fields_ = [("wT", C.c_void_p), ("nqT", C.c_int), ("ntT", C.c_int),
+                ("act_out", C.c_void_p), ("n_relu", C.c_int),
+                ("g_out", C.c_void_p),
+                ("add", C.c_void_p), ("add_f0", C.c_int), ("add_n", C.c_int)]
+
+
+class VsvDenseBwd(C.Structure):
+    _fields_ = [("n_layers", C.c_int), ("layer", VsvDenseBwdLayer * VSV_MAX_CHAIN),
+                ("n_rows", C.c_long), ("n_rowtiles", C.c_long), ("T", C.c_int), ("in_mode", C.c_int),
+                ("in_", C.c_void_p), ("in_f", C.c_int), ("dx_out", C.c_void_p)]
+
+
+class VsvLstmBwd(C.Structure):
+    _fields_ = [("wT_hh", C.c_void_p * 2), ("wT_in", C.c_void_p * 2), ("nt_x", C.c_int),
+                ("n_rows", C.c_long), ("n_rowtiles", C.c_long), ("T", C.c_int), ("t_out0", C.c_int),
+                ("sv_gates", C.c_void_p), ("sv_c", C.c_void_p), ("dh_top", C.c_void_p),
+                ("dgates", C.c_void_p), ("dx_tile", C.c_void_p), ("dx_rows", C.c_void_p), ("dx_f", C.c_int)]
+
+
+class VsvLoss(C.Structure):
+    _fields_ = [("pred", C.c_void_p), ("target", C.c_void_p),
+                ("B", C.c_int), ("H", C.c_int), ("T", C.c_int), ("Q", C.c_int),
+                ("q", C.c_float * 8), ("qw", C.c_float * 8),
+                ("ex_pred", C.c_void_p), ("ex_target", C.c_void_p),
+                ("X", C.c_int), ("ex_n", C.c_int), ("ex_l2", C.c_int),
+                ("ex_weight", C.c_float), ("kl_weight", C.c_float),
+                ("zm", C.c_void_p), ("zl", C.c_void_p), ("L", C.c_int),
+                ("d_pred", C.c_void_p), ("d_ex", C.c_void_p), ("d_zm", C.c_void_p), ("d_zl", C.c_void_p),
+                ("sums", C.c_void_p)]
+
+
 # name -> (restype, argtypes); the full list of symbols include/vsv_hip.h declares
 SIGNATURES = {
     "vsv_abi_version": (C.c_int, []),
@@ -79,6 +118,15 @@ SIGNATURES = {
     "vsv_percentile": (C.c_int, [C.c_void_p, C.c_long, C.c_int, C.POINTER(C.c_double), C.c_int,
                                  C.c_int, C.c_void_p, C.c_void_p]),
     "vsv_profile_next_decode": (None, [C.c_void_p, C.c_void_p]),
+    "vsv_train_encode": (C.c_int, [C.POINTER(VsvDims), C.c_void_p, C.c_int,
+                                   C.c_void_p, C.c_long, C.c_long, C.c_void_p, C.c_long, C.c_long,
+                                   C.c_long, C.c_int, C.c_void_p, C.POINTER(VsvTrainSave), C.c_void_p]),
+    "vsv_train_decode": (C.c_int, [C.POINTER(VsvDims), C.c_void_p, C.POINTER(VsvDecodeIn),
+                                   C.c_long, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
+                                   C.POINTER(VsvTrainSave), C.c_void_p]),
+    "vsv_dense_backward": (C.c_int, [C.POINTER(VsvDenseBwd), C.c_void_p]),
+    "vsv_lstm_backward": (C.c_int, [C.POINTER(VsvLstmBwd), C.c_int, C.c_int, C.c_void_p]),
+    "vsv_loss_grad": (C.c_int, [C.POINTER(VsvLoss), C.c_void_p]),
     "vsv_debug_layout": (C.c_int, [C.POINTER(VsvDims), C.POINTER(C.c_longlong), C.c_int]),
     "vsv_philox_normal": (C.c_int, [C.c_uint64, C.c_long, C.c_long, C.c_long, C.c_int, C.c_int,
                                     C.c_int, C.c_void_p, C.c_void_p]),
@@ -106,7 +154,7 @@ def load() -> C.CDLL:
             fn = getattr(lib, name)
             fn.restype = res
             fn.argtypes = args
-        if lib.vsv_abi_version() != 2:
+        if lib.vsv_abi_version() != 3:
             raise RuntimeError("libvsv_hip.so ABI version mismatch")
         _lib = lib
     return _lib

@@ -1,0 +1,399 @@
+"""Training on the HIP path: forward with saved activations, loss terms and
+gradients, BPTT, and the assembly of parameter gradients.
+
+Division of labour (DESIGN.md "Training"): the recurrent and element-wise work
+-- LSTM forward/backward through time, conv/linear chains forward/backward,
+losses -- runs in the hand-written kernels behind the C ABI
+(vsv_train_encode / vsv_train_decode / vsv_loss_grad / vsv_dense_backward /
+vsv_lstm_backward).  What is left are plain matrix products dW = G^T . X over
+tensors those kernels leave in HBM; they run as library GEMMs (torch.matmul ->
+rocBLAS) and are scattered onto the parameters through the same index maps that
+define the weight packing, so Toeplitz-expanded conv weights, interleaved LSTM
+gates and summed biases all come out as gradients of the original parameters.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Dict, List, Optional
+
+import numpy as np
+import torch
+
+from . import lib as _lib
+from .engine import Engine, build_gather_maps
+
+
+class _Sec:
+    def __init__(self, rec):
+        self.w_off, self.b_off, self.nq, self.nt, self.n_relu, self.n_out = [int(x) for x in rec]
+
+
+def read_layout(dims) -> dict:
+    """Blob geometry from vsv_debug_layout."""
+    L = _lib.load()
+    n = L.vsv_debug_layout(C.byref(dims), None, 0)
+    buf = (C.c_longlong * n)()
+    assert L.vsv_debug_layout(C.byref(dims), buf, n) == n
+    v = np.array(buf[:], dtype=np.int64)
+    recs = v[: 6 * 22].reshape(22, 6)
+    lay = {"enc": []}
+    for w in range(2):
+        base = w * 7
+        lay["enc"].append(dict(conv=[_Sec(recs[base + i]) for i in range(4)],
+                               lstm=[_Sec(recs[base + 4]), _Sec(recs[base + 5])], head=_Sec(recs[base + 6])))
+    lay["dec"] = dict(lstm=[_Sec(recs[14]), _Sec(recs[15])], head=[_Sec(recs[16 + i]) for i in range(6)])
+    sc = [int(x) for x in v[6 * 22:]]
+    (lay["enc"][0]["kx"], lay["enc"][1]["kx"], lay["enc"][0]["nh"], lay["enc"][1]["nh"], lay["E"], lay["ex_f0"],
+     lay["dec"]["kx"], lay["dec"]["n_head"], lay["dec"]["ex_layer"], lay["dec"]["ex_f0"],
+     lay["NTm"], lay["NTd"], lay["Hd"]) = sc
+    return lay
+
+
+# ---- index arithmetic of the fragment layout (vsv_layout.h) -------------------------------------
+
+def _slot_feature(s, hh):
+    """feature (row of a tile-ordered matrix) held at slot s, lane half hh (SLOT order)."""
+    return 32 * (s >> 4) + 8 * ((s >> 2) & 3) + 4 * hh + (s & 3)
+
+
+def _wpos(sec: _Sec, n, k):
+    """Position in the forward blob of W[n][k]: n = 32*tile + row, k = 2*kstep + half."""
+    return sec.w_off + (((k >> 3) * sec.nt + (n >> 5)) * 64 + ((k & 1) * 32 + (n & 31))) * 4 + ((k >> 1) & 3)
+
+
+def _bpos(sec: _Sec, n):
+    t, i = n >> 5, n & 31
+    return sec.b_off + (t * 2 + ((i >> 2) & 1)) * 16 + 4 * (i >> 3) + (i & 3)
+
+
+def transposed_map(sec: _Sec, ks0: int, nks: int, kind: str, ntT: int) -> np.ndarray:
+    """Forward-blob positions (or -1) of the transposed fragments of `sec` restricted to
+    its k-steps [ks0, ks0+nks): K' = all 16*nt forward output k-steps (slot order), output
+    tile t', row i' -> forward input feature
+      'slot': the feature at slot 16t' + 4(i'>>3) + (i'&3), half (i'>>2)&1   (previous layer's slot order)
+      'unit': hidden unit 8*(4*(i'>>3) + t') + 2*(i'&3) + ((i'>>2)&1)          (LSTM backward's unit tiles)
+      'nat' : feature 32t' + i'."""
+    nqT = 4 * sec.nt
+    q, t, l, j = np.meshgrid(np.arange(nqT), np.arange(ntT), np.arange(64), np.arange(4), indexing="ij")
+    s = 4 * q + j
+    hh, i = l >> 5, l & 31
+    n = _slot_feature(s, hh)
+    if kind == "slot":
+        kloc = 2 * (16 * t + 4 * (i >> 3) + (i & 3)) + ((i >> 2) & 1)
+    elif kind == "unit":
+        kloc = 8 * (4 * (i >> 3) + t) + 2 * (i & 3) + ((i >> 2) & 1)
+    else:
+        kloc = 32 * t + i
+    ok = kloc < 2 * nks
+    k = 2 * ks0 + np.where(ok, kloc, 0)
+    pos = _wpos(sec, n, k)
+    return np.where(ok, pos, -1).reshape(-1).astype(np.int64)
+
+
+class _BwdBlob:
+    """Transposed fragments of every layer, gathered on device from the forward blob."""
+
+    def __init__(self):
+        self.maps: List[np.ndarray] = []
+        self.off: Dict[str, tuple] = {}
+        self.cur = 0
+
+    def add(self, name, sec, ks0, nks, kind, ntT):
+        m = transposed_map(sec, ks0, nks, kind, ntT)
+        self.off[name] = (self.cur, 4 * sec.nt, ntT)
+        self.maps.append(m)
+        self.cur += m.size
+
+    def index(self):
+        return np.concatenate(self.maps)
+
+
+def _ptr(t: Optional[torch.Tensor]):
+    return None if t is None else t.data_ptr()
+
+
+class TrainEngine:
+    """Forward + backward of the train_step loss for one model on one GPU."""
+
+    def __init__(self, eng: Engine, named_shapes):
+        self.eng = eng
+        self.lib = eng.lib
+        self.dev = eng.device
+        self.dims = eng.dims
+        self.lay = lay = read_layout(eng.dims)
+        self.NL = eng.dims.mem_layers
+        self.n_conv = [eng.dims.n_conv, eng.dims.n_ctx_conv]
+        self.L, self.X, self.Q = eng.L, eng.X, eng.Q
+        self.Hm = eng.dims.mem_hidden
+        NTm, NTd = lay["NTm"], lay["NTd"]
+        # ---- backward blob
+        bb = _BwdBlob()
+        for w in range(2):
+            e = lay["enc"][w]
+            for li in range(1, self.n_conv[w]):
+                bb.add(f"e{w}.conv{li}", e["conv"][li], 0, 4 * e["conv"][li].nq, "slot", e["conv"][li - 1].nt)
+            kx = e["kx"]
+            bb.add(f"e{w}.in0", e["lstm"][0], 0, kx, "slot", kx // 16)
+            bb.add(f"e{w}.hh0", e["lstm"][0], kx, 4 * NTm, "unit", 4)
+            if self.NL == 2:
+                bb.add(f"e{w}.in1", e["lstm"][1], 0, 4 * NTm, "unit", 4)
+                bb.add(f"e{w}.hh1", e["lstm"][1], 4 * NTm, 4 * NTm, "unit", 4)
+            bb.add(f"e{w}.head", e["head"], 0, 4 * NTm, "unit", 4)
+        d = lay["dec"]
+        bb.add("d.in0", d["lstm"][0], 0, d["kx"], "nat", 1)
+        bb.add("d.hh0", d["lstm"][0], d["kx"], 4 * NTd, "unit", 4)
+        if self.NL == 2:
+            bb.add("d.in1", d["lstm"][1], 0, 4 * NTd, "unit", 4)
+            bb.add("d.hh1", d["lstm"][1], 4 * NTd, 4 * NTd, "unit", 4)
+        bb.add("d.head0", d["head"][0], 0, 4 * NTd, "unit", 4)
+        for li in range(1, d["n_head"]):
+            bb.add(f"d.head{li}", d["head"][li], 0, 4 * d["head"][li].nq, "slot", 4)
+        self.bb = bb
+        idx = bb.index()
+        self._bwd_idx = torch.from_numpy(np.where(idx < 0, 0, idx + 1)).to(self.dev)      # 0 -> the zero slot
+        # ---- parameter scatter maps (same maps as the device-side packing)
+        ia, ib = build_gather_maps(self.dims, list(named_shapes))
+        self._idx_a = torch.from_numpy(ia).to(self.dev)
+        self._idx_b = torch.from_numpy(ib).to(self.dev)
+        self._sizes = [int(np.prod(s)) for _, s in named_shapes]
+        self._shapes = [tuple(s) for _, s in named_shapes]
+        self._pos_cache: Dict[tuple, tuple] = {}
+
+    # -- helpers -----------------------------------------------------------------------
+    def _stream(self):
+        return C.c_void_p(torch.cuda.current_stream(self.dev).cuda_stream)
+
+    def _z(self, *shape):
+        return torch.zeros(shape, dtype=torch.float32, device=self.dev)
+
+    def _e(self, *shape):
+        return torch.empty(shape, dtype=torch.float32, device=self.dev)
+
+    def _wT(self, blobT, name):
+        off, nq, nt = self.bb.off[name]
+        return blobT.data_ptr() + 4 * off, nq, nt
+
+    def _wmap(self, sec: _Sec, n_out_slots: int, k_steps: int):
+        """(rows a = 2*slot+half of G, cols b = 2*kstep+half of X) -> blob positions; bias positions."""
+        key = (sec.w_off, n_out_slots, k_steps)
+        if key not in self._pos_cache:
+            a = np.arange(2 * n_out_slots)
+            n = _slot_feature(a >> 1, a & 1)
+            k = np.arange(2 * k_steps)
+            pos = _wpos(sec, n[:, None], k[None, :])
+            self._pos_cache[key] = (torch.from_numpy(pos.reshape(-1).astype(np.int64)).to(self.dev),
+                                    torch.from_numpy(_bpos(sec, n).astype(np.int64)).to(self.dev))
+        return self._pos_cache[key]
+
+    @staticmethod
+    def _mat(t: torch.Tensor) -> torch.Tensor:
+        """tile-B (NI, slots, 64) -> (2*slots, NI*32): row a = 2*slot + half."""
+        ni, ns, _ = t.shape
+        return t.reshape(ni, ns, 2, 32).permute(1, 2, 0, 3).reshape(2 * ns, ni * 32)
+
+    def _acc_layer(self, gp, sec, G, X, bias=True):
+        """gp[blob positions] += G^T . X (and the bias row sums).  G (NI, so, 64) slot order,
+        X (NI, ks, 64) in the layer's k order."""
+        Gm, Xm = self._mat(G), self._mat(X)
+        pos, bpos = self._wmap(sec, G.shape[1], X.shape[1])
+        gp.index_add_(0, pos, (Gm @ Xm.t()).reshape(-1))
+        if bias:
+            gp.index_add_(0, bpos, Gm.sum(dim=1))
+
+    # -- one forward/backward ----------------------------------------------------------
+    def loss_and_grads(self, surf: torch.Tensor, ex: Optional[torch.Tensor], horizon: int, loss_cfg: dict,
+                       eps: Optional[torch.Tensor] = None, seed: int = 0, want_grads: bool = True):
+        """surf (B,T,5,5) [, ex (B,T,X)] -> (losses dict of 0-d float64 tensors, gradient of
+        `loss` w.r.t. the PACKED blob or None).  loss_cfg: quantiles, quantile_weights, ex_n,
+        ex_l2, ex_weight, kl_weight."""
+        eng, lib, lay = self.eng, self.lib, self.lay
+        dev = self.dev
+        L, X, Q, NL = self.L, self.X, self.Q, self.NL
+        NTm, NTd = lay["NTm"], lay["NTd"]
+        surf = surf.to(dev, torch.float32).contiguous()
+        B, T = surf.shape[:2]
+        Cn = T - horizon
+        if X > 0:
+            ex = ex.to(dev, torch.float32).contiguous()
+        rt = (B + 31) // 32
+        st = self._stream()
+        packed = eng.packed
+
+        def run_encoder(which, Tw):
+            e = lay["enc"][which]
+            NI = rt * Tw
+            sv = dict(emb_acts=self._e(self.n_conv[which], NI, 64, 64), xe=self._e(NI, e["kx"], 64),
+                      gates=self._e(NI, NL, 16 * NTm, 64), c=self._e(NI, NL, 4 * NTm, 64),
+                      h=self._e(NI, NL, 4 * NTm, 64), hout=self._e(NI, 4 * NTm, 64))
+            out = self._e(B, Tw, e["nh"])
+            s = _lib.VsvTrainSave()
+            for k, v in sv.items():
+                setattr(s, k, v.data_ptr())
+            rc = lib.vsv_train_encode(C.byref(self.dims), packed.data_ptr(), which,
+                                      surf.data_ptr(), T * 25, 25, _ptr(ex), T * X, X,
+                                      B, Tw, out.data_ptr(), C.byref(s), st)
+            _lib.check(rc, "vsv_train_encode")
+            return out, sv
+
+        with torch.cuda.device(dev):
+            enc_out, sv_e = run_encoder(0, T)
+            ctx_out, sv_c = run_encoder(1, Cn)
+            zm, zl = enc_out[..., :L].contiguous(), enc_out[..., L:].contiguous()
+            # ---- decoder
+            NI, NIo = rt * T, rt * horizon
+            d = lay["dec"]
+            sv_d = dict(xe=self._e(NI, d["kx"], 64), gates=self._e(NI, NL, 16 * NTd, 64),
+                        c=self._e(NI, NL, 4 * NTd, 64), h=self._e(NI, NL, 4 * NTd, 64),
+                        hout=self._e(NIo, 4 * NTd, 64), head_acts=self._e(d["n_head"], NIo, 64, 64))
+            s = _lib.VsvTrainSave()
+            for k, v in sv_d.items():
+                setattr(s, k, v.data_ptr())
+            din = _lib.VsvDecodeIn()
+            din.ctx, din.ctx_rs, din.ctx_T, din.ctx_div = ctx_out.data_ptr(), Cn * L, Cn, 1
+            din.zb, din.lv, din.z_rs, din.z_T, din.z_div = zm.data_ptr(), zl.data_ptr(), T * L, T, 1
+            din.mu0, din.std0 = 0.0, 1.0
+            if eps is not None:
+                eps = eps.to(dev, torch.float32).contiguous()
+                assert eps.shape == (B, T, L)
+                din.eps_in, din.eps_T = eps.data_ptr(), T
+            din.eps_t0, din.seed, din.S, din.day0, din.step0, din.state_div = 0, seed & (2 ** 64 - 1), 1, 0, 0, 1
+            z = self._e(B, T, L)
+            s_out = self._e(B, horizon, Q, 5, 5)
+            e_out = self._e(B, horizon, X) if X > 0 else None
+            rc = lib.vsv_train_decode(C.byref(self.dims), packed.data_ptr(), C.byref(din), B, T, Cn,
+                                      z.data_ptr(), s_out.data_ptr(), _ptr(e_out), C.byref(s), st)
+            _lib.check(rc, "vsv_train_decode")
+            # ---- losses + output gradients
+            la = _lib.VsvLoss()
+            la.pred, la.target = s_out.data_ptr(), surf.data_ptr()
+            la.B, la.H, la.T, la.Q = B, horizon, T, Q
+            qw = np.asarray(loss_cfg["quantile_weights"], dtype=np.float64)
+            for i in range(Q):
+                la.q[i] = float(loss_cfg["quantiles"][i])
+                la.qw[i] = float(qw[i] / qw.sum())
+            d_pred, d_zm, d_zl = self._e(B, horizon, Q * 25), self._e(B, T, L), self._e(B, T, L)
+            d_ex = None
+            if X > 0:
+                d_ex = self._e(B, horizon, X)
+                la.ex_pred, la.ex_target, la.d_ex = e_out.data_ptr(), ex.data_ptr(), d_ex.data_ptr()
+                la.X, la.ex_n, la.ex_l2 = X, int(loss_cfg["ex_n"]), int(loss_cfg["ex_l2"])
+            la.ex_weight, la.kl_weight = float(loss_cfg["ex_weight"]), float(loss_cfg["kl_weight"])
+            la.zm, la.zl, la.L = zm.data_ptr(), zl.data_ptr(), L
+            la.d_pred, la.d_zm, la.d_zl = d_pred.data_ptr(), d_zm.data_ptr(), d_zl.data_ptr()
+            sums = torch.zeros(3, dtype=torch.float64, device=dev)
+            la.sums = sums.data_ptr()
+            _lib.check(lib.vsv_loss_grad(C.byref(la), st), "vsv_loss_grad")
+            re_s, re_e, kl = sums[0], sums[1], sums[2]
+            recon = re_s + loss_cfg["ex_weight"] * re_e if X > 0 else re_s
+            losses = {"loss": recon + loss_cfg["kl_weight"] * kl, "re_surface": re_s, "re_ex_feats": re_e,
+                      "reconstruction_loss": recon, "kl_loss": kl}
+            outputs = {"surf": s_out, "ex": e_out, "z_mean": zm, "z_log_var": zl, "z": z}
+            if not want_grads:
+                return losses, None, outputs
+
+            # ---- backward
+            ext = torch.cat([self._z(1), packed])
+            blobT = ext[self._bwd_idx]
+            gp = torch.zeros(packed.numel(), dtype=torch.float32, device=dev)
+
+            def dense_bwd(layers, n_inst_T, in_mode, in_t, in_f, want_dx):
+                a = _lib.VsvDenseBwd()
+                a.n_layers = len(layers)
+                for i, ly in enumerate(layers):
+                    for k, v in ly.items():
+                        setattr(a.layer[i], k, v)
+                a.n_rows, a.n_rowtiles, a.T = B, rt, n_inst_T
+                a.in_mode, a.in_, a.in_f = in_mode, in_t.data_ptr(), in_f
+                dx = self._e(rt * n_inst_T, 64, 64) if want_dx else None
+                a.dx_out = _ptr(dx)
+                _lib.check(lib.vsv_dense_backward(C.byref(a), st), "vsv_dense_backward")
+                return dx
+
+            def lstm_bwd(prefix, hidden, NT, sv, Tw, t_out0, dh_top, nt_x, dx_tile=None, dx_rows=None, dx_f=0):
+                a = _lib.VsvLstmBwd()
+                for l in range(NL):
+                    a.wT_hh[l] = self._wT(blobT, f"{prefix}.hh{l}")[0]
+                    a.wT_in[l] = self._wT(blobT, f"{prefix}.in{l}")[0]
+                a.nt_x, a.n_rows, a.n_rowtiles, a.T, a.t_out0 = nt_x, B, rt, Tw, t_out0
+                a.sv_gates, a.sv_c, a.dh_top = sv["gates"].data_ptr(), sv["c"].data_ptr(), dh_top.data_ptr()
+                dg = self._e(rt * Tw, NL, 16 * NT, 64)
+                a.dgates, a.dx_tile, a.dx_rows, a.dx_f = dg.data_ptr(), _ptr(dx_tile), _ptr(dx_rows), dx_f
+                _lib.check(lib.vsv_lstm_backward(C.byref(a), hidden, NL, st), "vsv_lstm_backward")
+                return dg
+
+            def lstm_wgrads(secs, sv, dg, Tw, NT, x_tile):
+                """dW of the LSTM layers: X = [x | h_prev] (layer 0), [h0 | h1_prev] (layer 1)."""
+                h = sv["h"].view(rt, Tw, NL, 4 * NT, 64)
+                hprev = torch.cat([torch.zeros_like(h[:, :1]), h[:, :-1]], dim=1).reshape(rt * Tw, NL, 4 * NT, 64)
+                for l in range(NL):
+                    xin = x_tile if l == 0 else sv["h"][:, l - 1]
+                    Xl = torch.cat([xin, hprev[:, l]], dim=1)
+                    self._acc_layer(gp, secs[l], dg[:, l], Xl)
+
+            # decoder head
+            hd = d["head"][: d["n_head"]]
+            layers, gs = [], []
+            for li in range(d["n_head"] - 1, -1, -1):
+                g = self._e(NIo, 64, 64)
+                gs.append((li, g))
+                w, nq, nt = self._wT(blobT, f"d.head{li}")
+                ly = dict(wT=w, nqT=nq, ntT=nt, n_relu=hd[li].n_relu, g_out=g.data_ptr())
+                if li < d["n_head"] - 1 and hd[li].n_relu > 0:
+                    ly["act_out"] = sv_d["head_acts"][li + 1].data_ptr()
+                if X > 0 and li == d["ex_layer"]:
+                    ly["add"], ly["add_f0"], ly["add_n"] = d_ex.data_ptr(), d["ex_f0"], X
+                layers.append(ly)
+            dh_top = dense_bwd(layers, horizon, 0, d_pred, Q * 25, True)
+            for li, g in gs:
+                self._acc_layer(gp, hd[li], g[:, : 16 * hd[li].nt], sv_d["head_acts"][li][:, : 4 * hd[li].nq])
+            # decoder LSTM
+            dx = self._e(B, T, 2 * L)
+            dg = lstm_bwd("d", lay["Hd"], NTd, sv_d, T, Cn, dh_top, 1, dx_rows=dx, dx_f=2 * L)
+            lstm_wgrads(d["lstm"], sv_d, dg, T, NTd, sv_d["xe"])
+            # reparameterisation (:199) and the context embedding
+            dz = dx[..., L:]
+            dzm_t = dz + d_zm
+            dzl_t = dz * 0.5 * (z - zm) + d_zl
+            d_ctx = dx[:, :Cn, :L].contiguous()
+
+            def encoder_bwd(which, sv, Tw, d_out):
+                e = lay["enc"][which]
+                pf = f"e{which}"
+                gh = self._e(rt * Tw, 64, 64)
+                w, nq, nt = self._wT(blobT, f"{pf}.head")
+                dh = dense_bwd([dict(wT=w, nqT=nq, ntT=nt, n_relu=0, g_out=gh.data_ptr())], Tw, 0, d_out,
+                               d_out.shape[-1], True)
+                self._acc_layer(gp, e["head"], gh[:, : 16 * e["head"].nt], sv["hout"])
+                dxt = self._e(rt * Tw, 64, 64)
+                dgl = lstm_bwd(pf, self.Hm, NTm, sv, Tw, 0, dh, e["kx"] // 16, dx_tile=dxt)
+                lstm_wgrads(e["lstm"], sv, dgl, Tw, NTm, sv["xe"])
+                nc = self.n_conv[which]
+                layers, gs = [], []
+                for li in range(nc - 1, -1, -1):
+                    g = self._e(rt * Tw, 64, 64)
+                    gs.append((li, g))
+                    ly = dict(ntT=0, nqT=0, n_relu=e["conv"][li].n_relu, g_out=g.data_ptr(),
+                              act_out=(sv["xe"] if li == nc - 1 else sv["emb_acts"][li + 1]).data_ptr())
+                    if li > 0:
+                        ly["wT"], ly["nqT"], ly["ntT"] = self._wT(blobT, f"{pf}.conv{li}")
+                    layers.append(ly)
+                dense_bwd(layers, Tw, 1, dxt, 0, False)
+                for li, g in gs:
+                    cs = e["conv"][li]
+                    self._acc_layer(gp, cs, g[:, : 16 * cs.nt], sv["emb_acts"][li][:, : 4 * cs.nq])
+
+            encoder_bwd(0, sv_e, T, torch.cat([dzm_t, dzl_t], dim=-1).contiguous())
+            encoder_bwd(1, sv_c, Cn, d_ctx)
+        return losses, gp, outputs
+
+    def param_grads(self, gp: torch.Tensor) -> List[torch.Tensor]:
+        """gradient w.r.t. the packed blob -> gradients of the parameters (spec order)."""
+        n = sum(self._sizes)
+        flat = torch.zeros(n + 1, dtype=torch.float32, device=self.dev)
+        flat.index_add_(0, self._idx_a, gp)
+        flat.index_add_(0, self._idx_b, gp)
+        out, o = [], 1
+        for sz, sh in zip(self._sizes, self._shapes):
+            out.append(flat[o:o + sz].view(sh))
+            o += sz
+        return out

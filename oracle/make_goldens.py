@@ -346,7 +346,29 @@ def main():
     main_training()
 
 
+def case_sampler():
+    """G10: the reference's CustomBatchSampler / VolSurfaceDataSetRand with random.seed(0)."""
+    import random
+    from vae.datasets_randomized import CustomBatchSampler, VolSurfaceDataSetRand
+    rng = np.random.Generator(np.random.PCG64(8000))
+    N = 64
+    surf = rng.standard_normal((N, 5, 5))
+    ex = rng.standard_normal((N, 3))
+    ds = VolSurfaceDataSetRand((surf, ex), min_seq_len=4, max_seq_len=10)
+    random.seed(0)
+    batches = list(CustomBatchSampler(ds, 16, 4))
+    flat = np.asarray([i for b in batches for i in b], dtype=np.int64)
+    sizes = np.asarray([len(b) for b in batches], dtype=np.int64)
+    lens = np.asarray([ds[b[0]]["surface"].shape[0] for b in batches], dtype=np.int64)
+    item = ds[3 * N + 60]                      # a tail window: shorter than its nominal length
+    np.savez_compressed(os.path.join(OUT, "g10_sampler.npz"), surface=surf, ex_feats=ex, flat=flat, sizes=sizes,
+                        lens=lens, n_items=np.int64(len(ds)), tail_len=np.int64(item["surface"].shape[0]),
+                        tail_first=item["surface"][0].numpy())
+    print("wrote g10_sampler")
+
+
 def main_training():
+    case_sampler()
     """G4 / G5: gradients (float64 reference)."""
     ex5 = vo.make_config(5, 3)
     no_ex = vo.make_config(5, 0)

@@ -320,3 +320,61 @@ def test_train_losses_and_gradients_vs_reference(name):
         assert abs(float(losses[k]) - want) <= 1e-3 * abs(want) + 1e-9, (k, float(losses[k]), want)
     grads = te.param_grads(gp)
     _check_grads(g, [n for n, _ in vo.state_dict_spec(cfg)], grads)
+
+
+def test_multihorizon_losses_and_gradients_vs_reference():
+    """train_step_multihorizon's accumulated loss and gradient (golden g5): one forward/backward
+    per horizon with its own injected noise, weights {1: 1.0, 7: 0.8, 14: 0.6, 30: 0.4}."""
+    g = load_golden("g5_multih_ex5_B4_T50")
+    cfg, eng, te = _train_setup(g)
+    for k in ("ex_loss_on_ret_only", "ex_feats_loss_type", "kl_weight", "re_feat_weight"):
+        v = g["cfg_" + k]
+        cfg[k] = v.item() if v.dtype.kind != "U" else str(v)
+    wts = {1: 1.0, 7: 0.8, 14: 0.6, 30: 0.4}
+    total, gp_sum, hl = 0.0, None, []
+    for i, h in enumerate(g["horizons"].tolist()):
+        losses, gp, _ = te.loss_and_grads(_t(g["surface"]), _t(g["ex_feats"]), h, _loss_cfg(cfg, g), eps=_t(g["eps"][i]))
+        hl.append(float(losses["loss"]))
+        total += wts[h] * float(losses["loss"])
+        gp_sum = wts[h] * gp if gp_sum is None else gp_sum + wts[h] * gp
+    assert np.max(np.abs(np.asarray(hl) - g["horizon_losses"]) / np.abs(g["horizon_losses"])) <= 1e-3
+    assert abs(total - float(g["loss"])) <= 1e-3 * abs(float(g["loss"]))
+    _check_grads(g, [n for n, _ in vo.state_dict_spec(cfg)], te.param_grads(gp_sum))
+
+
+def test_model_class_training_api():
+    """The drop-in class end to end on the GPU: the shapes the reference's own script test checks
+    (test_code/test_quantile_decoder.py:34-50, 105-178), train_step / test_step dict contract,
+    clipping, multi-horizon return types, and that optimisation actually reduces the loss."""
+    from vae.cvae_with_mem_randomized import CVAEMemRand
+    torch.manual_seed(0)
+    cfg = vo.make_config(5, 3, device="cuda:0", kl_weight=1e-5)
+    model = CVAEMemRand(cfg)
+    rng = np.random.default_rng(0)
+    x = {"surface": torch.from_numpy((0.2 + 0.1 * rng.standard_normal((16, 8, 5, 5))).astype(np.float32)),
+         "ex_feats": torch.from_numpy((0.01 * rng.standard_normal((16, 8, 3))).astype(np.float32))}
+    out = model.forward(x)
+    assert out[0].shape == (16, 1, 3, 5, 5) and out[1].shape == (16, 1, 3) and out[2].shape == (16, 8, 5)
+    s, e = model.get_surface_given_conditions({"surface": x["surface"][0, :7], "ex_feats": x["ex_feats"][0, :7]})
+    assert s.shape == (1, 1, 3, 5, 5) and e.shape == (1, 1, 3)
+    opt = torch.optim.AdamW(model.parameters(), lr=1e-3)
+    before = model.test_step(x)
+    assert set(before) == {"loss", "re_surface", "re_ex_feats", "reconstruction_loss", "kl_loss"}
+    first = None
+    for _ in range(30):
+        losses = model.train_step(x, opt)
+        assert all(torch.is_tensor(v) for v in losses.values()) and torch.isfinite(losses["loss"])
+        gn = torch.sqrt(sum((p.grad.double() ** 2).sum() for p in model.parameters()))
+        assert gn <= 1.0 + 1e-4                                     # clip_grad_norm_(1.0)
+        first = first if first is not None else float(losses["loss"])
+    assert float(losses["loss"]) < first
+    mh = model.train_step_multihorizon(x, opt, horizons=[1, 3])
+    assert isinstance(mh["loss"], float) and set(mh["horizon_losses"]) == {1, 3}
+    with pytest.raises(ValueError):
+        model.train_step_multihorizon(x, opt, horizons=[1, 30])
+    ar = model.generate_autoregressive_sequence({"surface": x["surface"][:2, :7], "ex_feats": x["ex_feats"][:2, :7]}, horizon=4)
+    assert ar[0].shape == (2, 4, 3, 5, 5) and ar[1].shape == (2, 4, 3)
+    # no-ex model: 4-tuple forward, zeros(1) placeholder
+    m2 = CVAEMemRand(vo.make_config(5, 0, device="cuda:0"))
+    l2 = m2.train_step({"surface": x["surface"]}, torch.optim.AdamW(m2.parameters(), lr=1e-4))
+    assert l2["re_ex_feats"].shape == (1,) and len(m2.forward({"surface": x["surface"]})) == 4

@@ -114,3 +114,27 @@ def test_gather_maps_reproduce_host_packing(L, X):
     ia, ib = build_gather_maps(dims, spec)
     flat = np.concatenate([[0.0]] + [W[n].ravel() for n, _ in spec]).astype(np.float32)
     assert np.array_equal(flat[ia] + flat[ib], pack_state_dict(dims, W))
+
+
+def test_dataset_and_sampler_match_reference():
+    """VolSurfaceDataSetRand / CustomBatchSampler against the reference's own output (golden g10,
+    random.seed(0)): same item windows, same batches in the same order."""
+    import random
+    from conftest import load_golden
+    from vae.datasets_randomized import CustomBatchSampler, VolSurfaceDataSetRand
+    g = load_golden("g10_sampler")
+    ds = VolSurfaceDataSetRand((g["surface"], g["ex_feats"]), min_seq_len=4, max_seq_len=10)
+    assert len(ds) == int(g["n_items"])
+    item = ds[3 * 64 + 60]
+    assert item["surface"].shape[0] == int(g["tail_len"]) and item["ex_feats"].shape == (int(g["tail_len"]), 3)
+    assert np.array_equal(item["surface"][0].numpy(), g["tail_first"])
+    random.seed(0)
+    batches = list(CustomBatchSampler(ds, 16, 4))
+    assert [len(b) for b in batches] == g["sizes"].tolist()
+    assert [i for b in batches for i in b] == g["flat"].tolist()
+    assert [ds[b[0]]["surface"].shape[0] for b in batches] == g["lens"].tolist()
+    for b in batches:                                     # a batch never mixes lengths
+        assert len({ds[i]["surface"].shape[0] for i in b}) == 1
+    # single-array dataset, float32 option
+    ds32 = VolSurfaceDataSetRand(g["surface"], 2, 3, dtype=torch.float32)
+    assert ds32[0]["surface"].dtype == torch.float32 and "ex_feats" not in ds32[0]

@@ -167,3 +167,29 @@ def test_torch_port_prior_generation(name):
     assert np.max(np.abs(z.numpy() - g["z_after"])) <= tol(dt)
     if ex is not None:
         assert np.max(np.abs(e.numpy() - g["ex_out"])) <= tol(dt)
+
+
+@pytest.mark.parametrize("name", golden_names("g4_"))
+def test_torch_port_gradients(name):
+    """The torch-CPU port as an autograd oracle: its gradients equal the reference's."""
+    import torch
+    from oracle.torch_port import TorchPort
+    g = load_golden(name)
+    cfg = cfg_of(g)
+    for k in ("ex_loss_on_ret_only", "ex_feats_loss_type", "kl_weight", "re_feat_weight"):
+        v = g["cfg_" + k]
+        cfg[k] = v.item() if v.dtype.kind != "U" else str(v)
+    W = vo.init_weights(cfg, int(g["seed"]), float(g["scale"]), np.float64)
+    port = TorchPort(cfg, W, torch.float64)
+    T = lambda a: None if a is None else torch.tensor(a, dtype=torch.float64)      # noqa: E731
+    losses = port.losses(T(g["surface"]), T(g.get("ex_feats")), T(g["eps"]), int(g["horizon"]),
+                         [float(x) for x in g["cfg_quantile_loss_weights"]])
+    losses["loss"].backward()
+    for k in ("loss", "re_surface", "kl_loss"):
+        assert abs(float(losses[k]) - float(g["loss_" + k])) <= 1e-9 * max(1.0, abs(float(g["loss_" + k])))
+    total = 0.0
+    for n, p in port.named_reference_parameters().items():
+        gr = p.grad.numpy()
+        total += float((gr ** 2).sum())
+        assert abs(np.sqrt((gr ** 2).sum()) - float(g["gnorm/" + n])) <= 1e-8 * max(1.0, float(g["gnorm/" + n])), n
+    assert abs(np.sqrt(total) - float(g["grad_total_norm"])) <= 1e-8 * float(g["grad_total_norm"])

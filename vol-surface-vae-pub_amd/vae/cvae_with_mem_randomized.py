@@ -497,14 +497,87 @@ class CVAEMemRand(BaseVAE):
         return {"loss": recon_err + self.kl_weight * kl, "re_surface": re_surface, "re_ex_feats": re_ex,
                 "reconstruction_loss": recon_err, "kl_loss": kl}
 
+    # -- training ------------------------------------------------------------------------
+    def _train_engine(self):
+        """The training engine (forward with saved activations, loss + BPTT kernels,
+        parameter-gradient assembly), built once per model."""
+        from vsv.train import TrainEngine
+        eng = self._engine()
+        te = self.__dict__.get("_vsv_train_engine")
+        if te is None or te.eng is not eng:
+            te = TrainEngine(eng, [(n, tuple(p.shape)) for n, p in self._hip_named_params()])
+            self.__dict__["_vsv_train_engine"] = te
+        if self.training and self.config.get("mem_dropout", 0) and not self.__dict__.get("_vsv_dropout_warned"):
+            import warnings
+            warnings.warn("the HIP training path does not apply nn.LSTM's inter-layer dropout yet "
+                          f"(mem_dropout={self.config['mem_dropout']}); training proceeds without it")
+            self.__dict__["_vsv_dropout_warned"] = True
+        return te
+
+    def _loss_cfg(self):
+        w = self.quantile_loss_fn.weights.detach().cpu().tolist()
+        X = self.config["ex_feats_dim"]
+        return dict(quantiles=self.quantile_loss_fn.quantiles.detach().cpu().tolist(), quantile_weights=w,
+                    ex_n=(1 if self.config["ex_loss_on_ret_only"] else max(X, 1)),
+                    ex_l2=int(isinstance(self.ex_feats_loss_fn, nn.MSELoss)),
+                    ex_weight=float(self.config["re_feat_weight"]), kl_weight=float(self.kl_weight))
+
+    def _loss_terms(self, x, horizon, want_grads):
+        surf, ex = self._batched(x)
+        T = surf.shape[1]
+        if T - horizon < 1:
+            raise ValueError(f"Insufficient sequence length: T={T}, horizon={horizon}, "
+                             f"resulting in C={T - horizon}. Need at least C >= 1.")
+        te = self._train_engine()
+        losses, gp, _ = te.loss_and_grads(surf, ex, horizon, self._loss_cfg(), seed=self._draw_seed(),
+                                          want_grads=want_grads)
+        if ex is None:
+            losses["re_ex_feats"] = torch.zeros(1)
+        return losses, gp
+
+    def _accumulate_grads(self, gp, weight=1.0):
+        te = self.__dict__["_vsv_train_engine"]
+        for (_, p), g in zip(self._hip_named_params(), te.param_grads(gp)):
+            g = (g * weight if weight != 1.0 else g).to(p.dtype)
+            p.grad = g.clone() if p.grad is None else p.grad + g
+
     def test_step(self, x):
         """Reference :1265-1308: forward + losses, returns a dict of tensors."""
-        return self._losses(x, self.forward(x), self.horizon)
+        return self._loss_terms(x, self.horizon, False)[0]
 
     def train_step(self, x, optimizer: torch.optim.Optimizer):
-        raise NotImplementedError("training kernels (BPTT) are not built yet in this round; "
-                                  "see DESIGN.md 'status'")
+        """Reference :1076-1137: zero_grad, forward, pinball + ex-feature + KL loss, backward,
+        clip_grad_norm_(1.0), optimizer.step().  Computed in float32 (the reference's CUDA path
+        runs this under bf16 autocast; its CPU path, which the parity goldens pin, in float32).
+        Returns a dict of tensors."""
+        optimizer.zero_grad()
+        losses, gp = self._loss_terms(x, self.horizon, True)
+        self._accumulate_grads(gp)
+        torch.nn.utils.clip_grad_norm_(self.parameters(), max_norm=1.0)
+        optimizer.step()
+        return losses
 
     def train_step_multihorizon(self, x, optimizer: torch.optim.Optimizer, horizons=[1, 7, 14, 30]):
-        raise NotImplementedError("training kernels (BPTT) are not built yet in this round; "
-                                  "see DESIGN.md 'status'")
+        """Reference :1139-1263: one forward per horizon (fresh noise each), losses weighted
+        {1: 1.0, 7: 0.8, 14: 0.6, 30: 0.4} (default 1.0), one backward, no clipping.  Returns floats."""
+        weights = {1: 1.0, 7: 0.8, 14: 0.6, 30: 0.4}
+        surface = x["surface"]
+        T = surface.shape[0] if surface.dim() == 3 else surface.shape[1]
+        max_horizon = max(horizons)
+        if T < 1 + max_horizon:
+            raise ValueError(f"Insufficient sequence length: T={T}, max_horizon={max_horizon}, "
+                             f"need at least T >= {1 + max_horizon}")
+        optimizer.zero_grad()
+        total_loss = total_re = total_kl = 0.0
+        horizon_losses = {}
+        for h in horizons:
+            w = weights.get(h, 1.0)
+            losses, gp = self._loss_terms(x, h, True)
+            self._accumulate_grads(gp, w)
+            total_loss += w * losses["loss"].item()
+            total_re += w * losses["reconstruction_loss"].item()
+            total_kl += w * losses["kl_loss"].item()
+            horizon_losses[h] = losses["loss"].item()
+        optimizer.step()
+        return {"loss": total_loss, "reconstruction_loss": total_re, "kl_loss": total_kl,
+                "horizon_losses": horizon_losses}

@@ -99,6 +99,63 @@ def cpu_baseline(cfg, W, vol, ex, C, H, S, budget_s: float):
                       f"torch CPU float32, {el:.1f} s"}
 
 
+def train_bench(dev, steps: int, cpu_steps: int):
+    """The metric's second half, 'train samples/s' (BASELINE configs[1]): CVAEMemRand ex_loss
+    (surface + 3 extra features, return-only L2 term), batch 64, sequence length drawn per batch
+    from [2, 21] (context 1-20 + horizon 1), AdamW(1e-5), the drop-in class's train_step on the
+    HIP kernels.  The CPU figure is the torch port's autograd step on the same batches."""
+    from oracle import vsv_oracle as vo
+    from vae.cvae_with_mem_randomized import CVAEMemRand
+    B = 64
+    cfg = vo.make_config(5, 3, device=str(dev))
+    W = vo.init_weights(cfg, 0, 1.0, np.float32)
+    torch.manual_seed(0)
+    model = CVAEMemRand(dict(cfg))
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in W.items()}, strict=False)
+    model.train()
+    opt = torch.optim.AdamW(model.parameters(), lr=1e-5)
+    rng = np.random.Generator(np.random.PCG64(4321))
+    lens = rng.integers(2, 22, size=steps + 3)
+    batches = [{"surface": torch.from_numpy((0.2 + 0.1 * rng.standard_normal((B, int(T), 5, 5))).astype(np.float32)).to(dev),
+                "ex_feats": torch.from_numpy((0.01 * rng.standard_normal((B, int(T), 3))).astype(np.float32)).to(dev)}
+               for T in lens]
+    for b in batches[:3]:
+        model.train_step(b, opt)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for b in batches[3:]:
+        model.train_step(b, opt)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    out = {"metric": "train samples/s", "value": B * steps / dt, "unit": "samples/s", "ms_per_step": dt / steps * 1e3,
+           "config": {"workload": "BASELINE configs[1]: CVAEMemRand ex_loss train_step, batch 64, T ~ U[2,21], "
+                                  "horizon 1, AdamW(1e-5), clip 1.0, dropout 0", "steps": steps}}
+    if cpu_steps > 0:
+        from oracle.torch_port import TorchPort
+        port = TorchPort(cfg, W, torch.float32)
+        params = list(port.parameters())
+        copt = torch.optim.AdamW(params, lr=1e-5)
+        gen = torch.Generator().manual_seed(5)
+
+        def cpu_step(b):
+            copt.zero_grad()
+            s, e = b["surface"].cpu(), b["ex_feats"].cpu()
+            eps = torch.randn((B, s.shape[1], 5), generator=gen)
+            port.losses(s, e, eps, 1)["loss"].backward()
+            torch.nn.utils.clip_grad_norm_(params, 1.0)
+            copt.step()
+
+        cpu_step(batches[0])
+        t0 = time.perf_counter()
+        for b in batches[3:3 + cpu_steps]:
+            cpu_step(b)
+        ct = time.perf_counter() - t0
+        out["cpu_baseline"] = {"value": B * cpu_steps / ct, "unit": "samples/s", "cores": int(torch.get_num_threads()),
+                               "kind": "port", "sample": f"{cpu_steps} train steps of the same batches, torch CPU "
+                                                         f"float32 autograd, {ct:.1f} s"}
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -112,6 +169,7 @@ def main():
     ap.add_argument("--ex-feats", type=int, default=3)
     ap.add_argument("--chunk-days", type=int, default=500)
     ap.add_argument("--cpu-budget", type=float, default=15.0, help="seconds of CPU baseline work (0 = skip)")
+    ap.add_argument("--train-steps", type=int, default=50, help="training steps of the secondary metric (0 = skip)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -211,6 +269,8 @@ def main():
     }
     if rank == 0 and args.cpu_budget > 0:
         out["cpu_baseline"] = cpu_baseline(cfg, W, vol_np, ex_np, C, H, S, args.cpu_budget)
+    if rank == 0 and args.train_steps > 0:
+        out["train"] = train_bench(dev, args.train_steps, 10 if args.cpu_budget > 0 else 0)
     if rank == 0:
         print(json.dumps(out), flush=True)
     if dist:

@@ -52,6 +52,33 @@ __device__ __forceinline__ void quad_mfma(f32x16 (&acc)[NC], const float4 (&a)[N
     for (int i = 0; i < NC; ++i) acc[i] = mfma32(a[i].w, b3, acc[i]);
 }
 
+// NC = 1: a quad is only 4 MFMAs (256 cycles), so the weights run four quads ahead.
+__device__ __forceinline__ void gemm_seg(f32x16 (&acc)[1], const float4* __restrict__ w, const int (&toff)[1],
+                                         int qstride, const float* b, int nq) {
+    const float4* wl = w + toff[0];
+    float4 a[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) a[u] = wl[(size_t)((u < nq) ? u : nq - 1) * qstride];
+    int q = 0;
+#pragma unroll 1
+    for (; q + 4 <= nq; q += 4) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const float4 cur[1] = {a[u]};
+            const int qn = (q + 4 + u < nq) ? q + 4 + u : nq - 1;
+            a[u] = wl[(size_t)qn * qstride];
+            quad_mfma<1>(acc, cur, b, q + u);
+        }
+    }
+#pragma unroll
+    for (int u = 0; u < 3; ++u) {
+        if (q + u < nq) {
+            const float4 cur[1] = {a[u]};
+            quad_mfma<1>(acc, cur, b, q + u);
+        }
+    }
+}
+
 template <int NC>
 __device__ __forceinline__ void gemm_seg(f32x16 (&acc)[NC], const float4* __restrict__ w, const int (&toff)[NC],
                                          int qstride, const float* b, int nq) {
@@ -375,13 +402,14 @@ __device__ __forceinline__ float decoder_input(const LstmSeqArgs& a, const DecIn
     return v;
 }
 
-constexpr int kOwn = 4;      // gate tiles per wave (tiles w, w+4, w+8, w+12): hidden size <= 128
+// OWN = gate tiles per wave: 4 (4 waves per row tile: tiles w, w+4, w+8, w+12; many row tiles) or
+// 1 (one wave per gate tile, NT waves per row tile: few row tiles, shortest time per step)
 
 // LSTM cell: lane holds gates (i,f,g,o) of unit 8t + 2jj + hh in acc[i][4jj .. 4jj+3]
-template <bool KEEP>
-__device__ __forceinline__ void lstm_cell(f32x16 (&acc)[kOwn], float (&c)[kOwn][4], float (&hn)[kOwn][4]) {
+template <bool KEEP, int OWN>
+__device__ __forceinline__ void lstm_cell(f32x16 (&acc)[OWN], float (&c)[OWN][4], float (&hn)[OWN][4]) {
 #pragma unroll
-    for (int i = 0; i < kOwn; ++i) {
+    for (int i = 0; i < OWN; ++i) {
 #pragma unroll
         for (int jj = 0; jj < 4; ++jj) {
             const float ig = fast_sigmoid(acc[i][4 * jj + 0]);
@@ -410,9 +438,13 @@ __device__ __forceinline__ void fused_head(const LstmSeqArgs& a, const float* ht
     const RowIo io = make_rowio(hd, row, row_ok, to);
     const int nl = hd.n_layers;
     float4 wq[4 * kHeadTiles];
+    float4 bq[4];
     {
         const int tw = wave < hd.layer[0].nt ? wave : hd.layer[0].nt - 1;
         tile_load<NT>(wq, (const float4*)hd.layer[0].w + tw * 64 + lane, hd.layer[0].nt * 64);
+        const float4* bp = (const float4*)(hd.layer[0].b + tw * 32 + hh * 16);
+#pragma unroll
+        for (int v = 0; v < 4; ++v) bq[v] = bp[v];
     }
     const float* src = htop;
 #pragma unroll 1
@@ -422,8 +454,10 @@ __device__ __forceinline__ void fused_head(const LstmSeqArgs& a, const float* ht
         const bool mine = wave < ly.nt;
         float* dst = ha + (size_t)(li & 1) * kDenseSlots * 64;
         f32x16 acc[1];
-        const int toff[1] = {(mine ? wave : ly.nt - 1) * 64};
-        load_bias<1>(acc, ly.b, toff, hh);
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+            acc[0][4 * v + 0] = bq[v].x; acc[0][4 * v + 1] = bq[v].y; acc[0][4 * v + 2] = bq[v].z; acc[0][4 * v + 3] = bq[v].w;
+        }
         if (mine) {
             if (li == 0) tile_mfma<NT>(acc[0], wq, src);
             else tile_mfma<4 * kHeadTiles>(acc[0], wq, src);
@@ -432,6 +466,9 @@ __device__ __forceinline__ void fused_head(const LstmSeqArgs& a, const float* ht
             const DenseLayerArg& nx = hd.layer[li + 1];
             const int tw = wave < nx.nt ? wave : nx.nt - 1;
             tile_load<4 * kHeadTiles>(wq, (const float4*)nx.w + tw * 64 + lane, nx.nt * 64);
+            const float4* bp = (const float4*)(nx.b + tw * 32 + hh * 16);
+#pragma unroll
+            for (int v = 0; v < 4; ++v) bq[v] = bp[v];
         }
         if (mine) {
 #pragma unroll
@@ -452,10 +489,13 @@ __device__ __forceinline__ void fused_head(const LstmSeqArgs& a, const float* ht
 #ifndef VSV_LSTM_OCC
 #define VSV_LSTM_OCC 2
 #endif
-template <int NT, int NL, int XMODE, bool HEAD, bool SAVE>
-__global__ void __launch_bounds__(256, VSV_LSTM_OCC) lstm_kernel(const LstmSeqArgs a) {
+template <int NT, int NL, int XMODE, bool HEAD, bool SAVE, int OWN>
+__global__ void __launch_bounds__((OWN == 4) ? 256 : 64 * NT, (OWN == 4) ? VSV_LSTM_OCC : (NT + 3) / 4)
+lstm_kernel(const LstmSeqArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    static_assert(NT <= 4 * kOwn, "hidden size <= 128");
+    static_assert(NT <= 16 && (OWN == 4 || OWN == 1), "hidden size <= 128");
+    static_assert(!HEAD || OWN == 4, "the fused head runs on the 4-wave schedule");
+    constexpr int NW = (OWN == 4) ? 4 : NT;                       // waves per workgroup
     constexpr int HPK = 4 * NT;                                   // k-steps of one layer's h
     constexpr int HP = 8 * NT;                                    // padded hidden units
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -471,11 +511,11 @@ __global__ void __launch_bounds__(256, VSV_LSTM_OCC) lstm_kernel(const LstmSeqAr
     float* ha = hb + (size_t)NL * HPK * 64;                       // head activations (HEAD only)
 
     // gate tiles of this wave; out-of-range ones are computed on a clamped tile and never stored
-    int toff[kOwn];
-    bool tval[kOwn];
+    int toff[OWN];
+    bool tval[OWN];
 #pragma unroll
-    for (int i = 0; i < kOwn; ++i) {
-        const int tl = wave + 4 * i;
+    for (int i = 0; i < OWN; ++i) {
+        const int tl = wave + NW * i;
         tval[i] = tl < NT;
         toff[i] = (tval[i] ? tl : NT - 1) * 64;
     }
@@ -492,15 +532,15 @@ __global__ void __launch_bounds__(256, VSV_LSTM_OCC) lstm_kernel(const LstmSeqAr
         if (d.gate_in) gate_in = d.gate_in + (size_t)(row / d.state_div) * NL * NT * 32;
     }
 
-    float c[NL][kOwn][4];
+    float c[NL][OWN][4];
     {
         const float* st = nullptr;
         if (XMODE == 1 && a.din.state_in) st = a.din.state_in + (size_t)(row / a.din.state_div) * NL * 2 * HP;
 #pragma unroll
         for (int l = 0; l < NL; ++l) {
 #pragma unroll
-            for (int i = 0; i < kOwn; ++i) {
-                const int tl = wave + 4 * i;
+            for (int i = 0; i < OWN; ++i) {
+                const int tl = wave + NW * i;
 #pragma unroll
                 for (int jj = 0; jj < 4; ++jj) {
                     float h0 = 0.0f, c0 = 0.0f;
@@ -517,7 +557,7 @@ __global__ void __launch_bounds__(256, VSV_LSTM_OCC) lstm_kernel(const LstmSeqAr
     }
     // x part of layer 0 for step 0 (slots wave, wave+4, ...: the waves share the assembly)
     if (XMODE == 1) {
-        for (int s = wave; s < kx; s += 4) {
+        for (int s = wave; s < kx; s += NW) {
             const float v = decoder_input(a, di, row, row_ok, true, 0, 2 * s + hh);
             xs[s * 64] = v;
             if (SAVE) a.sv_x[((size_t)(rowtile * a.T) * kx + s) * 64 + lane] = v;
@@ -529,8 +569,8 @@ __global__ void __launch_bounds__(256, VSV_LSTM_OCC) lstm_kernel(const LstmSeqAr
     for (int t = 0; t < a.T; ++t) {
 #pragma unroll
         for (int l = 0; l < NL; ++l) {
-            f32x16 acc[kOwn];
-            float hn[kOwn][4];
+            f32x16 acc[OWN];
+            float hn[OWN][4];
             const float4* w = (const float4*)a.w[l] + lane;
             const int nq_in = (l == 0) ? (kx >> 2) : NT;          // quads of the input segment
             const float* bin;
@@ -540,7 +580,7 @@ __global__ void __launch_bounds__(256, VSV_LSTM_OCC) lstm_kernel(const LstmSeqAr
             if (XMODE == 1 && t == 0 && gate_in) {
                 // first step from a shared state: bias + W_hh . h_prev was computed once per state row
 #pragma unroll
-                for (int i = 0; i < kOwn; ++i) {
+                for (int i = 0; i < OWN; ++i) {
                     const float4* p = (const float4*)(gate_in + ((size_t)l * NT + (toff[i] >> 6)) * 32 + hh * 16);
 #pragma unroll
                     for (int v = 0; v < 4; ++v) {
@@ -548,20 +588,20 @@ __global__ void __launch_bounds__(256, VSV_LSTM_OCC) lstm_kernel(const LstmSeqAr
                         acc[i][4 * v + 0] = x.x; acc[i][4 * v + 1] = x.y; acc[i][4 * v + 2] = x.z; acc[i][4 * v + 3] = x.w;
                     }
                 }
-                gemm_seg<kOwn>(acc, w, toff, NT * 64, bin, nq_in);
+                gemm_seg<OWN>(acc, w, toff, NT * 64, bin, nq_in);
             } else {
-                load_bias<kOwn>(acc, a.b[l], toff, hh);
-                gemm_seg<kOwn>(acc, w, toff, NT * 64, bin, nq_in);
-                gemm_seg<kOwn>(acc, w + (size_t)nq_in * NT * 64, toff, NT * 64, hl, NT);
+                load_bias<OWN>(acc, a.b[l], toff, hh);
+                gemm_seg<OWN>(acc, w, toff, NT * 64, bin, nq_in);
+                gemm_seg<OWN>(acc, w + (size_t)nq_in * NT * 64, toff, NT * 64, hl, NT);
             }
-            lstm_cell<SAVE>(acc, c[l], hn);
+            lstm_cell<SAVE, OWN>(acc, c[l], hn);
             if (SAVE) {
                 const size_t il = (size_t)(rowtile * a.T + t) * NL + l;
                 float* sg = a.sv_gates + il * (16 * NT) * 64 + lane;
                 float* sc = a.sv_c + il * HPK * 64 + lane;
                 float* sh = a.sv_h + il * HPK * 64 + lane;
 #pragma unroll
-                for (int i = 0; i < kOwn; ++i) {
+                for (int i = 0; i < OWN; ++i) {
                     if (tval[i]) {
 #pragma unroll
                         for (int r = 0; r < 16; ++r) sg[((toff[i] >> 2) + r) * 64] = acc[i][r];
@@ -576,7 +616,7 @@ __global__ void __launch_bounds__(256, VSV_LSTM_OCC) lstm_kernel(const LstmSeqAr
             // h of this layer is overwritten only after every wave has read the old one
             __syncthreads();
 #pragma unroll
-            for (int i = 0; i < kOwn; ++i) {
+            for (int i = 0; i < OWN; ++i) {
                 if (tval[i]) {
 #pragma unroll
                     for (int jj = 0; jj < 4; ++jj) hl[((toff[i] >> 4) + jj) * 64] = hn[i][jj];
@@ -584,7 +624,7 @@ __global__ void __launch_bounds__(256, VSV_LSTM_OCC) lstm_kernel(const LstmSeqAr
             }
             if (XMODE == 1 && l == NL - 1 && t + 1 < a.T) {
                 // x part of the NEXT step: xs was last read before this layer's first barrier
-                for (int s = wave; s < kx; s += 4) {
+                for (int s = wave; s < kx; s += NW) {
                     const float v = decoder_input(a, di, row, row_ok, true, t + 1, 2 * s + hh);
                     xs[s * 64] = v;
                     if (SAVE) a.sv_x[((size_t)(rowtile * a.T + t + 1) * kx + s) * 64 + lane] = v;
@@ -597,7 +637,7 @@ __global__ void __launch_bounds__(256, VSV_LSTM_OCC) lstm_kernel(const LstmSeqAr
         if (a.hout && t >= a.t_out0) {
             float* ho = a.hout + ((size_t)(rowtile * t_outs + (t - a.t_out0)) * HPK) * 64 + lane;
 #pragma unroll
-            for (int i = 0; i < kOwn; ++i) {
+            for (int i = 0; i < OWN; ++i) {
                 if (tval[i]) {
 #pragma unroll
                     for (int jj = 0; jj < 4; ++jj) ho[((toff[i] >> 4) + jj) * 64] = htop[((toff[i] >> 4) + jj) * 64];
@@ -611,7 +651,7 @@ __global__ void __launch_bounds__(256, VSV_LSTM_OCC) lstm_kernel(const LstmSeqAr
         for (int l = 0; l < NL; ++l) {
             float* st = a.state_out + ((size_t)row * NL + l) * 2 * HP;
 #pragma unroll
-            for (int i = 0; i < kOwn; ++i) {
+            for (int i = 0; i < OWN; ++i) {
                 if (tval[i]) {
 #pragma unroll
                     for (int jj = 0; jj < 4; ++jj) {
@@ -628,14 +668,14 @@ __global__ void __launch_bounds__(256, VSV_LSTM_OCC) lstm_kernel(const LstmSeqAr
         // continuing from this state share (consumed through gate_in)
 #pragma unroll
         for (int l = 0; l < NL; ++l) {
-            f32x16 acc[kOwn];
+            f32x16 acc[OWN];
             const int nq_in = (l == 0) ? (kx >> 2) : NT;
-            load_bias<kOwn>(acc, a.b[l], toff, hh);
-            gemm_seg<kOwn>(acc, (const float4*)a.w[l] + lane + (size_t)nq_in * NT * 64, toff, NT * 64,
+            load_bias<OWN>(acc, a.b[l], toff, hh);
+            gemm_seg<OWN>(acc, (const float4*)a.w[l] + lane + (size_t)nq_in * NT * 64, toff, NT * 64,
                            hb + (size_t)l * HPK * 64, NT);
             if (row_ok) {
 #pragma unroll
-                for (int i = 0; i < kOwn; ++i) {
+                for (int i = 0; i < OWN; ++i) {
                     if (tval[i]) {
                         float4* p = (float4*)(a.din.gate_out + (((size_t)row * NL + l) * NT + (toff[i] >> 6)) * 32 + hh * 16);
 #pragma unroll
@@ -1019,15 +1059,25 @@ static int launch_dense_chain(const DenseChainArgs& a, hipStream_t st) {
     return launch_check("dense_chain_kernel");
 }
 
-template <int NT, int NL, int XMODE, bool HEAD, bool SAVE = false>
-static int launch_lstm_t(const LstmSeqArgs& a, hipStream_t st) {
+// row tiles at or below this count run one wave per gate tile (NT waves per workgroup)
+constexpr long kWideMaxRowtiles = 256;
+
+template <int NT, int NL, int XMODE, bool HEAD, bool SAVE, int OWN>
+static int launch_lstm_o(const LstmSeqArgs& a, hipStream_t st) {
     const int slots = (XMODE == 0 ? 0 : a.kx) + NL * 4 * NT + (HEAD ? 2 * kDenseSlots : 0);
     const size_t lds = (size_t)slots * 64 * sizeof(float);
-    int rc = set_lds(lstm_kernel<NT, NL, XMODE, HEAD, SAVE>, lds);
+    int rc = set_lds(lstm_kernel<NT, NL, XMODE, HEAD, SAVE, OWN>, lds);
     if (rc) return rc;
     if (a.n_rowtiles > 0x7fffffffL) { set_error("lstm_kernel: too many rows"); return -2; }
-    hipLaunchKernelGGL((lstm_kernel<NT, NL, XMODE, HEAD, SAVE>), dim3((unsigned)a.n_rowtiles), dim3(256), lds, st, a);
+    hipLaunchKernelGGL((lstm_kernel<NT, NL, XMODE, HEAD, SAVE, OWN>), dim3((unsigned)a.n_rowtiles),
+                       dim3(OWN == 4 ? 256 : 64 * NT), lds, st, a);
     return launch_check("lstm_kernel");
+}
+
+template <int NT, int NL, int XMODE, bool HEAD, bool SAVE = false>
+static int launch_lstm_t(const LstmSeqArgs& a, hipStream_t st) {
+    if (!HEAD && a.n_rowtiles <= kWideMaxRowtiles) return launch_lstm_o<NT, NL, XMODE, false, SAVE, 1>(a, st);
+    return launch_lstm_o<NT, NL, XMODE, HEAD, SAVE, 4>(a, st);
 }
 
 template <int NT, int XMODE>

@@ -135,6 +135,7 @@ class Engine:
         self.gate_floats = int(self.lib.vsv_gate_floats(C.byref(self.dims)))
         self.packed = None
         self._maps = None
+        self._side = None
         if state_dict is not None:
             self.set_weights(state_dict)
 
@@ -188,6 +189,23 @@ class Engine:
                                      n_rows, T, _ptr(out), _ptr(ws), ws.numel(), self._stream())
         _lib.check(rc, "vsv_encode")
         return out
+
+    def encode_both_strided(self, surf, surf_rs, surf_ts, ex, ex_rs, ex_ts, n_rows, T, T_ctx=None):
+        """Posterior encoder (which=0, T steps) and context encoder (which=1, T_ctx steps) of the
+        same windows on two HIP streams: they are independent and, for a date-range prefix,
+        each is a latency-bound launch that fills only part of the chip."""
+        T_ctx = T if T_ctx is None else T_ctx
+        main = torch.cuda.current_stream(self.device)
+        if self._side is None:
+            self._side = torch.cuda.Stream(self.device)
+        side = self._side
+        side.wait_stream(main)
+        with torch.cuda.stream(side):
+            ctx = self.encode_strided(1, surf, surf_rs, surf_ts, ex, ex_rs, ex_ts, n_rows, T_ctx)
+        enc = self.encode_strided(0, surf, surf_rs, surf_ts, ex, ex_rs, ex_ts, n_rows, T)
+        main.wait_stream(side)
+        ctx.record_stream(main)
+        return enc, ctx
 
     # -- decoder -----------------------------------------------------------
     def decode(self, n_rows: int, T: int, t_out0: int, *,

@@ -82,9 +82,8 @@ def prior_mc_windows(eng: Engine, vol: torch.Tensor, ex: Optional[torch.Tensor],
     w0 = first_day - ctx_len                               # first calendar row of the first window
     sv = vol[w0:]
     se = ex[w0:] if eng.X > 0 else None
-    enc = eng.encode_strided(0, sv, 25, 25, se, eng.X, eng.X, n_days, ctx_len)
+    enc, ctx = eng.encode_both_strided(sv, 25, 25, se, eng.X, eng.X, n_days, ctx_len)
     zm = enc[..., :L].contiguous()
-    ctx = eng.encode_strided(1, sv, 25, 25, se, eng.X, eng.X, n_days, ctx_len)
     pre = eng.decode(n_days, ctx_len, ctx_len, ctx=ctx, zb=zm, want_state=True, want_gates=True)
     state, gates = pre["state"], pre["gates"]
     outs = []
@@ -135,9 +134,8 @@ def ar_generate(eng: Engine, surf_ctx: torch.Tensor, ex_ctx: Optional[torch.Tens
     for k in range(horizon):
         win = buf[:, k:]
         wex = exb[:, k:] if X > 0 else None
-        enc = eng.encode_strided(0, win, TT * 25, 25, wex, TT * X, X, R, C)
+        enc, ctx = eng.encode_both_strided(win, TT * 25, 25, wex, TT * X, X, R, C)
         zm = enc[..., :L].contiguous()
-        ctx = eng.encode_strided(1, win, TT * 25, 25, wex, TT * X, X, R, C)
         r = eng.decode(R, C + 1, C, ctx=ctx, zb=zm,
                        eps=None if eps is None else eps[:, k:k + 1].contiguous(), eps_t0=C,
                        seed=seed, S=S, day0=day0, step0=k)
@@ -229,9 +227,8 @@ def oracle_mc_windows(eng: Engine, vol: torch.Tensor, ex: Optional[torch.Tensor]
     w0 = first_day - ctx_len
     sv = vol[w0:]
     se = ex[w0:] if X > 0 else None
-    enc = eng.encode_strided(0, sv, 25, 25, se, X, X, n_days, T)            # posterior on context + target
+    enc, ctx = eng.encode_both_strided(sv, 25, 25, se, X, X, n_days, T, ctx_len)   # posterior on context + target
     zm, zl = enc[..., :L].contiguous(), enc[..., L:].contiguous()
-    ctx = eng.encode_strided(1, sv, 25, 25, se, X, X, n_days, ctx_len)
     outs = []
     for d0 in range(0, n_days, chunk_days):
         nd = min(chunk_days, n_days - d0)

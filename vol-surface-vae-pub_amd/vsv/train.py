@@ -115,6 +115,8 @@ def _ptr(t: Optional[torch.Tensor]):
 class TrainEngine:
     """Forward + backward of the train_step loss for one model on one GPU."""
 
+    _DUMP = 1 << 16
+
     def __init__(self, eng: Engine, named_shapes):
         self.eng = eng
         self.lib = eng.lib
@@ -153,8 +155,14 @@ class TrainEngine:
         self._bwd_idx = torch.from_numpy(np.where(idx < 0, 0, idx + 1)).to(self.dev)      # 0 -> the zero slot
         # ---- parameter scatter maps (same maps as the device-side packing)
         ia, ib = build_gather_maps(self.dims, list(named_shapes))
-        self._idx_a = torch.from_numpy(ia).to(self.dev)
-        self._idx_b = torch.from_numpy(ib).to(self.dev)
+        # blob positions that hold no parameter (zero padding) are scattered over a dump region
+        # behind the parameters instead of all landing on one word (atomic contention)
+        n_par = int(sum(int(np.prod(s)) for _, s in named_shapes))
+        dump = n_par + 1 + (np.arange(ia.size, dtype=np.int64) % self._DUMP)
+        self._idx_a = torch.from_numpy(np.where(ia == 0, dump, ia)).to(self.dev)
+        nz = np.nonzero(ib)[0]                                  # only the bias_hh entries
+        self._idx_b_pos = torch.from_numpy(nz.astype(np.int64)).to(self.dev)
+        self._idx_b = torch.from_numpy(ib[nz]).to(self.dev)
         self._sizes = [int(np.prod(s)) for _, s in named_shapes]
         self._shapes = [tuple(s) for _, s in named_shapes]
         self._pos_cache: Dict[tuple, tuple] = {}
@@ -196,9 +204,10 @@ class TrainEngine:
         X (NI, ks, 64) in the layer's k order."""
         Gm, Xm = self._mat(G), self._mat(X)
         pos, bpos = self._wmap(sec, G.shape[1], X.shape[1])
-        gp.index_add_(0, pos, (Gm @ Xm.t()).reshape(-1))
+        # every blob position belongs to exactly one (layer, row, column): plain copies, no atomics
+        gp.index_copy_(0, pos, (Gm @ Xm.t()).reshape(-1))
         if bias:
-            gp.index_add_(0, bpos, Gm.sum(dim=1))
+            gp.index_copy_(0, bpos, Gm.sum(dim=1))
 
     # -- one forward/backward ----------------------------------------------------------
     def loss_and_grads(self, surf: torch.Tensor, ex: Optional[torch.Tensor], horizon: int, loss_cfg: dict,
@@ -219,7 +228,13 @@ class TrainEngine:
         st = self._stream()
         packed = eng.packed
 
-        def run_encoder(which, Tw):
+        main = torch.cuda.current_stream(dev)
+        if eng._side is None:
+            eng._side = torch.cuda.Stream(dev)
+        side = eng._side
+
+        def run_encoder(which, Tw, stream):
+            """Buffers are allocated on the main stream; the three launches go to `stream`."""
             e = lay["enc"][which]
             NI = rt * Tw
             sv = dict(emb_acts=self._e(self.n_conv[which], NI, 64, 64), xe=self._e(NI, e["kx"], 64),
@@ -229,15 +244,19 @@ class TrainEngine:
             s = _lib.VsvTrainSave()
             for k, v in sv.items():
                 setattr(s, k, v.data_ptr())
-            rc = lib.vsv_train_encode(C.byref(self.dims), packed.data_ptr(), which,
-                                      surf.data_ptr(), T * 25, 25, _ptr(ex), T * X, X,
-                                      B, Tw, out.data_ptr(), C.byref(s), st)
+            with torch.cuda.stream(stream):
+                rc = lib.vsv_train_encode(C.byref(self.dims), packed.data_ptr(), which,
+                                          surf.data_ptr(), T * 25, 25, _ptr(ex), T * X, X,
+                                          B, Tw, out.data_ptr(), C.byref(s), self._stream())
             _lib.check(rc, "vsv_train_encode")
             return out, sv
 
         with torch.cuda.device(dev):
-            enc_out, sv_e = run_encoder(0, T)
-            ctx_out, sv_c = run_encoder(1, Cn)
+            # the two encoders are independent: context encoder on the side stream
+            side.wait_stream(main)
+            ctx_out, sv_c = run_encoder(1, Cn, side)
+            enc_out, sv_e = run_encoder(0, T, main)
+            main.wait_stream(side)
             zm, zl = enc_out[..., :L].contiguous(), enc_out[..., L:].contiguous()
             # ---- decoder
             NI, NIo = rt * T, rt * horizon
@@ -306,7 +325,7 @@ class TrainEngine:
                 a.in_mode, a.in_, a.in_f = in_mode, in_t.data_ptr(), in_f
                 dx = self._e(rt * n_inst_T, 64, 64) if want_dx else None
                 a.dx_out = _ptr(dx)
-                _lib.check(lib.vsv_dense_backward(C.byref(a), st), "vsv_dense_backward")
+                _lib.check(lib.vsv_dense_backward(C.byref(a), self._stream()), "vsv_dense_backward")
                 return dx
 
             def lstm_bwd(prefix, hidden, NT, sv, Tw, t_out0, dh_top, nt_x, dx_tile=None, dx_rows=None, dx_f=0):
@@ -318,7 +337,7 @@ class TrainEngine:
                 a.sv_gates, a.sv_c, a.dh_top = sv["gates"].data_ptr(), sv["c"].data_ptr(), dh_top.data_ptr()
                 dg = self._e(rt * Tw, NL, 16 * NT, 64)
                 a.dgates, a.dx_tile, a.dx_rows, a.dx_f = dg.data_ptr(), _ptr(dx_tile), _ptr(dx_rows), dx_f
-                _lib.check(lib.vsv_lstm_backward(C.byref(a), hidden, NL, st), "vsv_lstm_backward")
+                _lib.check(lib.vsv_lstm_backward(C.byref(a), hidden, NL, self._stream()), "vsv_lstm_backward")
                 return dg
 
             def lstm_wgrads(secs, sv, dg, Tw, NT, x_tile):
@@ -382,16 +401,20 @@ class TrainEngine:
                     cs = e["conv"][li]
                     self._acc_layer(gp, cs, g[:, : 16 * cs.nt], sv["emb_acts"][li][:, : 4 * cs.nq])
 
-            encoder_bwd(0, sv_e, T, torch.cat([dzm_t, dzl_t], dim=-1).contiguous())
-            encoder_bwd(1, sv_c, Cn, d_ctx)
+            d_enc = torch.cat([dzm_t, dzl_t], dim=-1).contiguous()
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                encoder_bwd(1, sv_c, Cn, d_ctx)
+            encoder_bwd(0, sv_e, T, d_enc)
+            main.wait_stream(side)
         return losses, gp, outputs
 
     def param_grads(self, gp: torch.Tensor) -> List[torch.Tensor]:
         """gradient w.r.t. the packed blob -> gradients of the parameters (spec order)."""
         n = sum(self._sizes)
-        flat = torch.zeros(n + 1, dtype=torch.float32, device=self.dev)
+        flat = torch.zeros(n + 1 + self._DUMP, dtype=torch.float32, device=self.dev)
         flat.index_add_(0, self._idx_a, gp)
-        flat.index_add_(0, self._idx_b, gp)
+        flat.index_add_(0, self._idx_b, gp[self._idx_b_pos])
         out, o = [], 1
         for sz, sh in zip(self._sizes, self._shapes):
             out.append(flat[o:o + sz].view(sh))

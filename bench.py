@@ -169,6 +169,7 @@ def main():
     ap.add_argument("--ex-feats", type=int, default=3)
     ap.add_argument("--chunk-days", type=int, default=500)
     ap.add_argument("--cpu-budget", type=float, default=15.0, help="seconds of CPU baseline work (0 = skip)")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL)")
     ap.add_argument("--train-steps", type=int, default=50, help="training steps of the secondary metric (0 = skip)")
     args = ap.parse_args()
 
@@ -177,12 +178,16 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise RuntimeError("bench.py needs a GPU: the HIP path has no CPU fallback")
+    local_rank %= torch.cuda.device_count()                 # identity on a full node; lets a 1-GPU box rehearse N > 1
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=dev)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(args.backend)
 
     from oracle import vsv_oracle as vo          # config/weight helpers + the cpu_baseline leg only
     from vsv import paths
@@ -194,17 +199,14 @@ def main():
     W = vo.init_weights(cfg, 0, 1.0, np.float32)
     eng = Engine(cfg, W, dev)
     vol_np, ex_np = synthetic_calendar(N * world, C, X)
-    lo = rank * N
-    vol = torch.from_numpy(vol_np[lo:lo + N + C]).to(dev)
-    ex = torch.from_numpy(ex_np[lo:lo + N + C]).to(dev) if X else None
-    gathered = [torch.empty((N, H, 3, 5, 5), dtype=torch.float32, device=dev) for _ in range(world)] if dist else None
+    # every rank holds the whole (small) calendar; vsv.sharded gives it its own N-day range
+    vol = torch.from_numpy(vol_np).to(dev)
+    ex = torch.from_numpy(ex_np).to(dev) if X else None
+    from vsv import sharded
 
     def one_step(events=None):
-        q = paths.prior_mc_windows(eng, vol, ex, C, N, C, H, S, seed=0, qs=(5, 50, 95), channel=1,
-                                   chunk_days=args.chunk_days, day_index0=C + lo, decode_events=events)
-        if dist:
-            dist.all_gather(gathered, q.contiguous())
-        return q
+        return sharded.prior_mc_sharded(eng, vol, ex, C, N * world, C, H, S, seed=0, qs=(5, 50, 95), channel=1,
+                                        chunk_days=args.chunk_days, decode_events=events)
 
     def fence():
         if dist:
@@ -221,7 +223,7 @@ def main():
     fence()
     dt = time.perf_counter() - t0
     if dist:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        t = torch.tensor([dt], dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 

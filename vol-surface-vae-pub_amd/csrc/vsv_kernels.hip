@@ -53,12 +53,13 @@ __device__ __forceinline__ void quad_mfma(f32x16 (&acc)[NC], const float4 (&a)[N
 }
 
 // NC = 1: a quad is only 4 MFMAs (256 cycles), so the weights run four quads ahead.
-__device__ __forceinline__ void gemm_seg(f32x16 (&acc)[1], const float4* __restrict__ w, const int (&toff)[1],
-                                         int qstride, const float* b, int nq) {
-    const float4* wl = w + toff[0];
+__device__ __forceinline__ void gemm_seg(f32x16 (&acc)[1], const float4* __restrict__ w, unsigned lane,
+                                         const int (&toff)[1], int qstride, const float* b, int nq) {
+    // w is wave-uniform: indexing it with 32-bit offsets keeps the address in SGPRs + one VGPR
+    const unsigned o = lane + (unsigned)toff[0];
     float4 a[4];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) a[u] = wl[(size_t)((u < nq) ? u : nq - 1) * qstride];
+    for (int u = 0; u < 4; ++u) a[u] = w[o + (unsigned)(((u < nq) ? u : nq - 1) * qstride)];
     int q = 0;
 #pragma unroll 1
     for (; q + 4 <= nq; q += 4) {
@@ -66,7 +67,7 @@ __device__ __forceinline__ void gemm_seg(f32x16 (&acc)[1], const float4* __restr
         for (int u = 0; u < 4; ++u) {
             const float4 cur[1] = {a[u]};
             const int qn = (q + 4 + u < nq) ? q + 4 + u : nq - 1;
-            a[u] = wl[(size_t)qn * qstride];
+            a[u] = w[o + (unsigned)(qn * qstride)];
             quad_mfma<1>(acc, cur, b, q + u);
         }
     }
@@ -80,42 +81,50 @@ __device__ __forceinline__ void gemm_seg(f32x16 (&acc)[1], const float4* __restr
 }
 
 template <int NC>
-__device__ __forceinline__ void gemm_seg(f32x16 (&acc)[NC], const float4* __restrict__ w, const int (&toff)[NC],
-                                         int qstride, const float* b, int nq) {
+__device__ __forceinline__ void gemm_seg(f32x16 (&acc)[NC], const float4* __restrict__ w, unsigned lane,
+                                         const int (&toff)[NC], int qstride, const float* b, int nq) {
     float4 a0[NC], a1[NC];
+    unsigned o[NC];
 #pragma unroll
-    for (int i = 0; i < NC; ++i) a0[i] = w[toff[i]];
+    for (int i = 0; i < NC; ++i) {
+        o[i] = lane + (unsigned)toff[i];
+        a0[i] = w[o[i]];
+    }
     int q = 0;
 #pragma unroll 1
     for (; q + 1 < nq; q += 2) {
-        const float4* w1 = w + (size_t)(q + 1) * qstride;
+        const unsigned q1 = (unsigned)((q + 1) * qstride);
 #pragma unroll
-        for (int i = 0; i < NC; ++i) a1[i] = w1[toff[i]];
+        for (int i = 0; i < NC; ++i) a1[i] = w[o[i] + q1];
         quad_mfma<NC>(acc, a0, b, q);
-        const float4* w2 = w + (size_t)((q + 2 < nq) ? q + 2 : q + 1) * qstride;
+        const unsigned q2 = (unsigned)(((q + 2 < nq) ? q + 2 : q + 1) * qstride);
 #pragma unroll
-        for (int i = 0; i < NC; ++i) a0[i] = w2[toff[i]];
+        for (int i = 0; i < NC; ++i) a0[i] = w[o[i] + q2];
         quad_mfma<NC>(acc, a1, b, q + 1);
     }
     if (q < nq) quad_mfma<NC>(acc, a0, b, q);
 }
 
-// One output tile over NQ k-quads with ALL its weights in registers (decoder head: one
-// tile per wave, so a one-quad prefetch distance would not cover the L2 latency; the
-// caller fetches the next layer's weights before it waits at the layer's barrier).
+// One output tile per wave (decoder head): the weights of the first kHalfQ quads are fetched by
+// the caller before it waits at the previous layer's barrier; while they are multiplied each
+// register is refilled with the quad kHalfQ further on, so the rest is in flight behind the MFMAs.
+constexpr int kHalfQ = 8;
 template <int NQ>
-__device__ __forceinline__ void tile_load(float4 (&a)[4 * kHeadTiles], const float4* __restrict__ w, int qstride) {
+__device__ __forceinline__ void tile_load(float4 (&a)[kHalfQ], const float4* __restrict__ w, unsigned off, int qstride) {
 #pragma unroll
-    for (int q = 0; q < NQ; ++q) a[q] = w[(size_t)q * qstride];
+    for (int q = 0; q < kHalfQ; ++q) a[q] = w[off + (unsigned)(((q < NQ) ? q : NQ - 1) * qstride)];
 }
 template <int NQ>
-__device__ __forceinline__ void tile_mfma(f32x16& acc, const float4 (&a)[4 * kHeadTiles], const float* b) {
+__device__ __forceinline__ void tile_mfma(f32x16& acc, float4 (&a)[kHalfQ], const float4* __restrict__ w, unsigned off,
+                                          int qstride, const float* b) {
 #pragma unroll
     for (int q = 0; q < NQ; ++q) {
-        acc = mfma32(a[q].x, b[(4 * q + 0) * 64], acc);
-        acc = mfma32(a[q].y, b[(4 * q + 1) * 64], acc);
-        acc = mfma32(a[q].z, b[(4 * q + 2) * 64], acc);
-        acc = mfma32(a[q].w, b[(4 * q + 3) * 64], acc);
+        const float4 cur = a[q % kHalfQ];
+        if (q + kHalfQ < NQ) a[q % kHalfQ] = w[off + (unsigned)((q + kHalfQ) * qstride)];
+        acc = mfma32(cur.x, b[(4 * q + 0) * 64], acc);
+        acc = mfma32(cur.y, b[(4 * q + 1) * 64], acc);
+        acc = mfma32(cur.z, b[(4 * q + 2) * 64], acc);
+        acc = mfma32(cur.w, b[(4 * q + 3) * 64], acc);
     }
 }
 
@@ -271,7 +280,7 @@ __device__ __forceinline__ void dense_layer(const DenseChainArgs& a, const RowIo
 #pragma unroll
     for (int i = 0; i < NT; ++i) toff[i] = i * 64;
     load_bias<NT>(acc, ly.b, toff, hh);
-    gemm_seg<NT>(acc, (const float4*)ly.w + lane, toff, NT * 64, col, ly.nq);
+    gemm_seg<NT>(acc, (const float4*)ly.w, lane, toff, NT * 64, col, ly.nq);
     const bool last = (li == a.n_layers - 1);
     dense_epilogue<NT>(a, io, li, last, acc, hh, ly.n_relu);
     if (!last) {
@@ -437,11 +446,11 @@ __device__ __forceinline__ void fused_head(const LstmSeqArgs& a, const float* ht
     const int hh = lane >> 5;
     const RowIo io = make_rowio(hd, row, row_ok, to);
     const int nl = hd.n_layers;
-    float4 wq[4 * kHeadTiles];
+    float4 wq[kHalfQ];
     float4 bq[4];
     {
         const int tw = wave < hd.layer[0].nt ? wave : hd.layer[0].nt - 1;
-        tile_load<NT>(wq, (const float4*)hd.layer[0].w + tw * 64 + lane, hd.layer[0].nt * 64);
+        tile_load<NT>(wq, (const float4*)hd.layer[0].w, tw * 64 + lane, hd.layer[0].nt * 64);
         const float4* bp = (const float4*)(hd.layer[0].b + tw * 32 + hh * 16);
 #pragma unroll
         for (int v = 0; v < 4; ++v) bq[v] = bp[v];
@@ -459,13 +468,14 @@ __device__ __forceinline__ void fused_head(const LstmSeqArgs& a, const float* ht
             acc[0][4 * v + 0] = bq[v].x; acc[0][4 * v + 1] = bq[v].y; acc[0][4 * v + 2] = bq[v].z; acc[0][4 * v + 3] = bq[v].w;
         }
         if (mine) {
-            if (li == 0) tile_mfma<NT>(acc[0], wq, src);
-            else tile_mfma<4 * kHeadTiles>(acc[0], wq, src);
+            const unsigned off = wave * 64 + lane;
+            if (li == 0) tile_mfma<NT>(acc[0], wq, (const float4*)ly.w, off, ly.nt * 64, src);
+            else tile_mfma<4 * kHeadTiles>(acc[0], wq, (const float4*)ly.w, off, ly.nt * 64, src);
         }
         if (!last) {
             const DenseLayerArg& nx = hd.layer[li + 1];
             const int tw = wave < nx.nt ? wave : nx.nt - 1;
-            tile_load<4 * kHeadTiles>(wq, (const float4*)nx.w + tw * 64 + lane, nx.nt * 64);
+            tile_load<4 * kHeadTiles>(wq, (const float4*)nx.w, tw * 64 + lane, nx.nt * 64);
             const float4* bp = (const float4*)(nx.b + tw * 32 + hh * 16);
 #pragma unroll
             for (int v = 0; v < 4; ++v) bq[v] = bp[v];
@@ -571,7 +581,7 @@ lstm_kernel(const LstmSeqArgs a) {
         for (int l = 0; l < NL; ++l) {
             f32x16 acc[OWN];
             float hn[OWN][4];
-            const float4* w = (const float4*)a.w[l] + lane;
+            const float4* w = (const float4*)a.w[l];
             const int nq_in = (l == 0) ? (kx >> 2) : NT;          // quads of the input segment
             const float* bin;
             if (l == 0) bin = (XMODE == 0) ? a.x_tileb + ((size_t)(rowtile * a.T + t) * kx) * 64 + lane : xs;
@@ -588,11 +598,11 @@ lstm_kernel(const LstmSeqArgs a) {
                         acc[i][4 * v + 0] = x.x; acc[i][4 * v + 1] = x.y; acc[i][4 * v + 2] = x.z; acc[i][4 * v + 3] = x.w;
                     }
                 }
-                gemm_seg<OWN>(acc, w, toff, NT * 64, bin, nq_in);
+                gemm_seg<OWN>(acc, w, lane, toff, NT * 64, bin, nq_in);
             } else {
                 load_bias<OWN>(acc, a.b[l], toff, hh);
-                gemm_seg<OWN>(acc, w, toff, NT * 64, bin, nq_in);
-                gemm_seg<OWN>(acc, w + (size_t)nq_in * NT * 64, toff, NT * 64, hl, NT);
+                gemm_seg<OWN>(acc, w, lane, toff, NT * 64, bin, nq_in);
+                gemm_seg<OWN>(acc, w + (size_t)nq_in * NT * 64, lane, toff, NT * 64, hl, NT);
             }
             lstm_cell<SAVE, OWN>(acc, c[l], hn);
             if (SAVE) {
@@ -671,7 +681,7 @@ lstm_kernel(const LstmSeqArgs a) {
             f32x16 acc[OWN];
             const int nq_in = (l == 0) ? (kx >> 2) : NT;
             load_bias<OWN>(acc, a.b[l], toff, hh);
-            gemm_seg<OWN>(acc, (const float4*)a.w[l] + lane + (size_t)nq_in * NT * 64, toff, NT * 64,
+            gemm_seg<OWN>(acc, (const float4*)a.w[l] + (size_t)nq_in * NT * 64, lane, toff, NT * 64,
                            hb + (size_t)l * HPK * 64, NT);
             if (row_ok) {
 #pragma unroll
@@ -709,7 +719,7 @@ __device__ __forceinline__ void dense_bwd_layer(const DenseBwdLayer& ly, float* 
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[i][r] = 0.0f;
     }
-    gemm_seg<NT>(acc, (const float4*)ly.wT + lane, toff, NT * 64, col, ly.nqT);
+    gemm_seg<NT>(acc, (const float4*)ly.wT, lane, toff, NT * 64, col, ly.nqT);
 #pragma unroll
     for (int tt = 0; tt < NT; ++tt)
 #pragma unroll
@@ -817,10 +827,10 @@ __global__ void __launch_bounds__(256, 1) lstm_bwd_kernel(const LstmBwdArgs a) {
             } else {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[0][r] = 0.0f;
-                gemm_seg<1>(acc, (const float4*)a.wT_in[l + 1] + lane, toff1, 4 * 64, dg + (size_t)(l + 1) * GK * 64, 4 * NT);
+                gemm_seg<1>(acc, (const float4*)a.wT_in[l + 1], lane, toff1, 4 * 64, dg + (size_t)(l + 1) * GK * 64, 4 * NT);
             }
             if (t + 1 < a.T)
-                gemm_seg<1>(acc, (const float4*)a.wT_hh[l] + lane, toff1, 4 * 64, dg + (size_t)l * GK * 64, 4 * NT);
+                gemm_seg<1>(acc, (const float4*)a.wT_hh[l], lane, toff1, 4 * 64, dg + (size_t)l * GK * 64, 4 * NT);
             // cell backward for the 16 units of this lane
             float dgv[16][4];
             const float* sg = a.sv_gates + (inst * NL + l) * GK * 64 + lane;
@@ -873,7 +883,7 @@ __global__ void __launch_bounds__(256, 1) lstm_bwd_kernel(const LstmBwdArgs a) {
             f32x16 acc[1];
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[0][r] = 0.0f;
-            gemm_seg<1>(acc, (const float4*)a.wT_in[0] + lane, toff1, a.nt_x * 64, dg, 4 * NT);
+            gemm_seg<1>(acc, (const float4*)a.wT_in[0], lane, toff1, a.nt_x * 64, dg, 4 * NT);
             if (a.dx_tile) {
                 float* o = a.dx_tile + (inst * 64 + 16 * wave) * 64 + lane;
 #pragma unroll

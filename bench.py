@@ -156,6 +156,47 @@ def train_bench(dev, steps: int, cpu_steps: int):
     return out
 
 
+def other_workloads(eng, dev, L, X, C, S):
+    """Secondary, smaller legs of the same engine so the other BASELINE configs carry a measured
+    figure too (not the headline; one untimed + one timed pass each):
+    c3 prior at horizon 30, c3 oracle (posterior) MC, c4-shaped autoregressive 30-step rollouts."""
+    from vsv import paths
+    res = []
+
+    def timed(fn):
+        fn()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        fn()
+        torch.cuda.synchronize()
+        return time.perf_counter() - t0
+
+    def cal(n, extra=0):
+        v, e = synthetic_calendar(n + extra, C, X, seed=77)
+        return torch.from_numpy(v).to(dev), (torch.from_numpy(e).to(dev) if X else None)
+
+    n, H = 1000, 30
+    v, e = cal(n)
+    dt = timed(lambda: paths.prior_mc_windows(eng, v, e, C, n, C, H, S, seed=1, chunk_days=100))
+    res.append({"workload": f"c3 prior MC, context {C}, latent {L}, {n} days x {S} samples x horizon {H}",
+                "value": n * S * H / dt, "unit": "surfaces/s", "ms": dt * 1e3})
+    n, H = 500, 1
+    v, e = cal(n, H)
+    dt = timed(lambda: paths.oracle_mc_windows(eng, v, e, C, n, C, H, S, seed=1, chunk_days=50))
+    res.append({"workload": f"c3 oracle (posterior) MC, context {C}, latent {L}, {n} days x {S} samples x horizon {H} "
+                            f"(every sample decodes all {C + H} positions)",
+                "value": n * S * H / dt, "unit": "surfaces/s", "ms": dt * 1e3})
+    n, H, Sa, Ca = 8, 30, 10000, 20
+    va, ea = synthetic_calendar(n, Ca, X, seed=78)
+    va = torch.from_numpy(va).to(dev)
+    ea = torch.from_numpy(ea).to(dev) if X else None
+    dt = timed(lambda: paths.ar_mc_windows(eng, va, ea, Ca, n, Ca, H, Sa, seed=1, chunk_days=4))
+    res.append({"workload": f"c4-shaped autoregressive MC, context {Ca}, latent {L}, ex_feats {X}, {n} days x {Sa} "
+                            f"rollouts x {H} steps (each step re-encodes its own {Ca}-day window)",
+                "value": n * Sa * H / dt, "unit": "surfaces/s", "ms": dt * 1e3})
+    return res
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -171,6 +212,7 @@ def main():
     ap.add_argument("--cpu-budget", type=float, default=15.0, help="seconds of CPU baseline work (0 = skip)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL)")
     ap.add_argument("--train-steps", type=int, default=50, help="training steps of the secondary metric (0 = skip)")
+    ap.add_argument("--others", type=int, default=1, help="1 = also time the secondary workloads (N=1 only)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -273,6 +315,8 @@ def main():
         out["cpu_baseline"] = cpu_baseline(cfg, W, vol_np, ex_np, C, H, S, args.cpu_budget)
     if rank == 0 and args.train_steps > 0:
         out["train"] = train_bench(dev, args.train_steps, 10 if args.cpu_budget > 0 else 0)
+    if world == 1 and args.others:
+        out["other_workloads"] = other_workloads(eng, dev, L, X, C, S)
     if rank == 0:
         print(json.dumps(out), flush=True)
     if dist:

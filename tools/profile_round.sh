@@ -12,10 +12,10 @@ set -e
 timeout -k 10 300 python3 -u bench.py > $out/${tag}_bench.log 2>&1
 tail -1 $out/${tag}_bench.log > $out/${tag}_bench.json
 rm -rf $out/prof_$tag $out/pmcf_$tag $out/pmcw_$tag
-timeout -k 10 200 rocprofv3 --kernel-trace --stats -d $out/prof_$tag -o bench -- python3 bench.py --steps 5 --warmup 2 --cpu-budget 0 --train-steps 5 > $out/prof_$tag.log 2>&1
+timeout -k 10 200 rocprofv3 --kernel-trace --stats -d $out/prof_$tag -o bench -- python3 bench.py --steps 5 --warmup 2 --cpu-budget 0 --train-steps 5 --others 0 > $out/prof_$tag.log 2>&1
 python3 tools/rocpd_stats.py $(ls $out/prof_$tag/*.db | head -1) > $out/${tag}_kernel_stats.txt
-timeout -s KILL 120 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $out/pmcf_$tag -o p -- python3 bench.py --steps 1 --warmup 1 --cpu-budget 0 --train-steps 0 > $out/pmcf_$tag.log 2>&1
-timeout -s KILL 120 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $out/pmcw_$tag -o p -- python3 bench.py --steps 1 --warmup 1 --cpu-budget 0 --train-steps 0 > $out/pmcw_$tag.log 2>&1
+timeout -s KILL 120 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $out/pmcf_$tag -o p -- python3 bench.py --steps 1 --warmup 1 --cpu-budget 0 --train-steps 0 --others 0 > $out/pmcf_$tag.log 2>&1
+timeout -s KILL 120 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $out/pmcw_$tag -o p -- python3 bench.py --steps 1 --warmup 1 --cpu-budget 0 --train-steps 0 --others 0 > $out/pmcw_$tag.log 2>&1
 python3 - "$out" "$tag" <<'EOF'
 import csv, sys, collections
 out, tag = sys.argv[1:3]

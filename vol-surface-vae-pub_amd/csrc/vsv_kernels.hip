@@ -25,6 +25,20 @@
 
 namespace vsv {
 
+// Diagnostic build only (-DVSV_STAMPS, tools/stamps.sh): per-wave s_memtime stamps of the fused decode
+// kernel's phases, written to a buffer nothing else reads.
+#ifdef VSV_STAMPS
+constexpr int kStampWgs = 16384;
+__device__ unsigned long long g_stamps[(size_t)kStampWgs * 4 * 16];
+#define VSV_STAMP(i)                                                                                          \
+    do {                                                                                                      \
+        if (XMODE == 1 && HEAD && lane == 0 && blockIdx.x < kStampWgs)                                        \
+            g_stamps[((size_t)blockIdx.x * 4 + wave) * 16 + (i)] = __builtin_amdgcn_s_memtime();               \
+    } while (0)
+#else
+#define VSV_STAMP(i) do {} while (0)
+#endif
+
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 __device__ __forceinline__ f32x16 mfma32(float a, float b, f32x16 c) {
@@ -105,6 +119,51 @@ __device__ __forceinline__ void gemm_seg(f32x16 (&acc)[NC], const float4* __rest
     if (q < nq) quad_mfma<NC>(acc, a0, b, q);
 }
 
+// Pinned software pipeline for the 4-tiles-per-wave schedule: the A fragments (global, L2-resident) and the
+// B values (bl(q, bv): 4 k-steps of this lane's activation column) of quad q+1 are issued BEFORE the 16
+// MFMAs of quad q and the scheduler may not move anything across the fences, so a load has a full quad
+// (>= 1024 cycles of matrix work) to land.  a0 holds quad 0 on entry (wload by the caller, as early as
+// it likes); on exit a0 is free again.
+template <int NC>
+__device__ __forceinline__ void wload(float4 (&a)[NC], const float4* __restrict__ w, const unsigned (&o)[NC], unsigned qoff) {
+#pragma unroll
+    for (int i = 0; i < NC; ++i) a[i] = w[o[i] + qoff];
+}
+template <int NC>
+__device__ __forceinline__ void mfma_quad(f32x16 (&acc)[NC], const float4 (&a)[NC], const float (&b)[4]) {
+#pragma unroll
+    for (int i = 0; i < NC; ++i) acc[i] = mfma32(a[i].x, b[0], acc[i]);
+#pragma unroll
+    for (int i = 0; i < NC; ++i) acc[i] = mfma32(a[i].y, b[1], acc[i]);
+#pragma unroll
+    for (int i = 0; i < NC; ++i) acc[i] = mfma32(a[i].z, b[2], acc[i]);
+#pragma unroll
+    for (int i = 0; i < NC; ++i) acc[i] = mfma32(a[i].w, b[3], acc[i]);
+}
+template <int NC, typename BL>
+__device__ __forceinline__ void gemm_stream(f32x16 (&acc)[NC], float4 (&a0)[NC], const float4* __restrict__ w,
+                                            const unsigned (&o)[NC], int qstride, int nq, BL bl) {
+    float4 a1[NC];
+    float b0[4], b1[4];
+    bl(0, b0);
+    int q = 0;
+#pragma unroll 1
+    for (; q + 1 < nq; q += 2) {
+        wload<NC>(a1, w, o, (unsigned)((q + 1) * qstride));
+        bl(q + 1, b1);
+        __builtin_amdgcn_sched_barrier(0);
+        mfma_quad<NC>(acc, a0, b0);
+        __builtin_amdgcn_sched_barrier(0);
+        const int q2 = (q + 2 < nq) ? q + 2 : q + 1;
+        wload<NC>(a0, w, o, (unsigned)(q2 * qstride));
+        bl(q2, b0);
+        __builtin_amdgcn_sched_barrier(0);
+        mfma_quad<NC>(acc, a1, b1);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    if (q < nq) mfma_quad<NC>(acc, a0, b0);
+}
+
 // One output tile per wave (decoder head): the weights of the first kHalfQ quads are fetched by
 // the caller before it waits at the previous layer's barrier; while they are multiplied each
 // register is refilled with the quad kHalfQ further on, so the rest is in flight behind the MFMAs.
@@ -142,6 +201,13 @@ __device__ __forceinline__ void load_bias(f32x16 (&acc)[NC], const float* __rest
     }
 }
 
+// A copy of x the optimiser cannot see through.  Lane-dependent addresses derived from it are computed
+// in the phase that uses them instead of being hoisted above the time loop and parked in scratch.
+__device__ __forceinline__ int opaque(int x) {
+    asm volatile("" : "+v"(x));
+    return x;
+}
+
 __device__ __forceinline__ float fast_sigmoid(float x) { return __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
 __device__ __forceinline__ float fast_tanh(float x) {
     const float e = __expf(-2.0f * fabsf(x));
@@ -166,9 +232,10 @@ __device__ __forceinline__ float philox_normal_elem(uint32_t k0, uint32_t k1, ui
     const uint32_t xa = p ? c2 : c0, xb = p ? c3 : c1;
     const float u1 = ((float)(xa >> 9) + 0.5f) * 1.1920928955078125e-07f;   // 2^-23
     const float u2 = ((float)(xb >> 9) + 0.5f) * 1.1920928955078125e-07f;
-    const float r = sqrtf(-2.0f * logf(u1));
-    const float th = 6.283185307179586f * u2;
-    return (f & 1) ? r * sinf(th) : r * cosf(th);
+    // hardware transcendentals: v_log_f32 (log2), v_sqrt_f32, v_sin_f32 / v_cos_f32 (argument in turns, so
+    // u2 goes in unscaled); absolute error ~1e-6 on an N(0,1) draw, far below the KS test's resolution
+    const float r = __builtin_amdgcn_sqrtf(-1.3862943611198906f * __builtin_amdgcn_logf(u1));
+    return r * ((f & 1) ? __builtin_amdgcn_sinf(u2) : __builtin_amdgcn_cosf(u2));
 }
 
 // ---------------------------------------------------------------------------
@@ -303,7 +370,7 @@ __device__ __forceinline__ void dense_layer(const DenseChainArgs& a, const RowIo
 
 __global__ void __launch_bounds__(256, 2) dense_chain_kernel(const DenseChainArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const long inst = (long)blockIdx.x * 4 + wave;
     if (inst >= a.n_rowtiles * a.T) return;
     const long rowtile = inst / a.T;
@@ -439,60 +506,98 @@ __device__ __forceinline__ void lstm_cell(f32x16 (&acc)[OWN], float (&c)[OWN][4]
 // wave `wave`; activations ping-pong between two LDS buffers (64 slots each) with one barrier
 // per layer; the next layer's weights are fetched before that barrier.  Every wave of the
 // workgroup must call this.
+// The row's output pointers, computed where they are used (the epilogue of the layer that stores) from
+// the caller's opaque lane index: hoisted above the time loop, sixteen 64-bit store addresses per lane
+// were kept alive -- in scratch -- through every GEMM.
+__device__ __forceinline__ RowIo late_rowio(const DenseChainArgs& hd, long rowtile, int lane, int to) {
+    const int mv = lane & 31;
+    const long rr = rowtile * 32 + mv;
+    const bool ok = rr < hd.n_rows;
+    return make_rowio(hd, ok ? rr : hd.n_rows - 1, ok, to);
+}
+
 template <int NT>
-__device__ __forceinline__ void fused_head(const LstmSeqArgs& a, const float* htop, float* ha, int lane, int wave,
-                                           long row, bool row_ok, int to) {
+__device__ __forceinline__ void head_preload(const LstmSeqArgs& a, float4 (&wq)[kHalfQ], float4 (&bq)[4], int lane, int wave) {
     const DenseChainArgs& hd = a.head;
     const int hh = lane >> 5;
-    const RowIo io = make_rowio(hd, row, row_ok, to);
-    const int nl = hd.n_layers;
-    float4 wq[kHalfQ];
-    float4 bq[4];
-    {
-        const int tw = wave < hd.layer[0].nt ? wave : hd.layer[0].nt - 1;
-        tile_load<NT>(wq, (const float4*)hd.layer[0].w, tw * 64 + lane, hd.layer[0].nt * 64);
-        const float4* bp = (const float4*)(hd.layer[0].b + tw * 32 + hh * 16);
+    const int tw = wave < hd.layer[0].nt ? wave : hd.layer[0].nt - 1;
+    tile_load<NT>(wq, (const float4*)hd.layer[0].w, tw * 64 + lane, hd.layer[0].nt * 64);
+    const float4* bp = (const float4*)(hd.layer[0].b + tw * 32 + hh * 16);
 #pragma unroll
-        for (int v = 0; v < 4; ++v) bq[v] = bp[v];
-    }
-    const float* src = htop;
+    for (int v = 0; v < 4; ++v) bq[v] = bp[v];
+}
+
+// wq / bq: weights and bias of the first head layer, fetched by head_preload (before the last LSTM
+// layer's cell and barriers, so they have landed by now).  htop0 / ha0: LDS bases WITHOUT the lane
+// offset; every layer re-derives its lane-dependent addresses from an opaque copy of the lane index so
+// that they are not kept alive (in scratch) across the whole time loop.
+template <int NT>
+__device__ __forceinline__ void fused_head(const LstmSeqArgs& a, float4 (&wq)[kHalfQ], float4 (&bq)[4], const float* htop0,
+                                           float* ha0, int lane, int wave, long rowtile, int to) {
+    const DenseChainArgs& hd = a.head;
+    const int nl = hd.n_layers;
 #pragma unroll 1
     for (int li = 0; li < nl; ++li) {
+        int lv = lane;
+        asm volatile("" : "+v"(lv));
+        const int hh = lv >> 5;
         const DenseLayerArg& ly = hd.layer[li];
         const bool last = (li == nl - 1);
         const bool mine = wave < ly.nt;
-        float* dst = ha + (size_t)(li & 1) * kDenseSlots * 64;
+        const float* src = (li == 0 ? htop0 : ha0 + (size_t)((li - 1) & 1) * kDenseSlots * 64) + lv;
+        float* dst = ha0 + (size_t)(li & 1) * kDenseSlots * 64 + lv;
         f32x16 acc[1];
 #pragma unroll
         for (int v = 0; v < 4; ++v) {
             acc[0][4 * v + 0] = bq[v].x; acc[0][4 * v + 1] = bq[v].y; acc[0][4 * v + 2] = bq[v].z; acc[0][4 * v + 3] = bq[v].w;
         }
         if (mine) {
-            const unsigned off = wave * 64 + lane;
+            const unsigned off = wave * 64 + lv;
             if (li == 0) tile_mfma<NT>(acc[0], wq, (const float4*)ly.w, off, ly.nt * 64, src);
             else tile_mfma<4 * kHeadTiles>(acc[0], wq, (const float4*)ly.w, off, ly.nt * 64, src);
         }
         if (!last) {
             const DenseLayerArg& nx = hd.layer[li + 1];
             const int tw = wave < nx.nt ? wave : nx.nt - 1;
-            tile_load<4 * kHeadTiles>(wq, (const float4*)nx.w, tw * 64 + lane, nx.nt * 64);
+            tile_load<4 * kHeadTiles>(wq, (const float4*)nx.w, tw * 64 + lv, nx.nt * 64);
             const float4* bp = (const float4*)(nx.b + tw * 32 + hh * 16);
 #pragma unroll
             for (int v = 0; v < 4; ++v) bq[v] = bp[v];
         }
         if (mine) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int f = feat_of(wave, r, hh);
-                float v = acc[0][r];
-                if (f < ly.n_relu) v = fmaxf(v, 0.0f);
-                if (li == hd.aux_layer && io.aux && f >= hd.aux_f0 && f < hd.aux_f0 + hd.aux_n) io.aux[f] = v;
-                if (!last) dst[(16 * wave + r) * 64] = v;
-                else if (io.out && f < hd.out_f) io.out[(size_t)f * io.fstride] = v;
+            for (int r = 0; r < 16; ++r)
+                if (feat_of(wave, r, hh) < ly.n_relu) acc[0][r] = fmaxf(acc[0][r], 0.0f);
+            if (!last) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) dst[(16 * wave + r) * 64] = acc[0][r];
+            }
+            const bool do_aux = (li == hd.aux_layer) && hd.aux != nullptr;
+            if (do_aux || last) {
+                const RowIo io = late_rowio(hd, rowtile, lv, to);
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int f0 = 32 * wave + 8 * g;                     // wave-uniform group of 8 features
+                    if (do_aux && io.aux && f0 + 8 > hd.aux_f0 && f0 < hd.aux_f0 + hd.aux_n) {
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) {
+                            const int f = f0 + 4 * hh + k;
+                            if (f >= hd.aux_f0 && f < hd.aux_f0 + hd.aux_n) io.aux[f] = acc[0][4 * g + k];
+                        }
+                    }
+                    if (last && io.out && f0 < hd.out_f) {
+                        float* po = io.out + (size_t)(f0 + 4 * hh) * io.fstride;
+#pragma unroll
+                        for (int k = 0; k < 4; ++k)
+                            if (f0 + 4 * hh + k < hd.out_f) po[(size_t)k * io.fstride] = acc[0][4 * g + k];
+                    }
+                }
             }
         }
         if (!last) __syncthreads();
-        src = dst;
+#ifdef VSV_STAMPS
+        if (lane == 0 && blockIdx.x < kStampWgs) g_stamps[((size_t)blockIdx.x * 4 + wave) * 16 + 8 + li] = __builtin_amdgcn_s_memtime();
+#endif
     }
 }
 
@@ -508,7 +613,13 @@ lstm_kernel(const LstmSeqArgs a) {
     constexpr int NW = (OWN == 4) ? 4 : NT;                       // waves per workgroup
     constexpr int HPK = 4 * NT;                                   // k-steps of one layer's h
     constexpr int HP = 8 * NT;                                    // padded hidden units
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    VSV_STAMP(0);
+#ifdef VSV_STAMPS
+    if (XMODE == 1 && HEAD && lane == 0 && blockIdx.x < kStampWgs)
+        g_stamps[((size_t)blockIdx.x * 4 + wave) * 16 + 15] =
+            (unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 4) | ((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 20) << 32);
+#endif
     const long rowtile = (long)blockIdx.x;
     const int hh = lane >> 5, m = lane & 31;
     const long row_raw = rowtile * 32 + m;
@@ -516,18 +627,23 @@ lstm_kernel(const LstmSeqArgs a) {
     const long row = row_ok ? row_raw : a.n_rows - 1;
     const int kx = a.kx;
     const int xk = (XMODE == 0) ? 0 : kx;                         // x k-steps staged in LDS (decoder only)
-    float* xs = smem + lane;
-    float* hb = xs + (size_t)xk * 64;                             // h of layer l: hb + l*HPK*64
-    float* ha = hb + (size_t)NL * HPK * 64;                       // head activations (HEAD only)
+    float* const xs0 = smem;                                      // LDS bases without the lane offset
+    float* const hb0 = xs0 + (size_t)xk * 64;                     // h of layer l: hb + l*HPK*64
+    float* const ha0 = hb0 + (size_t)NL * HPK * 64;               // head activations (HEAD only)
+    float* const xs = xs0 + lane;                                 // prologue / epilogue views
+    float* const hb = hb0 + lane;
 
     // gate tiles of this wave; out-of-range ones are computed on a clamped tile and never stored
+    constexpr bool ALLV = (OWN * NW == NT);                       // every wave owns OWN existing tiles
     int toff[OWN];
+    unsigned wo[OWN];
     bool tval[OWN];
 #pragma unroll
     for (int i = 0; i < OWN; ++i) {
         const int tl = wave + NW * i;
-        tval[i] = tl < NT;
+        tval[i] = ALLV || tl < NT;
         toff[i] = (tval[i] ? tl : NT - 1) * 64;
+        wo[i] = (unsigned)lane + (unsigned)toff[i];
     }
 
     DecIn di = {};
@@ -542,28 +658,64 @@ lstm_kernel(const LstmSeqArgs a) {
         if (d.gate_in) gate_in = d.gate_in + (size_t)(row / d.state_div) * NL * NT * 32;
     }
 
+    // Gate accumulators start from the bias, or (first step from a shared state) from bias + W_hh . h_prev,
+    // computed once per state row.  The loads are issued one stage early -- at kernel entry, or right
+    // after the previous layer's cell has consumed the accumulators -- so the barriers hide them.
+    f32x16 acc[OWN];
+    float4 a0[OWN];                                               // quad 0 of the next gate GEMM (OWN == 4)
+    auto acc_init = [&](int l, bool shared, int lv) {
+        const int hh = lv >> 5;
+        const float* p0 = shared ? gate_in + (size_t)l * NT * 32 : a.b[l];
+#pragma unroll
+        for (int i = 0; i < OWN; ++i) {
+            const float4* p = (const float4*)(p0 + (toff[i] >> 6) * 32 + hh * 16);
+#pragma unroll
+            for (int v = 0; v < 4; ++v) {
+                const float4 x = p[v];
+                acc[i][4 * v + 0] = x.x; acc[i][4 * v + 1] = x.y; acc[i][4 * v + 2] = x.z; acc[i][4 * v + 3] = x.w;
+            }
+        }
+    };
+    const bool shared0 = (XMODE == 1) && gate_in != nullptr;
+    acc_init(0, shared0, lane);
+    if (OWN == 4) wload<OWN>(a0, (const float4*)a.w[0], wo, 0u);
+
+    // state: (h | c) per layer, each HP floats in lane order (position 8*tile + 4*hh + jj holds unit
+    // 8*tile + 2*jj + hh), so a lane's four units of a tile are one float4
     float c[NL][OWN][4];
     {
         const float* st = nullptr;
         if (XMODE == 1 && a.din.state_in) st = a.din.state_in + (size_t)(row / a.din.state_div) * NL * 2 * HP;
+        float4 hv[NL][OWN], cv[NL][OWN];
 #pragma unroll
-        for (int l = 0; l < NL; ++l) {
+        for (int l = 0; l < NL; ++l)
 #pragma unroll
             for (int i = 0; i < OWN; ++i) {
-                const int tl = wave + NW * i;
+                hv[l][i] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+                cv[l][i] = hv[l][i];
+            }
+        if (st) {
+#pragma unroll
+            for (int l = 0; l < NL; ++l)
+#pragma unroll
+                for (int i = 0; i < OWN; ++i) {
+                    const float* ps = st + (size_t)l * 2 * HP + (toff[i] >> 3) + 4 * hh;
+                    if (!gate_in) hv[l][i] = *(const float4*)ps;      // with gate_in the old h is never read
+                    cv[l][i] = *(const float4*)(ps + HP);
+                }
+        }
+#pragma unroll
+        for (int l = 0; l < NL; ++l)
+#pragma unroll
+            for (int i = 0; i < OWN; ++i) {
+                const float hq[4] = {hv[l][i].x, hv[l][i].y, hv[l][i].z, hv[l][i].w};
+                const float cq[4] = {cv[l][i].x, cv[l][i].y, cv[l][i].z, cv[l][i].w};
 #pragma unroll
                 for (int jj = 0; jj < 4; ++jj) {
-                    float h0 = 0.0f, c0 = 0.0f;
-                    if (st && tval[i]) {
-                        const int u = 8 * tl + 2 * jj + hh;
-                        if (!gate_in) h0 = st[(size_t)l * 2 * HP + u];   // with gate_in the old h is never read
-                        c0 = st[(size_t)l * 2 * HP + HP + u];
-                    }
-                    if (tval[i]) hb[(l * HPK + 4 * tl + jj) * 64] = h0;
-                    c[l][i][jj] = c0;
+                    if (tval[i]) hb[(l * HPK + (toff[i] >> 4) + jj) * 64] = hq[jj];
+                    c[l][i][jj] = tval[i] ? cq[jj] : 0.0f;
                 }
             }
-        }
     }
     // x part of layer 0 for step 0 (slots wave, wave+4, ...: the waves share the assembly)
     if (XMODE == 1) {
@@ -574,37 +726,65 @@ lstm_kernel(const LstmSeqArgs a) {
         }
     }
     __syncthreads();
+    VSV_STAMP(1);
 
     const int t_outs = a.T - a.t_out0;
+    float4 wq[HEAD ? kHalfQ : 1], bq[HEAD ? 4 : 1];               // first head layer, fetched ahead
     for (int t = 0; t < a.T; ++t) {
+        const bool shared = shared0 && t == 0;
+        const bool head_now = HEAD && t >= a.t_out0;
 #pragma unroll
         for (int l = 0; l < NL; ++l) {
-            f32x16 acc[OWN];
             float hn[OWN][4];
             const float4* w = (const float4*)a.w[l];
             const int nq_in = (l == 0) ? (kx >> 2) : NT;          // quads of the input segment
-            const float* bin;
-            if (l == 0) bin = (XMODE == 0) ? a.x_tileb + ((size_t)(rowtile * a.T + t) * kx) * 64 + lane : xs;
-            else bin = hb + (size_t)(l - 1) * HPK * 64;
+            const int lv = opaque(lane);
+            float* const xs = xs0 + lv;
+            float* const hb = hb0 + lv;
             float* hl = hb + (size_t)l * HPK * 64;
-            if (XMODE == 1 && t == 0 && gate_in) {
-                // first step from a shared state: bias + W_hh . h_prev was computed once per state row
+            unsigned wo[OWN];
 #pragma unroll
-                for (int i = 0; i < OWN; ++i) {
-                    const float4* p = (const float4*)(gate_in + ((size_t)l * NT + (toff[i] >> 6)) * 32 + hh * 16);
+            for (int i = 0; i < OWN; ++i) wo[i] = (unsigned)lv + (unsigned)toff[i];
+            if constexpr (OWN == 4) {
+                // one A stream over [input part | recurrent part]; a shared first step has no recurrent part
+                const int nq = shared ? nq_in : nq_in + NT;
+                if constexpr (XMODE == 0) {
+                    if (l == 0) {
+                        const float* xg = a.x_tileb + ((size_t)(rowtile * a.T + t) * kx) * 64 + lv;
+                        gemm_stream<OWN>(acc, a0, w, wo, NT * 64, nq, [&](int q, float (&bv)[4]) {
+                            if (q < nq_in) {
 #pragma unroll
-                    for (int v = 0; v < 4; ++v) {
-                        const float4 x = p[v];
-                        acc[i][4 * v + 0] = x.x; acc[i][4 * v + 1] = x.y; acc[i][4 * v + 2] = x.z; acc[i][4 * v + 3] = x.w;
+                                for (int j = 0; j < 4; ++j) bv[j] = xg[(4 * q + j) * 64];
+                            } else {
+#pragma unroll
+                                for (int j = 0; j < 4; ++j) bv[j] = hl[(4 * (q - nq_in) + j) * 64];
+                            }
+                        });
                     }
                 }
-                gemm_seg<OWN>(acc, w, lane, toff, NT * 64, bin, nq_in);
+                if (XMODE == 1 || l > 0) {
+                    const float* bin = (l == 0) ? xs : hb + (size_t)(l - 1) * HPK * 64;
+                    gemm_stream<OWN>(acc, a0, w, wo, NT * 64, nq, [&](int q, float (&bv)[4]) {
+                        const float* bp = (q < nq_in) ? bin + (size_t)(4 * q) * 64 : hl + (size_t)(4 * (q - nq_in)) * 64;
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) bv[j] = bp[j * 64];
+                    });
+                }
+                if (l + 1 < NL) wload<OWN>(a0, (const float4*)a.w[l + 1], wo, 0u);
+                else if (!head_now && t + 1 < a.T) wload<OWN>(a0, (const float4*)a.w[0], wo, 0u);
             } else {
-                load_bias<OWN>(acc, a.b[l], toff, hh);
-                gemm_seg<OWN>(acc, w, lane, toff, NT * 64, bin, nq_in);
-                gemm_seg<OWN>(acc, w + (size_t)nq_in * NT * 64, lane, toff, NT * 64, hl, NT);
+                const float* bin;
+                if (l == 0) bin = (XMODE == 0) ? a.x_tileb + ((size_t)(rowtile * a.T + t) * kx) * 64 + lv : xs;
+                else bin = hb + (size_t)(l - 1) * HPK * 64;
+                gemm_seg<OWN>(acc, w, lv, toff, NT * 64, bin, nq_in);
+                if (!shared) gemm_seg<OWN>(acc, w + (size_t)nq_in * NT * 64, lv, toff, NT * 64, hl, NT);
             }
+            if constexpr (HEAD) {
+                if (l == NL - 1 && head_now) head_preload<NT>(a, wq, bq, opaque(lane), wave);
+            }
+            VSV_STAMP(2 + 3 * l);
             lstm_cell<SAVE, OWN>(acc, c[l], hn);
+            VSV_STAMP(3 + 3 * l);
             if (SAVE) {
                 const size_t il = (size_t)(rowtile * a.T + t) * NL + l;
                 float* sg = a.sv_gates + il * (16 * NT) * 64 + lane;
@@ -623,26 +803,33 @@ lstm_kernel(const LstmSeqArgs a) {
                     }
                 }
             }
-            // h of this layer is overwritten only after every wave has read the old one
-            __syncthreads();
+            // the accumulators are free: start the next stage's initial values
+            if (l + 1 < NL) acc_init(l + 1, shared, opaque(lane));
+            else if (!head_now && t + 1 < a.T) acc_init(0, false, opaque(lane));
+            // h of this layer is overwritten only after every wave has read the old one (a shared first
+            // step has no recurrent product, so nobody reads it)
+            if (!shared) __syncthreads();
+            const int lw = opaque(lane);
+            float* const hlw = hb0 + lw + (size_t)l * HPK * 64;
 #pragma unroll
             for (int i = 0; i < OWN; ++i) {
                 if (tval[i]) {
 #pragma unroll
-                    for (int jj = 0; jj < 4; ++jj) hl[((toff[i] >> 4) + jj) * 64] = hn[i][jj];
+                    for (int jj = 0; jj < 4; ++jj) hlw[((toff[i] >> 4) + jj) * 64] = hn[i][jj];
                 }
             }
             if (XMODE == 1 && l == NL - 1 && t + 1 < a.T) {
                 // x part of the NEXT step: xs was last read before this layer's first barrier
                 for (int s = wave; s < kx; s += NW) {
-                    const float v = decoder_input(a, di, row, row_ok, true, t + 1, 2 * s + hh);
-                    xs[s * 64] = v;
+                    const float v = decoder_input(a, di, row, row_ok, true, t + 1, 2 * s + (lw >> 5));
+                    (xs0 + lw)[s * 64] = v;
                     if (SAVE) a.sv_x[((size_t)(rowtile * a.T + t + 1) * kx + s) * 64 + lane] = v;
                 }
             }
             __syncthreads();
+            VSV_STAMP(4 + 3 * l);
         }
-        const float* htop = hb + (size_t)(NL - 1) * HPK * 64;
+        const float* htop = hb0 + lane + (size_t)(NL - 1) * HPK * 64;
         // ---- outputs
         if (a.hout && t >= a.t_out0) {
             float* ho = a.hout + ((size_t)(rowtile * t_outs + (t - a.t_out0)) * HPK) * 64 + lane;
@@ -654,8 +841,23 @@ lstm_kernel(const LstmSeqArgs a) {
                 }
             }
         }
-        if (HEAD && t >= a.t_out0) fused_head<NT>(a, htop, ha, lane, wave, row, row_ok, t - a.t_out0);
+        if constexpr (HEAD) {
+            if (head_now) {
+                fused_head<NT>(a, wq, bq, hb0 + (size_t)(NL - 1) * HPK * 64, ha0, lane, wave, rowtile, t - a.t_out0);
+                if (t + 1 < a.T) {
+                    const int ln = opaque(lane);
+                    acc_init(0, false, ln);
+                    if (OWN == 4) {
+                        unsigned wn[OWN];
+#pragma unroll
+                        for (int i = 0; i < OWN; ++i) wn[i] = (unsigned)ln + (unsigned)toff[i];
+                        wload<OWN>(a0, (const float4*)a.w[0], wn, 0u);
+                    }
+                }
+            }
+        }
     }
+    VSV_STAMP(13);
     if (a.state_out && row_ok) {
 #pragma unroll
         for (int l = 0; l < NL; ++l) {
@@ -663,12 +865,10 @@ lstm_kernel(const LstmSeqArgs a) {
 #pragma unroll
             for (int i = 0; i < OWN; ++i) {
                 if (tval[i]) {
-#pragma unroll
-                    for (int jj = 0; jj < 4; ++jj) {
-                        const int u = 2 * ((toff[i] >> 4) + jj) + hh;
-                        st[u] = hb[(l * HPK + (toff[i] >> 4) + jj) * 64];
-                        st[HP + u] = c[l][i][jj];
-                    }
+                    const int s0 = l * HPK + (toff[i] >> 4);
+                    *(float4*)(st + (toff[i] >> 3) + 4 * hh) =
+                        make_float4(hb[(s0 + 0) * 64], hb[(s0 + 1) * 64], hb[(s0 + 2) * 64], hb[(s0 + 3) * 64]);
+                    *(float4*)(st + HP + (toff[i] >> 3) + 4 * hh) = make_float4(c[l][i][0], c[l][i][1], c[l][i][2], c[l][i][3]);
                 }
             }
         }
@@ -729,7 +929,7 @@ __device__ __forceinline__ void dense_bwd_layer(const DenseBwdLayer& ly, float* 
 
 __global__ void __launch_bounds__(256, 2) dense_bwd_kernel(const DenseBwdArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const long inst = (long)blockIdx.x * 4 + wave;
     if (inst >= a.n_rowtiles * a.T) return;
     const long rowtile = inst / a.T;
@@ -794,7 +994,7 @@ template <int NT, int NL>
 __global__ void __launch_bounds__(256, 1) lstm_bwd_kernel(const LstmBwdArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int GK = 16 * NT;                                   // k-steps of one layer's gate rows
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const long rowtile = (long)blockIdx.x;
     const int hh = lane >> 5, m = lane & 31;
     const long row_raw = rowtile * 32 + m;
@@ -1261,6 +1461,13 @@ extern "C" int vsv_decode(const vsv_dims* dims, const float* packed, const vsv_d
     if (ev1) (void)hipEventRecord(ev1, st);
     return rc;
 }
+
+#ifdef VSV_STAMPS
+extern "C" int vsv_debug_stamps(unsigned long long* host_out, size_t n) {
+    if (n > sizeof(g_stamps) / 8) n = sizeof(g_stamps) / 8;
+    return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_stamps), n * 8);
+}
+#endif
 
 extern "C" void vsv_profile_next_decode(void* ev_start, void* ev_stop) {
     g_prof_ev[0] = (hipEvent_t)ev_start;

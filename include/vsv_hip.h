@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define VSV_ABI_VERSION 3
+#define VSV_ABI_VERSION 4
 #define VSV_MAX_CONV 4
 #define VSV_MAX_CHAIN 6
 
@@ -155,11 +155,17 @@ int vsv_decode(const vsv_dims *dims, const float *packed, const vsv_decode_in *i
 /* ---- MC reduction ------------------------------------------------------------
  * np.percentile(x, q, axis=samples) with linear interpolation -- the MC->quantile
  * convention of experiments/bootstrap_baseline/generate_bootstrap_autoregressive.py:194-199.
- * in: (n_vec, S) sample-minor.  out[(v / inner)*nq*inner + k*inner + v % inner] is
- * the k-th percentile of vector v (inner = 25 gives (..., nq, 5, 5) per (day, step)).
- * q_host: nq percentiles in [0,100] (host).  S <= 16384. */
+ * in: sample-minor vectors of S floats; vector v = (group g = v / inner, i = v % inner) starts at
+ * in + (g*group_stride + i)*S, so group_stride = inner is a dense (n_vec, S) array and
+ * group_stride = Q*25 with in offset by channel*25*S reduces ONE decoder channel of the
+ * (days, steps, Q*25, S) tensor vsv_decode writes, in place.
+ * out[(v / inner)*nq*inner + k*inner + v % inner] is the k-th percentile of vector v
+ * (inner = 25 gives (..., nq, 5, 5) per (day, step)).  q_host: nq percentiles in [0,100] (host).
+ * S <= 1024: one wavefront sorts a vector in registers (bitonic network, cross-lane exchanges);
+ * S <= 16384: one workgroup per vector, sorted in LDS.  A NaN sample is ordered arbitrarily
+ * (np.percentile would return NaN). */
 int vsv_percentile(const float *in, long n_vec, int S, const double *q_host, int nq,
-                   int inner, float *out, void *stream);
+                   int inner, long group_stride, float *out, void *stream);
 
 /* ---- noise ---------------------------------------------------------------------
  * The eps the decoder draws in Philox mode, materialised: out (n_days*S, n_steps, L).

@@ -126,7 +126,8 @@ def test_percentile_matches_numpy():
     cfg = vo.make_config(5, 0)
     eng, _ = _engine(cfg, 0, 1.0)
     rng = np.random.default_rng(1)
-    for S in (1000, 10000, 37, 1, 2):
+    # S <= 1024: wavefront-level register sort (every lane-count class and its edges); above: LDS sort
+    for S in (1000, 10000, 37, 1, 2, 3, 63, 64, 65, 128, 200, 256, 300, 512, 513, 1023, 1024, 1025, 2048):
         x = rng.standard_normal((4, 25, S)).astype(np.float32)
         got = _n(eng.percentile(_t(x), (5, 50, 95), inner=25))          # (4, 3, 25)
         want = np.percentile(x.astype(np.float64), [5, 50, 95], axis=-1).transpose(1, 0, 2)
@@ -138,6 +139,19 @@ def test_percentile_matches_numpy():
     got = _n(eng.percentile(_t(x), (5, 50, 95), inner=25))
     want = np.percentile(x, [5, 50, 95], axis=-1).transpose(1, 0, 2)
     assert err(got, want) <= 1e-7
+    # one decoder channel of a (groups, Q*25, S) tensor, read in place through the group stride
+    for S in (1000, 5000):
+        x = rng.standard_normal((6, 3, 25, S)).astype(np.float32)
+        for ch in range(3):
+            got = _n(eng.percentile(_t(x).view(6, 75, S), (5, 50, 95), inner=25, channel=ch, n_channels=3))
+            want = np.percentile(x[:, ch].astype(np.float64), [5, 50, 95], axis=-1).transpose(1, 0, 2)
+            assert got.shape == want.shape and err(got, want) <= 1e-6, (S, ch)
+    # other percentile sets, including the extremes
+    x = rng.standard_normal((2, 25, 777)).astype(np.float32)
+    qs = (0, 1, 25, 33.3, 75, 99, 100)
+    got = _n(eng.percentile(_t(x), qs, inner=25))
+    want = np.percentile(x.astype(np.float64), list(qs), axis=-1).transpose(1, 0, 2)
+    assert err(got, want) <= 1e-6
 
 
 def test_philox_matches_oracle_and_fused_mode():

@@ -28,13 +28,13 @@ vol, ex = torch.from_numpy(v).to(dev), torch.from_numpy(e).to(dev)
 for _ in range(3):
     paths.prior_mc_windows(eng, vol, ex, C, N, C, H, S, seed=0, chunk_days=500)
 torch.cuda.synchronize()
-n = 16384 * 4 * 16
+n = 16384 * 4 * 32
 buf = (ctypes.c_ulonglong * n)()
 eng.lib.vsv_debug_stamps.argtypes = [ctypes.c_void_p, ctypes.c_size_t]
 eng.lib.vsv_debug_stamps.restype = ctypes.c_int
 rc = eng.lib.vsv_debug_stamps(buf, n)
 assert rc == 0, rc
-st = np.frombuffer(buf, dtype=np.uint64).reshape(16384, 4, 16)[: (N * S + 31) // 32].astype(np.int64)
+st = np.frombuffer(buf, dtype=np.uint64).reshape(16384, 4, 32)[: (N * S + 31) // 32].astype(np.int64)
 names = ["prologue", "L0 gemm", "L0 cell", "L0 barriers", "L1 gemm", "L1 cell", "L1 barriers",
          "head0", "head1", "head2", "head3", "head4", "tail"]
 t = st[:, :, :14]
@@ -43,6 +43,11 @@ print("phase                median    p10     p90   (cycles per wave)")
 for i, nm in enumerate(names):
     x = d[:, :, i].ravel()
     print(f"{nm:18s} {np.median(x):9.0f} {np.percentile(x, 10):7.0f} {np.percentile(x, 90):7.0f}")
+pro = st[:, :, [0, 16, 17, 18, 1]]
+dp = np.diff(pro, axis=2)
+for i, nm in enumerate(["  setup (ids, divisions)", "  gate/weight/state loads + h init", "  x assembly (Philox)", "  barrier"]):
+    x = dp[:, :, i].ravel()
+    print(f"{nm:34s} {np.median(x):9.0f} {np.percentile(x, 10):7.0f} {np.percentile(x, 90):7.0f}")
 life = (t[:, :, 13] - t[:, :, 0]).ravel()
 print(f"wave lifetime      {np.median(life):9.0f} {np.percentile(life, 10):7.0f} {np.percentile(life, 90):7.0f}")
 hw = st[:, 0, 15]

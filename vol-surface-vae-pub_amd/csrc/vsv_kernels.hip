@@ -29,11 +29,11 @@ namespace vsv {
 // kernel's phases, written to a buffer nothing else reads.
 #ifdef VSV_STAMPS
 constexpr int kStampWgs = 16384;
-__device__ unsigned long long g_stamps[(size_t)kStampWgs * 4 * 16];
+__device__ unsigned long long g_stamps[(size_t)kStampWgs * 4 * 32];
 #define VSV_STAMP(i)                                                                                          \
     do {                                                                                                      \
         if (XMODE == 1 && HEAD && lane == 0 && blockIdx.x < kStampWgs)                                        \
-            g_stamps[((size_t)blockIdx.x * 4 + wave) * 16 + (i)] = __builtin_amdgcn_s_memtime();               \
+            g_stamps[((size_t)blockIdx.x * 4 + wave) * 32 + (i)] = __builtin_amdgcn_s_memtime();               \
     } while (0)
 #else
 #define VSV_STAMP(i) do {} while (0)
@@ -596,7 +596,7 @@ __device__ __forceinline__ void fused_head(const LstmSeqArgs& a, float4 (&wq)[kH
         }
         if (!last) __syncthreads();
 #ifdef VSV_STAMPS
-        if (lane == 0 && blockIdx.x < kStampWgs) g_stamps[((size_t)blockIdx.x * 4 + wave) * 16 + 8 + li] = __builtin_amdgcn_s_memtime();
+        if (lane == 0 && blockIdx.x < kStampWgs) g_stamps[((size_t)blockIdx.x * 4 + wave) * 32 + 8 + li] = __builtin_amdgcn_s_memtime();
 #endif
     }
 }
@@ -617,7 +617,7 @@ lstm_kernel(const LstmSeqArgs a) {
     VSV_STAMP(0);
 #ifdef VSV_STAMPS
     if (XMODE == 1 && HEAD && lane == 0 && blockIdx.x < kStampWgs)
-        g_stamps[((size_t)blockIdx.x * 4 + wave) * 16 + 15] =
+        g_stamps[((size_t)blockIdx.x * 4 + wave) * 32 + 15] =
             (unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 4) | ((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 20) << 32);
 #endif
     const long rowtile = (long)blockIdx.x;
@@ -648,14 +648,20 @@ lstm_kernel(const LstmSeqArgs a) {
 
     DecIn di = {};
     const float* gate_in = nullptr;
+    // rows fit 31 bits (checked by the launcher): 32-bit divisions; a divisor beyond that gives quotient 0
+    const uint32_t row32 = (uint32_t)row;
+    auto div32 = [](long dv) { return (uint32_t)(dv > 0x7fffffffL ? 0x7fffffffL : dv); };
+    uint32_t state_row = 0;
     if (XMODE == 1) {
         const vsv_decode_in& d = a.din;
-        di.ctx = d.ctx ? d.ctx + (row / d.ctx_div) * d.ctx_rs : nullptr;
-        di.z_idx = (row / d.z_div) * d.z_rs;
+        const uint32_t day_rel = row32 / div32(d.S);
+        di.ctx = d.ctx ? d.ctx + (long)(row32 / div32(d.ctx_div)) * d.ctx_rs : nullptr;
+        di.z_idx = (long)(row32 / div32(d.z_div)) * d.z_rs;
         di.eps = d.eps_in ? d.eps_in + (size_t)row * d.eps_T * a.L : nullptr;
-        di.sample = (uint32_t)(row % d.S);
-        di.day = (uint32_t)(d.day0 + row / d.S);
-        if (d.gate_in) gate_in = d.gate_in + (size_t)(row / d.state_div) * NL * NT * 32;
+        di.sample = row32 - day_rel * div32(d.S);
+        di.day = (uint32_t)d.day0 + day_rel;
+        state_row = row32 / div32(d.state_div);
+        if (d.gate_in) gate_in = d.gate_in + (size_t)state_row * NL * NT * 32;
     }
 
     // Gate accumulators start from the bias, or (first step from a shared state) from bias + W_hh . h_prev,
@@ -676,7 +682,8 @@ lstm_kernel(const LstmSeqArgs a) {
             }
         }
     };
-    const bool shared0 = (XMODE == 1) && gate_in != nullptr;
+    const bool shared0 = (XMODE == 1) && a.din.gate_in != nullptr;      // wave-uniform
+    VSV_STAMP(16);
     acc_init(0, shared0, lane);
     if (OWN == 4) wload<OWN>(a0, (const float4*)a.w[0], wo, 0u);
 
@@ -684,8 +691,8 @@ lstm_kernel(const LstmSeqArgs a) {
     // 8*tile + 2*jj + hh), so a lane's four units of a tile are one float4
     float c[NL][OWN][4];
     {
-        const float* st = nullptr;
-        if (XMODE == 1 && a.din.state_in) st = a.din.state_in + (size_t)(row / a.din.state_div) * NL * 2 * HP;
+        const bool has_state = (XMODE == 1) && a.din.state_in != nullptr;  // wave-uniform
+        const float* st = has_state ? a.din.state_in + (size_t)state_row * NL * 2 * HP : nullptr;
         float4 hv[NL][OWN], cv[NL][OWN];
 #pragma unroll
         for (int l = 0; l < NL; ++l)
@@ -694,13 +701,13 @@ lstm_kernel(const LstmSeqArgs a) {
                 hv[l][i] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
                 cv[l][i] = hv[l][i];
             }
-        if (st) {
+        if (has_state) {
 #pragma unroll
             for (int l = 0; l < NL; ++l)
 #pragma unroll
                 for (int i = 0; i < OWN; ++i) {
                     const float* ps = st + (size_t)l * 2 * HP + (toff[i] >> 3) + 4 * hh;
-                    if (!gate_in) hv[l][i] = *(const float4*)ps;      // with gate_in the old h is never read
+                    if (!shared0) hv[l][i] = *(const float4*)ps;      // with gate_in the old h is never read
                     cv[l][i] = *(const float4*)(ps + HP);
                 }
         }
@@ -717,6 +724,7 @@ lstm_kernel(const LstmSeqArgs a) {
                 }
             }
     }
+    VSV_STAMP(17);
     // x part of layer 0 for step 0 (slots wave, wave+4, ...: the waves share the assembly)
     if (XMODE == 1) {
         for (int s = wave; s < kx; s += NW) {
@@ -725,6 +733,7 @@ lstm_kernel(const LstmSeqArgs a) {
             if (SAVE) a.sv_x[((size_t)(rowtile * a.T) * kx + s) * 64 + lane] = v;
         }
     }
+    VSV_STAMP(18);
     __syncthreads();
     VSV_STAMP(1);
 
@@ -1179,11 +1188,12 @@ struct PercArgs {
 };
 
 __global__ void __launch_bounds__(256) percentile_kernel(const float* __restrict__ in, long n_vec, int S, int P2,
-                                                         PercArgs pa, int inner, float* __restrict__ out) {
+                                                         PercArgs pa, int inner, long group_stride,
+                                                         float* __restrict__ out) {
     extern __shared__ __attribute__((aligned(16))) float buf[];
     const int tid = threadIdx.x;
     for (long v = blockIdx.x; v < n_vec; v += gridDim.x) {
-        const float* src = in + (size_t)v * S;
+        const float* src = in + ((size_t)(v / inner) * group_stride + (size_t)(v % inner)) * S;
         for (int i = tid; i < P2; i += 256) buf[i] = (i < S) ? src[i] : INFINITY;
         for (int k = 2; k <= P2; k <<= 1) {
             for (int j = k >> 1; j > 0; j >>= 1) {
@@ -1208,6 +1218,80 @@ __global__ void __launch_bounds__(256) percentile_kernel(const float* __restrict
         }
         __syncthreads();
     }
+}
+
+// Wavefront-level selection for S <= 1024: one wave sorts one vector entirely in registers (lane holds
+// the E consecutive elements lane*E .. lane*E+E-1 of the padded vector) with a bitonic network --
+// compare-exchanges at distance < E are register-to-register, the others one cross-lane exchange per
+// element -- no LDS traffic and no barriers; then the numpy 'linear' interpolation.
+template <int E>
+__global__ void __launch_bounds__(256) percentile_wave_kernel(const float* __restrict__ in, long n_vec, int S, PercArgs pa,
+                                                              int inner, long group_stride, float* __restrict__ out) {
+    const int lane = threadIdx.x & 63;
+    const long v = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (v >= n_vec) return;
+    const float* src = in + ((size_t)(v / inner) * group_stride + (size_t)(v % inner)) * S;
+    float x[E];
+    if (E >= 4 && (S & 3) == 0) {
+#pragma unroll
+        for (int e = 0; e < E; e += 4) {
+            const int i = lane * E + e;
+            float4 q = make_float4(INFINITY, INFINITY, INFINITY, INFINITY);
+            if (i < S) q = *(const float4*)(src + i);
+            x[e] = q.x; x[e + 1] = q.y; x[e + 2] = q.z; x[e + 3] = q.w;
+        }
+    } else {
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
+            const int i = lane * E + e;
+            x[e] = (i < S) ? src[i] : INFINITY;
+        }
+    }
+#pragma unroll
+    for (int k = 2; k <= 64 * E; k <<= 1) {
+#pragma unroll
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            if (j < E) {
+                // both elements in this lane; ascending block iff bit k of the element index is clear
+#pragma unroll
+                for (int e = 0; e < E; ++e) {
+                    if ((e & j) == 0) {
+                        const float lo = fminf(x[e], x[e | j]), hi = fmaxf(x[e], x[e | j]);
+                        const bool asc = (k < E) ? ((e & k) == 0) : ((lane & (k / E)) == 0);
+                        x[e] = asc ? lo : hi;
+                        x[e | j] = asc ? hi : lo;
+                    }
+                }
+            } else {
+                const int lm = j / E;                            // partner lane = lane ^ lm, same register
+                const bool asc = (k >= 64 * E) ? true : ((lane & (k / E)) == 0);
+                const bool keep_min = asc == ((lane & lm) == 0);
+#pragma unroll
+                for (int e = 0; e < E; ++e) {
+                    const float o = __shfl_xor(x[e], lm, 64);
+                    x[e] = keep_min ? fminf(x[e], o) : fmaxf(x[e], o);
+                }
+            }
+        }
+    }
+    // element i of the sorted vector is register i % E of lane i / E
+    float res = 0.0f;
+    for (int k = 0; k < pa.nq; ++k) {
+        const int lo = pa.lo[k];
+        const int hi = (lo + 1 < S) ? lo + 1 : S - 1;
+        float a = 0.0f, b = 0.0f;
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
+            if ((lo % E) == e) a = x[e];
+            if ((hi % E) == e) b = x[e];
+        }
+        a = __shfl(a, lo / E, 64);
+        b = __shfl(b, hi / E, 64);
+        const float d = b - a, fr = pa.fr[k];
+        const float r = (fr >= 0.5f) ? b - d * (1.0f - fr) : a + d * fr;
+        if (lane == k) res = r;
+    }
+    if (lane < pa.nq) out[(size_t)(v / inner) * pa.nq * inner + (size_t)lane * inner + (v % inner)] = res;
 }
 
 __global__ void __launch_bounds__(256) philox_normal_kernel(uint64_t seed, long day0, long S, int step0, int n_steps,
@@ -1409,6 +1493,7 @@ extern "C" int vsv_decode(const vsv_dims* dims, const float* packed, const vsv_d
     if (!packed || !in) { set_error("vsv_decode: null pointer"); return -1; }
     if (n_rows < 0 || T < 0 || t_out0 < 0 || t_out0 > T) { set_error("vsv_decode: bad sizes"); return -1; }
     if (n_rows == 0 || T == 0) return 0;
+    if (n_rows > 0x7fffffffL) { set_error("vsv_decode: more than 2^31-1 rows in one call"); return -2; }
     const int touts = T - t_out0;
     if (touts > 0 && (!surf_out || !ws)) { set_error("vsv_decode: surf_out/ws null"); return -1; }
     if (touts > 0 && ws_bytes < vsv_decode_ws_bytes(dims, n_rows, T, t_out0)) { set_error("vsv_decode: workspace too small"); return -1; }
@@ -1474,13 +1559,22 @@ extern "C" void vsv_profile_next_decode(void* ev_start, void* ev_stop) {
     g_prof_ev[1] = (hipEvent_t)ev_stop;
 }
 
+template <int E>
+static void launch_percentile_wave(const float* in, long n_vec, int S, const PercArgs& pa, int inner, long group_stride,
+                                   float* out, hipStream_t st) {
+    hipLaunchKernelGGL(percentile_wave_kernel<E>, dim3((unsigned)((n_vec + 3) / 4)), dim3(256), 0, st, in, n_vec, S, pa,
+                       inner, group_stride, out);
+}
+
 extern "C" int vsv_percentile(const float* in, long n_vec, int S, const double* q_host, int nq,
-                              int inner, float* out, void* stream) {
+                              int inner, long group_stride, float* out, void* stream) {
     if (!in || !out || !q_host) { set_error("vsv_percentile: null pointer"); return -1; }
     if (nq < 1 || nq > 8) { set_error("vsv_percentile: nq must be in [1,8]"); return -1; }
     if (S < 1 || S > 16384) { set_error("vsv_percentile: S must be in [1,16384]"); return -1; }
     if (n_vec < 0 || inner < 1 || n_vec % inner != 0) { set_error("vsv_percentile: n_vec must be a multiple of inner"); return -1; }
+    if (group_stride < inner) { set_error("vsv_percentile: group_stride must be >= inner"); return -1; }
     if (n_vec == 0) return 0;
+    if ((n_vec + 3) / 4 > 0x7fffffffL) { set_error("vsv_percentile: too many vectors"); return -2; }
     PercArgs pa = {};
     pa.nq = nq;
     for (int i = 0; i < nq; ++i) {
@@ -1491,6 +1585,16 @@ extern "C" int vsv_percentile(const float* in, long n_vec, int S, const double* 
         pa.lo[i] = lo;
         pa.fr[i] = (float)(pos - lo);
     }
+    hipStream_t st = (hipStream_t)stream;
+    if (S <= 1024) {
+        // wavefront-level selection: a wave per vector, sorted in registers
+        if (S <= 64) launch_percentile_wave<1>(in, n_vec, S, pa, inner, group_stride, out, st);
+        else if (S <= 128) launch_percentile_wave<2>(in, n_vec, S, pa, inner, group_stride, out, st);
+        else if (S <= 256) launch_percentile_wave<4>(in, n_vec, S, pa, inner, group_stride, out, st);
+        else if (S <= 512) launch_percentile_wave<8>(in, n_vec, S, pa, inner, group_stride, out, st);
+        else launch_percentile_wave<16>(in, n_vec, S, pa, inner, group_stride, out, st);
+        return launch_check("percentile_wave_kernel");
+    }
     int P2 = 2;
     while (P2 < S) P2 <<= 1;
     const size_t lds = (size_t)P2 * sizeof(float);
@@ -1498,7 +1602,7 @@ extern "C" int vsv_percentile(const float* in, long n_vec, int S, const double* 
     if (rc) return rc;
     const long maxb = 256L * 16;
     const unsigned blocks = (unsigned)(n_vec < maxb ? n_vec : maxb);
-    hipLaunchKernelGGL(percentile_kernel, dim3(blocks), dim3(256), lds, (hipStream_t)stream, in, n_vec, S, P2, pa, inner, out);
+    hipLaunchKernelGGL(percentile_kernel, dim3(blocks), dim3(256), lds, st, in, n_vec, S, P2, pa, inner, group_stride, out);
     return launch_check("percentile_kernel");
 }
 
@@ -1570,7 +1674,7 @@ extern "C" int vsv_train_decode(const vsv_dims* dims, const float* packed, const
     VSV_LAYOUT_OR_FAIL("vsv_train_decode")
     if (!packed || !in || !sv || !surf_out) { set_error("vsv_train_decode: null pointer"); return -1; }
     if (!sv->xe || !sv->gates || !sv->c || !sv->h || !sv->hout || !sv->head_acts) { set_error("vsv_train_decode: incomplete save set"); return -1; }
-    if (n_rows < 1 || T < 1 || t_out0 < 0 || t_out0 >= T) { set_error("vsv_train_decode: bad sizes"); return -1; }
+    if (n_rows < 1 || n_rows > 0x7fffffffL || T < 1 || t_out0 < 0 || t_out0 >= T) { set_error("vsv_train_decode: bad sizes"); return -1; }
     if (in->ctx_T > 0 && (!in->ctx || in->ctx_div < 1)) { set_error("vsv_train_decode: ctx missing"); return -1; }
     if (in->z_T > 0 && (!in->zb || in->z_div < 1)) { set_error("vsv_train_decode: zb missing"); return -1; }
     if (in->ctx_T > T || in->z_T > T) { set_error("vsv_train_decode: ctx_T/z_T exceed T"); return -1; }

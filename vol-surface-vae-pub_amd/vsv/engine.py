@@ -274,17 +274,44 @@ class Engine:
         return {"surf": surf, "ex": ex, "state": state, "z": z, "gates": gates}
 
     # -- reduction / noise ---------------------------------------------------
-    def percentile(self, samples: torch.Tensor, qs: Sequence[float] = (5, 50, 95), inner: int = 25) -> torch.Tensor:
-        """samples (..., inner-multiple, S) sample-minor -> (n_vec/inner, nq, inner)."""
+    def percentile(self, samples: torch.Tensor, qs: Sequence[float] = (5, 50, 95), inner: int = 25,
+                   channel: Optional[int] = None, n_channels: int = 1) -> torch.Tensor:
+        """samples (..., inner-multiple, S) sample-minor -> (n_groups, nq, inner).
+        With channel/n_channels the tensor is (..., n_channels*inner, S) and only the `inner` vectors of
+        that channel are reduced per group, read in place through the group stride (no gather copy)."""
         samples = _f32c(samples, self.device)
         S = samples.shape[-1]
-        n_vec = samples.numel() // S
+        n_all = samples.numel() // S
+        if channel is None:
+            n_vec, stride, off = n_all, inner, 0
+        else:
+            assert 0 <= channel < n_channels and n_all % (n_channels * inner) == 0
+            n_vec, stride, off = n_all // n_channels, n_channels * inner, channel * inner * S
         q = (C.c_double * len(qs))(*[float(x) for x in qs])
         out = torch.empty((n_vec // inner, len(qs), inner), dtype=torch.float32, device=self.device)
         with torch.cuda.device(self.device):
-            rc = self.lib.vsv_percentile(_ptr(samples), n_vec, S, q, len(qs), inner, _ptr(out), self._stream())
+            rc = self.lib.vsv_percentile(samples.data_ptr() + 4 * off, n_vec, S, q, len(qs), inner, stride,
+                                         _ptr(out), self._stream())
         _lib.check(rc, "vsv_percentile")
         return out
+
+    def reduce_async(self, samples: torch.Tensor, qs, inner: int, channel: Optional[int], n_channels: int):
+        """percentile() on the side stream, ordered after the work queued so far on the current stream:
+        the reduction of one chunk of MC samples (LDS / VALU work) overlaps the MFMA-bound decode of the
+        next.  Call join_side() before reading the results on the current stream."""
+        main = torch.cuda.current_stream(self.device)
+        if self._side is None:
+            self._side = torch.cuda.Stream(self.device)
+        self._side.wait_stream(main)
+        with torch.cuda.stream(self._side):
+            out = self.percentile(samples, qs, inner, channel, n_channels)
+        samples.record_stream(self._side)
+        out.record_stream(main)
+        return out
+
+    def join_side(self):
+        if self._side is not None:
+            torch.cuda.current_stream(self.device).wait_stream(self._side)
 
     def philox_normal(self, seed: int, day0: int, n_days: int, S: int, step0: int, n_steps: int) -> torch.Tensor:
         out = torch.empty((n_days * S, n_steps, self.L), dtype=torch.float32, device=self.device)

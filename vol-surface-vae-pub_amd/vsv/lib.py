@@ -116,7 +116,7 @@ SIGNATURES = {
                              C.c_long, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
                              C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     "vsv_percentile": (C.c_int, [C.c_void_p, C.c_long, C.c_int, C.POINTER(C.c_double), C.c_int,
-                                 C.c_int, C.c_void_p, C.c_void_p]),
+                                 C.c_int, C.c_long, C.c_void_p, C.c_void_p]),
     "vsv_profile_next_decode": (None, [C.c_void_p, C.c_void_p]),
     "vsv_train_encode": (C.c_int, [C.POINTER(VsvDims), C.c_void_p, C.c_int,
                                    C.c_void_p, C.c_long, C.c_long, C.c_void_p, C.c_long, C.c_long,
@@ -154,7 +154,7 @@ def load() -> C.CDLL:
             fn = getattr(lib, name)
             fn.restype = res
             fn.argtypes = args
-        if lib.vsv_abi_version() != 3:
+        if lib.vsv_abi_version() != 4:
             raise RuntimeError("libvsv_hip.so ABI version mismatch")
         _lib = lib
     return _lib

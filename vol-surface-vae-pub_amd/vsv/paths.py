@@ -97,12 +97,13 @@ def prior_mc_windows(eng: Engine, vol: torch.Tensor, ex: Optional[torch.Tensor],
         r = eng.decode(nd * n_samples, horizon, 0, state_in=state[d0:d0 + nd], state_div=n_samples,
                        gate_in=gates[d0:d0 + nd], seed=seed, S=n_samples, day0=day_index0 + d0, out_mode=1)
         smp = r["surf"]                                    # (nd, H, Q*25, S)
+        # reduced on the side stream while the next chunk decodes
         if channel is None:
-            q = eng.percentile(smp, qs, inner=Q * 25).view(nd, horizon, len(qs), Q, 5, 5)
+            q = eng.reduce_async(smp, qs, Q * 25, None, 1).view(nd, horizon, len(qs), Q, 5, 5)
         else:
-            sel = smp.view(nd, horizon, Q, 25, n_samples)[:, :, channel]
-            q = eng.percentile(sel, qs, inner=25).view(nd, horizon, len(qs), 5, 5)
+            q = eng.reduce_async(smp, qs, 25, channel, Q).view(nd, horizon, len(qs), 5, 5)
         outs.append(q)
+    eng.join_side()
     return torch.cat(outs, dim=0)
 
 
@@ -237,9 +238,9 @@ def oracle_mc_windows(eng: Engine, vol: torch.Tensor, ex: Optional[torch.Tensor]
                        seed=seed, S=n_samples, day0=day_index0 + d0, out_mode=1)
         smp = r["surf"]                                                       # (nd, H, Q*25, S)
         if channel is None:
-            q = eng.percentile(smp, qs, inner=Q * 25).view(nd, horizon, len(qs), Q, 5, 5)
+            q = eng.reduce_async(smp, qs, Q * 25, None, 1).view(nd, horizon, len(qs), Q, 5, 5)
         else:
-            sel = smp.view(nd, horizon, Q, 25, n_samples)[:, :, channel]
-            q = eng.percentile(sel, qs, inner=25).view(nd, horizon, len(qs), 5, 5)
+            q = eng.reduce_async(smp, qs, 25, channel, Q).view(nd, horizon, len(qs), 5, 5)
         outs.append(q)
+    eng.join_side()
     return torch.cat(outs, dim=0)

@@ -203,8 +203,9 @@ __device__ __forceinline__ void load_bias(f32x16 (&acc)[NC], const float* __rest
 
 // A copy of x the optimiser cannot see through.  Lane-dependent addresses derived from it are computed
 // in the phase that uses them instead of being hoisted above the time loop and parked in scratch.
+template <bool ON = true>
 __device__ __forceinline__ int opaque(int x) {
-    asm volatile("" : "+v"(x));
+    if (ON) asm volatile("" : "+v"(x));
     return x;
 }
 
@@ -281,6 +282,22 @@ struct DenseChainArgs {
 
 constexpr int kDenseSlots = 16 * kHeadTiles;     // LDS k-step slots per wave
 
+// layer[li] of dense_chain_kernel's by-value argument, read from the kernarg segment itself (scalar
+// loads at a run-time offset): indexing the by-value copy with a run-time li makes the compiler keep
+// the whole struct in scratch (1 KiB per lane).  The struct is the kernel's only explicit argument,
+// so it sits at offset 0 of the segment.
+__device__ __forceinline__ DenseLayerArg chain_layer_of_kernarg(int li) {
+    typedef const __attribute__((address_space(4))) DenseChainArgs* KP;
+    const KP kp = (KP)__builtin_amdgcn_kernarg_segment_ptr();
+    DenseLayerArg r;
+    r.w = kp->layer[li].w;
+    r.b = kp->layer[li].b;
+    r.nq = kp->layer[li].nq;
+    r.nt = kp->layer[li].nt;
+    r.n_relu = kp->layer[li].n_relu;
+    return r;
+}
+
 // Per-(row, t) pointers of a chain's side effects, hoisted out of the per-register epilogue:
 // out + f*fstride is the final store (row-major or sample-minor), inj/aux are pre-offset by
 // their first feature so they are indexed by the feature number itself.  inj and aux features
@@ -304,6 +321,16 @@ __device__ __forceinline__ RowIo make_rowio(const DenseChainArgs& a, long row, b
     if (a.inj) io.inj = a.inj + row * a.inj_rs + (long)t * a.inj_ts - a.inj_f0;
     if (a.aux && row_ok) io.aux = a.aux + ((size_t)row * a.T + t) * a.aux_n - a.aux_f0;
     return io;
+}
+
+// The row's output pointers, computed where they are used (the epilogue of the layer that stores) from
+// the caller's opaque lane index: hoisted above the time loop, sixteen 64-bit store addresses per lane
+// were kept alive -- in scratch -- through every GEMM.
+__device__ __forceinline__ RowIo late_rowio(const DenseChainArgs& hd, long rowtile, int lane, int to) {
+    const int mv = lane & 31;
+    const long rr = rowtile * 32 + mv;
+    const bool ok = rr < hd.n_rows;
+    return make_rowio(hd, ok ? rr : hd.n_rows - 1, ok, to);
 }
 
 // ReLU mask, injection and aux output for the NT tiles of layer li (in place)
@@ -338,9 +365,13 @@ __device__ __forceinline__ void dense_store(const DenseChainArgs& a, const RowIo
 }
 
 template <int NT>
-__device__ __forceinline__ void dense_layer(const DenseChainArgs& a, const RowIo& io, int li, float* col, int lane,
-                                            long inst) {
-    const DenseLayerArg& ly = a.layer[li];
+__device__ __forceinline__ void dense_layer(const DenseChainArgs& a, const DenseLayerArg& ly, long rowtile, int t, int li,
+                                            float* col0, int lane0, long inst) {
+    // every lane-dependent value of the layer (feature masks, LDS and global addresses) is derived from an
+    // opaque copy of the lane index, so that it is computed here and not hoisted above the layer loop,
+    // where the masks and addresses of all layers together overflowed the register file into scratch
+    const int lane = opaque(lane0);
+    float* const col = col0 + lane;
     const int hh = lane >> 5;
     f32x16 acc[NT];
     int toff[NT];
@@ -349,6 +380,9 @@ __device__ __forceinline__ void dense_layer(const DenseChainArgs& a, const RowIo
     load_bias<NT>(acc, ly.b, toff, hh);
     gemm_seg<NT>(acc, (const float4*)ly.w, lane, toff, NT * 64, col, ly.nq);
     const bool last = (li == a.n_layers - 1);
+    // row pointers only where a layer touches global memory, from an opaque lane (see late_rowio)
+    RowIo io = {nullptr, 1, nullptr, nullptr};
+    if ((last && (a.inj != nullptr || a.out_mode != 0)) || li == a.aux_layer) io = late_rowio(a, rowtile, lane, t);
     dense_epilogue<NT>(a, io, li, last, acc, hh, ly.n_relu);
     if (!last) {
 #pragma unroll
@@ -393,18 +427,18 @@ __global__ void __launch_bounds__(256, 2) dense_chain_kernel(const DenseChainArg
         for (int s = 0; s < a.in_ks; ++s) col[s * 64] = src[s * 64];
         for (int s = a.in_ks; s < kDenseSlots; ++s) col[s * 64] = 0.0f;
     }
-    const RowIo io = make_rowio(a, row, row_ok, t);
 #pragma unroll 1
     for (int li = 0; li < a.n_layers; ++li) {
         if (a.save) {
             float* sv = a.save + ((size_t)li * (a.n_rowtiles * a.T) + inst) * kDenseSlots * 64 + lane;
             for (int s = 0; s < kDenseSlots; ++s) sv[s * 64] = col[s * 64];
         }
-        switch (a.layer[li].nt) {
-            case 1: dense_layer<1>(a, io, li, col, lane, inst); break;
-            case 2: dense_layer<2>(a, io, li, col, lane, inst); break;
-            case 3: dense_layer<3>(a, io, li, col, lane, inst); break;
-            default: dense_layer<4>(a, io, li, col, lane, inst); break;
+        const DenseLayerArg ly = chain_layer_of_kernarg(li);
+        switch (ly.nt) {
+            case 1: dense_layer<1>(a, ly, rowtile, t, li, col - lane, lane, inst); break;
+            case 2: dense_layer<2>(a, ly, rowtile, t, li, col - lane, lane, inst); break;
+            case 3: dense_layer<3>(a, ly, rowtile, t, li, col - lane, lane, inst); break;
+            default: dense_layer<4>(a, ly, rowtile, t, li, col - lane, lane, inst); break;
         }
     }
 }
@@ -506,16 +540,6 @@ __device__ __forceinline__ void lstm_cell(f32x16 (&acc)[OWN], float (&c)[OWN][4]
 // wave `wave`; activations ping-pong between two LDS buffers (64 slots each) with one barrier
 // per layer; the next layer's weights are fetched before that barrier.  Every wave of the
 // workgroup must call this.
-// The row's output pointers, computed where they are used (the epilogue of the layer that stores) from
-// the caller's opaque lane index: hoisted above the time loop, sixteen 64-bit store addresses per lane
-// were kept alive -- in scratch -- through every GEMM.
-__device__ __forceinline__ RowIo late_rowio(const DenseChainArgs& hd, long rowtile, int lane, int to) {
-    const int mv = lane & 31;
-    const long rr = rowtile * 32 + mv;
-    const bool ok = rr < hd.n_rows;
-    return make_rowio(hd, ok ? rr : hd.n_rows - 1, ok, to);
-}
-
 template <int NT>
 __device__ __forceinline__ void head_preload(const LstmSeqArgs& a, float4 (&wq)[kHalfQ], float4 (&bq)[4], int lane, int wave) {
     const DenseChainArgs& hd = a.head;
@@ -634,6 +658,8 @@ lstm_kernel(const LstmSeqArgs a) {
     float* const hb = hb0 + lane;
 
     // gate tiles of this wave; out-of-range ones are computed on a clamped tile and never stored
+    // (opaque<OWN == 4>: the one-wave-per-gate-tile schedule has registers to spare, and pinning its
+    // address arithmetic to the phases measured 60% slower on the date-range prefix)
     constexpr bool ALLV = (OWN * NW == NT);                       // every wave owns OWN existing tiles
     int toff[OWN];
     unsigned wo[OWN];
@@ -747,7 +773,7 @@ lstm_kernel(const LstmSeqArgs a) {
             float hn[OWN][4];
             const float4* w = (const float4*)a.w[l];
             const int nq_in = (l == 0) ? (kx >> 2) : NT;          // quads of the input segment
-            const int lv = opaque(lane);
+            const int lv = opaque<OWN == 4>(lane);
             float* const xs = xs0 + lv;
             float* const hb = hb0 + lv;
             float* hl = hb + (size_t)l * HPK * 64;
@@ -789,7 +815,7 @@ lstm_kernel(const LstmSeqArgs a) {
                 if (!shared) gemm_seg<OWN>(acc, w + (size_t)nq_in * NT * 64, lv, toff, NT * 64, hl, NT);
             }
             if constexpr (HEAD) {
-                if (l == NL - 1 && head_now) head_preload<NT>(a, wq, bq, opaque(lane), wave);
+                if (l == NL - 1 && head_now) head_preload<NT>(a, wq, bq, opaque<OWN == 4>(lane), wave);
             }
             VSV_STAMP(2 + 3 * l);
             lstm_cell<SAVE, OWN>(acc, c[l], hn);
@@ -813,12 +839,12 @@ lstm_kernel(const LstmSeqArgs a) {
                 }
             }
             // the accumulators are free: start the next stage's initial values
-            if (l + 1 < NL) acc_init(l + 1, shared, opaque(lane));
-            else if (!head_now && t + 1 < a.T) acc_init(0, false, opaque(lane));
+            if (l + 1 < NL) acc_init(l + 1, shared, opaque<OWN == 4>(lane));
+            else if (!head_now && t + 1 < a.T) acc_init(0, false, opaque<OWN == 4>(lane));
             // h of this layer is overwritten only after every wave has read the old one (a shared first
             // step has no recurrent product, so nobody reads it)
             if (!shared) __syncthreads();
-            const int lw = opaque(lane);
+            const int lw = opaque<OWN == 4>(lane);
             float* const hlw = hb0 + lw + (size_t)l * HPK * 64;
 #pragma unroll
             for (int i = 0; i < OWN; ++i) {
@@ -854,7 +880,7 @@ lstm_kernel(const LstmSeqArgs a) {
             if (head_now) {
                 fused_head<NT>(a, wq, bq, hb0 + (size_t)(NL - 1) * HPK * 64, ha0, lane, wave, rowtile, t - a.t_out0);
                 if (t + 1 < a.T) {
-                    const int ln = opaque(lane);
+                    const int ln = opaque<OWN == 4>(lane);
                     acc_init(0, false, ln);
                     if (OWN == 4) {
                         unsigned wn[OWN];

@@ -194,9 +194,20 @@ int vsv_philox_normal(uint64_t seed, long day0, long n_days, long S, int step0, 
  *   gates     [inst][layers][16*NT][64]         activated gates i,f,g,o (slot 16*tile+4*jj+gate)
  *   c, h      [inst][layers][4*NT][64]          cell / hidden state after the step (natural)
  *   hout      [tile*(T-t_out0) + t-t_out0][4*NT][64]  top-layer h of the output steps
- *   head_acts decoder: [n_head][out inst][64][64]     input of every head layer */
+ *   head_acts decoder: [n_head][out inst][64][64]     input of every head layer
+ *   hd        [inst][4*NT][64]                  layer 0's h after dropout (drop_p > 0, 2 layers)
+ * drop_p > 0 turns on nn.LSTM's inter-layer dropout (train mode, :155/:307/:476 with
+ * config["mem_dropout"]): every hidden unit of layer 0's output is zeroed with probability
+ * drop_p and the survivors scaled by 1/(1-drop_p) before layer 1 reads them (the recurrent
+ * path keeps the undropped h).  The mask is a pure function of (drop_seed, drop_id, row, t,
+ * unit) -- Philox4x32-10, vsv_dropout_mask materialises it -- where drop_id tells the three
+ * LSTMs of a model apart (0 posterior encoder, 1 context encoder, 2 decoder). */
 typedef struct vsv_train_save {
     float *emb_acts, *xe, *gates, *c, *h, *hout, *head_acts;
+    float *hd;
+    float drop_p;
+    uint64_t drop_seed;
+    int drop_id;
 } vsv_train_save;
 
 /* vsv_encode / vsv_decode (out_mode 0, zero initial state, head not fused) that also fill `sv`. */
@@ -245,6 +256,9 @@ typedef struct vsv_lstm_bwd {
     const float *sv_gates, *sv_c, *dh_top;
     float *dgates, *dx_tile, *dx_rows;
     int dx_f;
+    float drop_p;                           /* as in vsv_train_save: masks d(layer 0 output) coming from layer 1 */
+    uint64_t drop_seed;
+    int drop_id;
 } vsv_lstm_bwd;
 int vsv_lstm_backward(const vsv_lstm_bwd *d, int hidden, int layers, void *stream);
 
@@ -265,6 +279,13 @@ typedef struct vsv_loss {
     double *sums;
 } vsv_loss;
 int vsv_loss_grad(const vsv_loss *d, void *stream);
+
+/* The dropout factors (0 or 1/(1-p)) the training kernels apply to layer `layer`'s output of
+ * LSTM `id`: out (n_rows, T, hidden).  Test / debugging aid: the reference draws its masks from
+ * torch's generator (inside nn.LSTM), so parity is checked with this mask injected into the
+ * oracle and the keep rate is checked distributionally. */
+int vsv_dropout_mask(float p, uint64_t seed, int id, int layer, long n_rows, int T, int hidden,
+                     float *out, void *stream);
 
 /* ---- profiling aid -----------------------------------------------------------------
  * Arms the NEXT vsv_decode call made by this thread: it records the two hipEvent_t

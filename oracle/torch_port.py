@@ -46,6 +46,26 @@ class TorchPort(nn.Module):
     def w(self, name):
         return self.p[name.replace(".", "/")]
 
+    # dropout factors injected by a test: {"encoder"|"ctx_encoder"|"decoder": (B,T,hidden) of 0 or 1/(1-p)}
+    drop_masks: Optional[Dict[str, torch.Tensor]] = None
+
+    def _mem(self, name, x):
+        """nn.LSTM forward (:155, :307, :476).  With injected masks the two layers run as two
+        one-layer LSTMs on the same parameters and layer 0's output is multiplied by the mask in
+        between -- what nn.LSTM(dropout=p) does in train mode with its own Bernoulli draw."""
+        m = self.mems[name]
+        if not self.drop_masks or self.nl == 1:
+            return m(x)[0]
+        B = x.shape[0]
+        h = x
+        for l in range(self.nl):
+            ws = [getattr(m, f"{p}_l{l}") for p in ("weight_ih", "weight_hh", "bias_ih", "bias_hh")]
+            z = torch.zeros(1, B, m.hidden_size, dtype=x.dtype)
+            h = torch._VF.lstm(h, (z, z), ws, True, 1, 0.0, False, False, True)[0]
+            if l + 1 < self.nl:
+                h = h * self.drop_masks[name][:, : h.shape[1]]
+        return h
+
     def named_reference_parameters(self):
         """(reference state_dict name, parameter) pairs."""
         out = {}
@@ -69,7 +89,7 @@ class TorchPort(nn.Module):
         e = self._embed(surf, "encoder.surface_embedding", "enc_conv", len(self.cfg["surface_hidden"]))
         if ex is not None:
             e = torch.cat([e, ex], dim=-1)                                            # :188
-        h, _ = self.mems["encoder"](e)
+        h = self._mem("encoder", e)
         zm = F.linear(h, self.w("encoder.z_mean_layer.weight"), self.w("encoder.z_mean_layer.bias"))
         zl = F.linear(h, self.w("encoder.z_log_var_layer.weight"), self.w("encoder.z_log_var_layer.bias"))
         return zm, zl
@@ -79,13 +99,13 @@ class TorchPort(nn.Module):
                         len(self.cfg["ctx_surface_hidden"]))
         if ex is not None:
             e = torch.cat([e, ex], dim=-1)
-        h, _ = self.mems["ctx_encoder"](e)
+        h = self._mem("ctx_encoder", e)
         return F.linear(h, self.w("ctx_encoder.final_compression.weight"),
                         self.w("ctx_encoder.final_compression.bias"))                # :343
 
     def decoder(self, dec_in):
         B, T = dec_in.shape[:2]
-        h, _ = self.mems["decoder"](dec_in)                                           # :491
+        h = self._mem("decoder", dec_in)                                              # :491
         sh = self.cfg["surface_hidden"]
         s = F.linear(h, self.w("decoder.surface_decoder_input.weight"), self.w("decoder.surface_decoder_input.bias"))
         s = s.reshape(B * T, sh[-1], 5, 5)                                            # :501

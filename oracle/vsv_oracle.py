@@ -495,6 +495,24 @@ def philox4x32_10(c0, c1, c2, c3, k0: int, k1: int):
     return tuple(c.astype(np.uint32) for c in (c0, c1, c2, c3))
 
 
+def dropout_mask(p: float, seed: int, lstm_id: int, layer: int, n_rows: int, T: int, hidden: int) -> np.ndarray:
+    """The inter-layer dropout factors of the HIP training path (vsv_hip.h, vsv_train_save): unit
+    u = 8*tile + 2*jj + hh of (row, t) is kept (factor 1/(1-p)) iff the top 24 bits of word jj of the
+    Philox block with counter (row, t, 2*tile + hh, 0x44520000 | id << 8 | layer) are >= p * 2^24.
+    Stands in for the Bernoulli draw inside nn.LSTM(dropout=p) (cvae_with_mem_randomized.py:155)."""
+    groups = 2 * ((hidden + 7) // 8)
+    r, t, g = np.meshgrid(np.arange(n_rows), np.arange(T), np.arange(groups), indexing="ij")
+    x = philox4x32_10(r, t, g, np.full_like(g, 0x44520000 | (lstm_id << 8) | layer),
+                      seed & 0xFFFFFFFF, (seed >> 32) & 0xFFFFFFFF)
+    out = np.zeros((n_rows, T, 4 * groups), dtype=np.float32)
+    scale = np.float32(1.0) / (np.float32(1.0) - np.float32(p))
+    for jj in range(4):
+        keep = (x[jj] >> np.uint32(8)).astype(np.float32) * np.float32(2.0 ** -24) >= np.float32(p)
+        u = 8 * (g >> 1) + 2 * jj + (g & 1)
+        out[r, t, u] = np.where(keep, scale, np.float32(0.0))
+    return out[:, :, :hidden]
+
+
 def philox_normal(seed: int, day0: int, n_days: int, n_samples: int, step0: int,
                   n_steps: int, latent_dim: int) -> np.ndarray:
     """The noise the HIP path draws in on-device RNG mode: element

@@ -356,6 +356,64 @@ def test_multihorizon_losses_and_gradients_vs_reference():
     _check_grads(g, [n for n, _ in vo.state_dict_spec(cfg)], te.param_grads(gp_sum))
 
 
+@pytest.mark.parametrize("L,X,B,T,h,p", [(5, 3, 37, 12, 3, 0.25), (12, 3, 8, 30, 7, 0.3), (5, 0, 64, 6, 1, 0.2)])
+def test_train_with_lstm_dropout_vs_autograd_oracle(L, X, B, T, h, p):
+    """nn.LSTM's inter-layer dropout (train mode, mem_dropout 0.2-0.3 in every production config).  The
+    reference draws its masks from torch's generator inside nn.LSTM, so they cannot be reproduced: the
+    HIP path's Philox masks are (a) checked against their numpy restatement and for their keep rate,
+    (b) injected into the torch-port autograd oracle (pinned to the reference by goldens g4), whose
+    loss and parameter gradients the HIP forward + BPTT must match."""
+    from oracle.torch_port import TorchPort
+    from vsv.engine import Engine
+    from vsv.train import TrainEngine
+    cfg = vo.make_config(L, X)
+    cfg.update(ex_loss_on_ret_only=True, ex_feats_loss_type="l2", kl_weight=1e-3, re_feat_weight=1.0)
+    W = vo.init_weights(cfg, 21, 1.5, np.float32)
+    eng = Engine(cfg, W, "cuda:0")
+    spec = vo.state_dict_spec(cfg)
+    te = TrainEngine(eng, spec)
+    rng = np.random.default_rng(8)
+    surf = (0.2 + 0.1 * rng.standard_normal((B, T, 5, 5))).astype(np.float32)
+    ex = (0.01 * rng.standard_normal((B, T, X))).astype(np.float32) if X else None
+    eps = rng.standard_normal((B, T, L)).astype(np.float32)
+    seed = 0x1234_5678_9ABC
+    Hm, Hd = cfg["mem_hidden"], 125 + X
+    masks = {}
+    for name, lid, hid, Tw in (("encoder", 0, Hm, T), ("ctx_encoder", 1, Hm, T - h), ("decoder", 2, Hd, T)):
+        m = _n(eng.dropout_mask(p, seed, lid, 0, B, Tw, hid))
+        assert np.array_equal(m, vo.dropout_mask(p, seed, lid, 0, B, Tw, hid)), name
+        keep = float((m > 0).mean())
+        assert abs(keep - (1 - p)) <= 4 * np.sqrt(p * (1 - p) / m.size) + 1e-3, (name, keep)
+        assert np.allclose(m[m > 0], 1.0 / (1.0 - p))
+        masks[name] = torch.from_numpy(m.astype(np.float32))
+    assert not np.array_equal(_n(eng.dropout_mask(p, seed, 0, 0, B, T, Hm)), _n(eng.dropout_mask(p, seed + 1, 0, 0, B, T, Hm)))
+    lc = dict(quantiles=cfg["quantiles"], quantile_weights=[5.0, 1.0, 5.0], ex_n=1, ex_l2=1, ex_weight=1.0, kl_weight=1e-3)
+    losses, gp, _ = te.loss_and_grads(_t(surf), _t(ex), h, lc, eps=_t(eps), dropout_p=p, dropout_seed=seed)
+    port = TorchPort(cfg, W, torch.float32)
+    port.drop_masks = masks
+    want = port.losses(torch.from_numpy(surf), None if ex is None else torch.from_numpy(ex), torch.from_numpy(eps), h,
+                       quantile_weights=[5.0, 1.0, 5.0])
+    want["loss"].backward()
+    for k in ("loss", "re_surface", "reconstruction_loss", "kl_loss"):
+        assert abs(float(losses[k]) - float(want[k])) <= 1e-3 * abs(float(want[k])) + 1e-9, k
+    ref = port.named_reference_parameters()
+    tot_g = tot_w = 0.0
+    for (n, _), gr in zip(spec, te.param_grads(gp)):
+        if n.startswith("quantile_loss_fn"):
+            continue
+        wg = ref[n].grad
+        wg = np.zeros(ref[n].shape, dtype=np.float32) if wg is None else wg.numpy()
+        gr = _n(gr)
+        nrm = float(np.sqrt((wg.astype(np.float64) ** 2).sum()))
+        assert float(np.sqrt(((gr - wg).astype(np.float64) ** 2).sum())) <= 1e-3 * nrm + 1e-7, n
+        tot_g += float((gr.astype(np.float64) ** 2).sum())
+        tot_w += nrm ** 2
+    assert abs(np.sqrt(tot_g) - np.sqrt(tot_w)) <= 1e-3 * np.sqrt(tot_w)
+    # the mask matters (the same step without dropout gives another loss) and p = 0 is the old path
+    l0, _, _ = te.loss_and_grads(_t(surf), _t(ex), h, lc, eps=_t(eps), want_grads=False)
+    assert abs(float(l0["loss"]) - float(losses["loss"])) > 1e-7
+
+
 def test_model_class_training_api():
     """The drop-in class end to end on the GPU: the shapes the reference's own script test checks
     (test_code/test_quantile_decoder.py:34-50, 105-178), train_step / test_step dict contract,

@@ -193,3 +193,28 @@ def test_torch_port_gradients(name):
         total += float((gr ** 2).sum())
         assert abs(np.sqrt((gr ** 2).sum()) - float(g["gnorm/" + n])) <= 1e-8 * max(1.0, float(g["gnorm/" + n])), n
     assert abs(np.sqrt(total) - float(g["grad_total_norm"])) <= 1e-8 * float(g["grad_total_norm"])
+
+
+def test_dropout_mask_restatement_and_masked_port():
+    """The numpy restatement of the HIP path's inter-layer dropout masks: keep rate, scale, seed and
+    stream separation; and the torch port's masked two-pass LSTM equals nn.LSTM when the mask is 1."""
+    from oracle.torch_port import TorchPort
+    p = 0.3
+    m = vo.dropout_mask(p, 99, 0, 0, 64, 20, 100)
+    assert m.shape == (64, 20, 100) and set(np.unique(m)) == {np.float32(0.0), np.float32(1.0) / (np.float32(1.0) - np.float32(p))}
+    assert abs(float((m > 0).mean()) - (1 - p)) < 0.01
+    assert not np.array_equal(m, vo.dropout_mask(p, 99, 1, 0, 64, 20, 100))
+    assert not np.array_equal(m, vo.dropout_mask(p, 100, 0, 0, 64, 20, 100))
+    assert np.array_equal(m[:10, :5], vo.dropout_mask(p, 99, 0, 0, 10, 5, 100))       # a pure function of (row, t, unit)
+    cfg = vo.make_config(5, 3)
+    W = vo.init_weights(cfg, 3, 1.0, np.float32)
+    port = TorchPort(cfg, W, torch.float32)
+    rng = np.random.default_rng(0)
+    B, T, h = 3, 7, 2
+    s = torch.from_numpy((0.2 + 0.1 * rng.standard_normal((B, T, 5, 5))).astype(np.float32))
+    e = torch.from_numpy((0.01 * rng.standard_normal((B, T, 3))).astype(np.float32))
+    eps = torch.from_numpy(rng.standard_normal((B, T, 5)).astype(np.float32))
+    a = port.losses(s, e, eps, h)["loss"]
+    port.drop_masks = {n: torch.ones(B, T, hd) for n, hd in (("encoder", 100), ("ctx_encoder", 100), ("decoder", 128))}
+    b = port.losses(s, e, eps, h)["loss"]
+    assert abs(float(a) - float(b)) <= 1e-6 * abs(float(a))

@@ -218,9 +218,8 @@ __device__ __forceinline__ float fast_tanh(float x) {
 // ---------------------------------------------------------------------------
 // Philox4x32-10 + Box-Muller: one N(0,1) value per (sample, day, step, f).
 // ---------------------------------------------------------------------------
-__device__ __forceinline__ float philox_normal_elem(uint32_t k0, uint32_t k1, uint32_t sample,
-                                                    uint32_t day, uint32_t step, int f) {
-    uint32_t c0 = sample, c1 = day, c2 = step, c3 = (uint32_t)(f >> 2);
+__device__ __forceinline__ void philox4x32_10(uint32_t k0, uint32_t k1, uint32_t& c0, uint32_t& c1, uint32_t& c2,
+                                              uint32_t& c3) {
 #pragma unroll
     for (int r = 0; r < 10; ++r) {
         const uint32_t hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
@@ -229,6 +228,31 @@ __device__ __forceinline__ float philox_normal_elem(uint32_t k0, uint32_t k1, ui
         c0 = n0; c1 = lo1; c2 = n2; c3 = lo0;
         k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
     }
+}
+
+// nn.LSTM's inter-layer dropout (train mode): the factor (0 or 1/(1-p)) applied to the four hidden
+// units 8*tile + 2*jj + hh (jj = 0..3) of `row` at step t of layer `layer` of LSTM `id` (0 posterior
+// encoder, 1 context encoder, 2 decoder).  One Philox block per (row, t, tile, hh); unit u keeps its
+// value iff the top 24 bits of word jj, scaled to [0,1), are >= p.  Forward and backward call this
+// with the same arguments, so the mask is never stored.
+struct DropArgs {
+    float p, scale;             // p = 0: no dropout
+    uint32_t k0, k1;            // seed
+    uint32_t id;
+};
+__device__ __forceinline__ void dropout_factors(const DropArgs& d, uint32_t row, uint32_t t, int tile, int hh, int layer,
+                                                float (&f)[4]) {
+    uint32_t c0 = row, c1 = t, c2 = (uint32_t)(2 * tile + hh), c3 = 0x44520000u | (d.id << 8) | (uint32_t)layer;
+    philox4x32_10(d.k0, d.k1, c0, c1, c2, c3);
+    const uint32_t x[4] = {c0, c1, c2, c3};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) f[j] = ((float)(x[j] >> 8) * 5.9604644775390625e-08f >= d.p) ? d.scale : 0.0f;
+}
+
+__device__ __forceinline__ float philox_normal_elem(uint32_t k0, uint32_t k1, uint32_t sample,
+                                                    uint32_t day, uint32_t step, int f) {
+    uint32_t c0 = sample, c1 = day, c2 = step, c3 = (uint32_t)(f >> 2);
+    philox4x32_10(k0, k1, c0, c1, c2, c3);
     const int p = (f & 3) >> 1;
     const uint32_t xa = p ? c2 : c0, xb = p ? c3 : c1;
     const float u1 = ((float)(xa >> 9) + 0.5f) * 1.1920928955078125e-07f;   // 2^-23
@@ -471,6 +495,10 @@ struct LstmSeqArgs {
     // training (SAVE): activated gates [inst][l][16*NT][64] (slot 16*tile + 4*jj + gate), cell and hidden
     // state after the step [inst][l][4*NT][64], decoder x part [inst][kx][64]; inst = rowtile*T + t
     float *sv_gates, *sv_c, *sv_h, *sv_x;
+    // training with mem_dropout > 0 (SAVE, NL == 2): layer 1 reads the dropped copy of layer 0's h,
+    // which is also saved ([inst][4*NT][64]) as the X of layer 1's weight gradient
+    DropArgs drop;
+    float* sv_hd;
 };
 
 // per-thread constants of the decoder input assembly
@@ -656,6 +684,7 @@ lstm_kernel(const LstmSeqArgs a) {
     float* const ha0 = hb0 + (size_t)NL * HPK * 64;               // head activations (HEAD only)
     float* const xs = xs0 + lane;                                 // prologue / epilogue views
     float* const hb = hb0 + lane;
+    const bool dropping = SAVE && NL > 1 && a.drop.p > 0.0f;      // wave-uniform; the dropped h lives at ha0
 
     // gate tiles of this wave; out-of-range ones are computed on a clamped tile and never stored
     // (opaque<OWN == 4>: the one-wave-per-gate-tile schedule has registers to spare, and pinning its
@@ -798,7 +827,7 @@ lstm_kernel(const LstmSeqArgs a) {
                     }
                 }
                 if (XMODE == 1 || l > 0) {
-                    const float* bin = (l == 0) ? xs : hb + (size_t)(l - 1) * HPK * 64;
+                    const float* bin = (l == 0) ? xs : ((SAVE && dropping) ? ha0 + lv : hb + (size_t)(l - 1) * HPK * 64);
                     gemm_stream<OWN>(acc, a0, w, wo, NT * 64, nq, [&](int q, float (&bv)[4]) {
                         const float* bp = (q < nq_in) ? bin + (size_t)(4 * q) * 64 : hl + (size_t)(4 * (q - nq_in)) * 64;
 #pragma unroll
@@ -810,7 +839,7 @@ lstm_kernel(const LstmSeqArgs a) {
             } else {
                 const float* bin;
                 if (l == 0) bin = (XMODE == 0) ? a.x_tileb + ((size_t)(rowtile * a.T + t) * kx) * 64 + lv : xs;
-                else bin = hb + (size_t)(l - 1) * HPK * 64;
+                else bin = (SAVE && dropping) ? ha0 + lv : hb + (size_t)(l - 1) * HPK * 64;
                 gemm_seg<OWN>(acc, w, lv, toff, NT * 64, bin, nq_in);
                 if (!shared) gemm_seg<OWN>(acc, w + (size_t)nq_in * NT * 64, lv, toff, NT * 64, hl, NT);
             }
@@ -838,6 +867,21 @@ lstm_kernel(const LstmSeqArgs a) {
                     }
                 }
             }
+            float hd[OWN][4];
+            if (SAVE && l + 1 < NL && dropping) {
+#pragma unroll
+                for (int i = 0; i < OWN; ++i) {
+                    float fct[4];
+                    dropout_factors(a.drop, row32, (uint32_t)t, toff[i] >> 6, hh, l, fct);
+#pragma unroll
+                    for (int jj = 0; jj < 4; ++jj) hd[i][jj] = hn[i][jj] * fct[jj];
+                    if (tval[i]) {
+                        float* sd = a.sv_hd + (size_t)(rowtile * a.T + t) * HPK * 64 + lane;
+#pragma unroll
+                        for (int jj = 0; jj < 4; ++jj) sd[((toff[i] >> 4) + jj) * 64] = hd[i][jj];
+                    }
+                }
+            }
             // the accumulators are free: start the next stage's initial values
             if (l + 1 < NL) acc_init(l + 1, shared, opaque<OWN == 4>(lane));
             else if (!head_now && t + 1 < a.T) acc_init(0, false, opaque<OWN == 4>(lane));
@@ -851,6 +895,10 @@ lstm_kernel(const LstmSeqArgs a) {
                 if (tval[i]) {
 #pragma unroll
                     for (int jj = 0; jj < 4; ++jj) hlw[((toff[i] >> 4) + jj) * 64] = hn[i][jj];
+                    if (SAVE && l + 1 < NL && dropping) {
+#pragma unroll
+                        for (int jj = 0; jj < 4; ++jj) (ha0 + lw)[((toff[i] >> 4) + jj) * 64] = hd[i][jj];
+                    }
                 }
             }
             if (XMODE == 1 && l == NL - 1 && t + 1 < a.T) {
@@ -1063,6 +1111,19 @@ __global__ void __launch_bounds__(256, 1) lstm_bwd_kernel(const LstmBwdArgs a) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[0][r] = 0.0f;
                 gemm_seg<1>(acc, (const float4*)a.wT_in[l + 1], lane, toff1, 4 * 64, dg + (size_t)(l + 1) * GK * 64, 4 * NT);
+                if (a.drop_p > 0.0f) {
+                    // layer l+1 read the dropped copy of this layer's h: same Philox factors as the forward
+                    const DropArgs da = {a.drop_p, 1.0f / (1.0f - a.drop_p), (uint32_t)a.drop_seed,
+                                         (uint32_t)(a.drop_seed >> 32), (uint32_t)a.drop_id};
+                    const uint32_t rowc = (uint32_t)(row_ok ? row_raw : a.n_rows - 1);
+#pragma unroll
+                    for (int jq = 0; jq < 4; ++jq) {
+                        float fct[4];
+                        dropout_factors(da, rowc, (uint32_t)t, 4 * jq + wave, hh, l, fct);
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) acc[0][4 * jq + r] *= fct[r];
+                    }
+                }
             }
             if (t + 1 < a.T)
                 gemm_seg<1>(acc, (const float4*)a.wT_hh[l], lane, toff1, 4 * 64, dg + (size_t)l * GK * 64, 4 * NT);
@@ -1384,7 +1445,7 @@ constexpr long kWideMaxRowtiles = 256;
 
 template <int NT, int NL, int XMODE, bool HEAD, bool SAVE, int OWN>
 static int launch_lstm_o(const LstmSeqArgs& a, hipStream_t st) {
-    const int slots = (XMODE == 0 ? 0 : a.kx) + NL * 4 * NT + (HEAD ? 2 * kDenseSlots : 0);
+    const int slots = (XMODE == 0 ? 0 : a.kx) + NL * 4 * NT + (HEAD ? 2 * kDenseSlots : 0) + (SAVE ? 4 * NT : 0);
     const size_t lds = (size_t)slots * 64 * sizeof(float);
     int rc = set_lds(lstm_kernel<NT, NL, XMODE, HEAD, SAVE, OWN>, lds);
     if (rc) return rc;
@@ -1422,6 +1483,18 @@ static int launch_lstm(const LstmSeqArgs& a, int NT, int NL, bool head, hipStrea
 }
 
 static thread_local hipEvent_t g_prof_ev[2] = {nullptr, nullptr};
+
+static int fill_dropout(LstmSeqArgs& l, const vsv_train_save* sv, int NL, const char* who) {
+    l.drop = DropArgs{0.0f, 1.0f, 0u, 0u, 0u};
+    l.sv_hd = nullptr;
+    if (!(sv->drop_p > 0.0f) || NL < 2) return 0;              // nn.LSTM applies dropout between layers only
+    if (sv->drop_p >= 1.0f) { set_error("%s: dropout probability must be < 1", who); return -1; }
+    if (!sv->hd) { set_error("%s: dropout needs the hd save buffer", who); return -1; }
+    l.drop = DropArgs{sv->drop_p, 1.0f / (1.0f - sv->drop_p), (uint32_t)sv->drop_seed, (uint32_t)(sv->drop_seed >> 32),
+                      (uint32_t)sv->drop_id};
+    l.sv_hd = sv->hd;
+    return 0;
+}
 
 static void fill_dense(DenseChainArgs& a, int li, const float* packed, const Sec& s) {
     a.layer[li].w = packed + s.w_off;
@@ -1632,6 +1705,35 @@ extern "C" int vsv_percentile(const float* in, long n_vec, int S, const double* 
     return launch_check("percentile_kernel");
 }
 
+// factor (0 or 1/(1-p)) of every (row, t, unit) as the training kernels apply it: out (n_rows, T, hidden)
+__global__ void __launch_bounds__(256) dropout_mask_kernel(DropArgs d, int layer, long n_rows, int T, int hidden,
+                                                           float* __restrict__ out) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;           // one (row, t, tile, hh) group per thread
+    const int groups = 2 * ((hidden + 7) / 8);
+    if (i >= n_rows * T * groups) return;
+    const int g = (int)(i % groups);
+    const long rt = i / groups;
+    float f[4];
+    dropout_factors(d, (uint32_t)(rt / T), (uint32_t)(rt % T), g >> 1, g & 1, layer, f);
+#pragma unroll
+    for (int jj = 0; jj < 4; ++jj) {
+        const int u = 8 * (g >> 1) + 2 * jj + (g & 1);
+        if (u < hidden) out[rt * hidden + u] = f[jj];
+    }
+}
+
+extern "C" int vsv_dropout_mask(float p, uint64_t seed, int id, int layer, long n_rows, int T, int hidden,
+                                float* out, void* stream) {
+    if (!out) { set_error("vsv_dropout_mask: null pointer"); return -1; }
+    if (!(p >= 0.0f && p < 1.0f) || n_rows < 0 || T < 0 || hidden < 1) { set_error("vsv_dropout_mask: bad arguments"); return -1; }
+    const long total = n_rows * T * (2 * ((hidden + 7) / 8));
+    if (total == 0) return 0;
+    const DropArgs d = {p, 1.0f / (1.0f - p), (uint32_t)seed, (uint32_t)(seed >> 32), (uint32_t)id};
+    hipLaunchKernelGGL(dropout_mask_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       d, layer, n_rows, T, hidden, out);
+    return launch_check("dropout_mask_kernel");
+}
+
 extern "C" int vsv_philox_normal(uint64_t seed, long day0, long n_days, long S, int step0, int n_steps,
                                  int L, float* out, void* stream) {
     if (!out) { set_error("vsv_philox_normal: null pointer"); return -1; }
@@ -1681,6 +1783,7 @@ extern "C" int vsv_train_encode(const vsv_dims* dims, const float* packed, int w
     l.x_tileb = sv->xe; l.L = lay.L;
     l.hout = sv->hout; l.t_out0 = 0;
     l.sv_gates = sv->gates; l.sv_c = sv->c; l.sv_h = sv->h;
+    if (int rcd = fill_dropout(l, sv, lay.NL, "vsv_train_encode")) return rcd;
     rc = launch_lstm<0>(l, lay.NTm, lay.NL, false, st);
     if (rc) return rc;
 
@@ -1720,6 +1823,7 @@ extern "C" int vsv_train_decode(const vsv_dims* dims, const float* packed, const
     l.din.state_div = 1;
     l.hout = sv->hout; l.t_out0 = t_out0;
     l.sv_gates = sv->gates; l.sv_c = sv->c; l.sv_h = sv->h; l.sv_x = sv->xe;
+    if (int rcd = fill_dropout(l, sv, lay.NL, "vsv_train_decode")) return rcd;
     int rc = launch_lstm<1>(l, lay.NTd, lay.NL, false, st);
     if (rc) return rc;
 
@@ -1768,6 +1872,7 @@ extern "C" int vsv_lstm_backward(const vsv_lstm_bwd* d, int hidden, int layers, 
         d->n_rowtiles > 0x7fffffffL) { set_error("vsv_lstm_backward: bad sizes"); return -1; }
     if (d->nt_x < 0 || d->nt_x > 4 || (d->nt_x > 0 && !d->wT_in[0])) { set_error("vsv_lstm_backward: bad nt_x"); return -1; }
     if (layers == 2 && (!d->wT_hh[1] || !d->wT_in[1])) { set_error("vsv_lstm_backward: layer 1 weights missing"); return -1; }
+    if (d->drop_p < 0.0f || d->drop_p >= 1.0f) { set_error("vsv_lstm_backward: dropout probability must be in [0,1)"); return -1; }
     const int NT = (hidden + 7) / 8;
     hipStream_t st = (hipStream_t)stream;
     if (NT == 13) return layers == 2 ? launch_lstm_bwd<13, 2>(*d, st) : launch_lstm_bwd<13, 1>(*d, st);

@@ -507,11 +507,6 @@ class CVAEMemRand(BaseVAE):
         if te is None or te.eng is not eng:
             te = TrainEngine(eng, [(n, tuple(p.shape)) for n, p in self._hip_named_params()])
             self.__dict__["_vsv_train_engine"] = te
-        if self.training and self.config.get("mem_dropout", 0) and not self.__dict__.get("_vsv_dropout_warned"):
-            import warnings
-            warnings.warn("the HIP training path does not apply nn.LSTM's inter-layer dropout yet "
-                          f"(mem_dropout={self.config['mem_dropout']}); training proceeds without it")
-            self.__dict__["_vsv_dropout_warned"] = True
         return te
 
     def _loss_cfg(self):
@@ -529,8 +524,11 @@ class CVAEMemRand(BaseVAE):
             raise ValueError(f"Insufficient sequence length: T={T}, horizon={horizon}, "
                              f"resulting in C={T - horizon}. Need at least C >= 1.")
         te = self._train_engine()
+        # nn.LSTM applies its inter-layer dropout in train mode only (and only with > 1 layer)
+        p = float(self.config.get("mem_dropout", 0) or 0) if self.training else 0.0
         losses, gp, _ = te.loss_and_grads(surf, ex, horizon, self._loss_cfg(), seed=self._draw_seed(),
-                                          want_grads=want_grads)
+                                          want_grads=want_grads, dropout_p=p,
+                                          dropout_seed=self._draw_seed() if p > 0 else 0)
         if ex is None:
             losses["re_ex_feats"] = torch.zeros(1)
         return losses, gp

@@ -313,6 +313,15 @@ class Engine:
         if self._side is not None:
             torch.cuda.current_stream(self.device).wait_stream(self._side)
 
+    def dropout_mask(self, p: float, seed: int, lstm_id: int, layer: int, n_rows: int, T: int, hidden: int):
+        """The factors (0 or 1/(1-p)) the training kernels apply between LSTM layers: (n_rows, T, hidden)."""
+        out = torch.empty((n_rows, T, hidden), dtype=torch.float32, device=self.device)
+        with torch.cuda.device(self.device):
+            rc = self.lib.vsv_dropout_mask(p, seed & (2 ** 64 - 1), lstm_id, layer, n_rows, T, hidden,
+                                           _ptr(out), self._stream())
+        _lib.check(rc, "vsv_dropout_mask")
+        return out
+
     def philox_normal(self, seed: int, day0: int, n_days: int, S: int, step0: int, n_steps: int) -> torch.Tensor:
         out = torch.empty((n_days * S, n_steps, self.L), dtype=torch.float32, device=self.device)
         with torch.cuda.device(self.device):

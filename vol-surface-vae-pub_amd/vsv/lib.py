@@ -64,7 +64,8 @@ VSV_MAX_CHAIN = 6
 
 
 class VsvTrainSave(C.Structure):
-    _fields_ = [(n, C.c_void_p) for n in ("emb_acts", "xe", "gates", "c", "h", "hout", "head_acts")]
+    _fields_ = [(n, C.c_void_p) for n in ("emb_acts", "xe", "gates", "c", "h", "hout", "head_acts", "hd")] + \
+               [("drop_p", C.c_float), ("drop_seed", C.c_uint64), ("drop_id", C.c_int)]
 
 
 class VsvDenseBwdLayer(C.Structure):
@@ -84,7 +85,8 @@ class VsvLstmBwd(C.Structure):
     _fields_ = [("wT_hh", C.c_void_p * 2), ("wT_in", C.c_void_p * 2), ("nt_x", C.c_int),
                 ("n_rows", C.c_long), ("n_rowtiles", C.c_long), ("T", C.c_int), ("t_out0", C.c_int),
                 ("sv_gates", C.c_void_p), ("sv_c", C.c_void_p), ("dh_top", C.c_void_p),
-                ("dgates", C.c_void_p), ("dx_tile", C.c_void_p), ("dx_rows", C.c_void_p), ("dx_f", C.c_int)]
+                ("dgates", C.c_void_p), ("dx_tile", C.c_void_p), ("dx_rows", C.c_void_p), ("dx_f", C.c_int),
+                ("drop_p", C.c_float), ("drop_seed", C.c_uint64), ("drop_id", C.c_int)]
 
 
 class VsvLoss(C.Structure):
@@ -118,6 +120,8 @@ SIGNATURES = {
     "vsv_percentile": (C.c_int, [C.c_void_p, C.c_long, C.c_int, C.POINTER(C.c_double), C.c_int,
                                  C.c_int, C.c_long, C.c_void_p, C.c_void_p]),
     "vsv_profile_next_decode": (None, [C.c_void_p, C.c_void_p]),
+    "vsv_dropout_mask": (C.c_int, [C.c_float, C.c_uint64, C.c_int, C.c_int, C.c_long, C.c_int, C.c_int,
+                                   C.c_void_p, C.c_void_p]),
     "vsv_train_encode": (C.c_int, [C.POINTER(VsvDims), C.c_void_p, C.c_int,
                                    C.c_void_p, C.c_long, C.c_long, C.c_void_p, C.c_long, C.c_long,
                                    C.c_long, C.c_int, C.c_void_p, C.POINTER(VsvTrainSave), C.c_void_p]),

@@ -211,10 +211,12 @@ class TrainEngine:
 
     # -- one forward/backward ----------------------------------------------------------
     def loss_and_grads(self, surf: torch.Tensor, ex: Optional[torch.Tensor], horizon: int, loss_cfg: dict,
-                       eps: Optional[torch.Tensor] = None, seed: int = 0, want_grads: bool = True):
+                       eps: Optional[torch.Tensor] = None, seed: int = 0, want_grads: bool = True,
+                       dropout_p: float = 0.0, dropout_seed: int = 0):
         """surf (B,T,5,5) [, ex (B,T,X)] -> (losses dict of 0-d float64 tensors, gradient of
         `loss` w.r.t. the PACKED blob or None).  loss_cfg: quantiles, quantile_weights, ex_n,
-        ex_l2, ex_weight, kl_weight."""
+        ex_l2, ex_weight, kl_weight.  dropout_p > 0: nn.LSTM's inter-layer dropout (train mode) in
+        all three memories, masks keyed by dropout_seed (vsv_hip.h, vsv_train_save)."""
         eng, lib, lay = self.eng, self.lib, self.lay
         dev = self.dev
         L, X, Q, NL = self.L, self.X, self.Q, self.NL
@@ -227,6 +229,13 @@ class TrainEngine:
         rt = (B + 31) // 32
         st = self._stream()
         packed = eng.packed
+        drop_p = float(dropout_p) if NL > 1 else 0.0
+        drop_seed = int(dropout_seed) & (2 ** 64 - 1)
+
+        def set_drop(s, sv, NI, NT, drop_id):
+            if drop_p > 0:
+                sv["hd"] = self._e(NI, 4 * NT, 64)
+                s.hd, s.drop_p, s.drop_seed, s.drop_id = sv["hd"].data_ptr(), drop_p, drop_seed, drop_id
 
         main = torch.cuda.current_stream(dev)
         if eng._side is None:
@@ -244,6 +253,7 @@ class TrainEngine:
             s = _lib.VsvTrainSave()
             for k, v in sv.items():
                 setattr(s, k, v.data_ptr())
+            set_drop(s, sv, NI, NTm, which)
             with torch.cuda.stream(stream):
                 rc = lib.vsv_train_encode(C.byref(self.dims), packed.data_ptr(), which,
                                           surf.data_ptr(), T * 25, 25, _ptr(ex), T * X, X,
@@ -267,6 +277,7 @@ class TrainEngine:
             s = _lib.VsvTrainSave()
             for k, v in sv_d.items():
                 setattr(s, k, v.data_ptr())
+            set_drop(s, sv_d, NI, NTd, 2)
             din = _lib.VsvDecodeIn()
             din.ctx, din.ctx_rs, din.ctx_T, din.ctx_div = ctx_out.data_ptr(), Cn * L, Cn, 1
             din.zb, din.lv, din.z_rs, din.z_T, din.z_div = zm.data_ptr(), zl.data_ptr(), T * L, T, 1
@@ -330,6 +341,7 @@ class TrainEngine:
 
             def lstm_bwd(prefix, hidden, NT, sv, Tw, t_out0, dh_top, nt_x, dx_tile=None, dx_rows=None, dx_f=0):
                 a = _lib.VsvLstmBwd()
+                a.drop_p, a.drop_seed, a.drop_id = drop_p, drop_seed, {"e0": 0, "e1": 1, "d": 2}[prefix]
                 for l in range(NL):
                     a.wT_hh[l] = self._wT(blobT, f"{prefix}.hh{l}")[0]
                     a.wT_in[l] = self._wT(blobT, f"{prefix}.in{l}")[0]
@@ -345,7 +357,8 @@ class TrainEngine:
                 h = sv["h"].view(rt, Tw, NL, 4 * NT, 64)
                 hprev = torch.cat([torch.zeros_like(h[:, :1]), h[:, :-1]], dim=1).reshape(rt * Tw, NL, 4 * NT, 64)
                 for l in range(NL):
-                    xin = x_tile if l == 0 else sv["h"][:, l - 1]
+                    # layer 1 read layer 0's h AFTER dropout when it is on
+                    xin = x_tile if l == 0 else (sv["hd"] if drop_p > 0 else sv["h"][:, l - 1])
                     Xl = torch.cat([xin, hprev[:, l]], dim=1)
                     self._acc_layer(gp, secs[l], dg[:, l], Xl)
 

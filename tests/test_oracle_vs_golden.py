@@ -198,6 +198,7 @@ def test_torch_port_gradients(name):
 def test_dropout_mask_restatement_and_masked_port():
     """The numpy restatement of the HIP path's inter-layer dropout masks: keep rate, scale, seed and
     stream separation; and the torch port's masked two-pass LSTM equals nn.LSTM when the mask is 1."""
+    import torch
     from oracle.torch_port import TorchPort
     p = 0.3
     m = vo.dropout_mask(p, 99, 0, 0, 64, 20, 100)

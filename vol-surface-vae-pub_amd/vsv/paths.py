@@ -107,6 +107,94 @@ def prior_mc_windows(eng: Engine, vol: torch.Tensor, ex: Optional[torch.Tensor],
     return torch.cat(outs, dim=0)
 
 
+def prior_windows(eng: Engine, vol: torch.Tensor, ex: Optional[torch.Tensor], first_day: int, n_days: int,
+                  ctx_len: int, horizon: int, n_samples: int = 1, seed: int = 0,
+                  day_index0: Optional[int] = None, chunk_rows: int = 1 << 19):
+    """The per-day generation loop of generate_surfaces.py:60-102 / eval_utils.py:42-70 /
+    generate_vae_tf_sequences.py (sampling_mode "prior") WITHOUT the reduction: for every day in
+    [first_day, first_day + n_days), n_samples prior draws from the window vol[day-C:day].
+    Returns (n_days, n_samples, horizon, Q, 5, 5)[, (n_days, n_samples, horizon, X)] -- the raw
+    samples in the reference's layout, on device.  Philox keyed by the global day index."""
+    assert first_day >= ctx_len and first_day + n_days <= vol.shape[0]
+    vol = vol.to(device=eng.device, dtype=torch.float32).contiguous()
+    if eng.X > 0:
+        ex = ex.to(device=eng.device, dtype=torch.float32).contiguous()
+    if day_index0 is None:
+        day_index0 = first_day
+    L, Q, X, S = eng.L, eng.Q, eng.X, n_samples
+    w0 = first_day - ctx_len
+    enc, ctx = eng.encode_both_strided(vol[w0:], 25, 25, ex[w0:] if X > 0 else None, X, X, n_days, ctx_len)
+    zm = enc[..., :L].contiguous()
+    pre = eng.decode(n_days, ctx_len, ctx_len, ctx=ctx, zb=zm, want_state=True, want_gates=S > 1)
+    out_s = torch.empty((n_days, S, horizon, Q, 5, 5), dtype=torch.float32, device=eng.device)
+    out_e = torch.empty((n_days, S, horizon, X), dtype=torch.float32, device=eng.device) if X > 0 else None
+    chunk_days = max(1, chunk_rows // max(1, S * horizon))
+    for d0 in range(0, n_days, chunk_days):
+        nd = min(chunk_days, n_days - d0)
+        r = eng.decode(nd * S, horizon, 0, state_in=pre["state"][d0:d0 + nd], state_div=S,
+                       gate_in=None if pre["gates"] is None else pre["gates"][d0:d0 + nd],
+                       seed=seed, S=S, day0=day_index0 + d0, out_mode=0)
+        out_s[d0:d0 + nd] = r["surf"].view(nd, S, horizon, Q, 5, 5)
+        if X > 0:
+            out_e[d0:d0 + nd] = r["ex"].view(nd, S, horizon, X)
+    return out_s, out_e
+
+
+def oracle_windows(eng: Engine, vol: torch.Tensor, ex: Optional[torch.Tensor], first_day: int, n_days: int,
+                   ctx_len: int, horizon: int, n_samples: int = 1, seed: int = 0,
+                   day_index0: Optional[int] = None, chunk_rows: int = 1 << 16):
+    """Teacher-forcing generation with posterior ("oracle") sampling, generate_vae_tf_sequences.py:109-123:
+    model.forward on vol[day-C : day+H] for every day, z sampled at all C+H positions.  Raw samples
+    (n_days, n_samples, horizon, Q, 5, 5)[, (n_days, n_samples, horizon, X)]."""
+    T = ctx_len + horizon
+    assert first_day >= ctx_len and first_day + n_days + horizon <= vol.shape[0] + 0
+    vol = vol.to(device=eng.device, dtype=torch.float32).contiguous()
+    if eng.X > 0:
+        ex = ex.to(device=eng.device, dtype=torch.float32).contiguous()
+    if day_index0 is None:
+        day_index0 = first_day
+    L, Q, X, S = eng.L, eng.Q, eng.X, n_samples
+    w0 = first_day - ctx_len
+    enc, ctx = eng.encode_both_strided(vol[w0:], 25, 25, ex[w0:] if X > 0 else None, X, X, n_days, T, ctx_len)
+    zm, zl = enc[..., :L].contiguous(), enc[..., L:].contiguous()
+    out_s = torch.empty((n_days, S, horizon, Q, 5, 5), dtype=torch.float32, device=eng.device)
+    out_e = torch.empty((n_days, S, horizon, X), dtype=torch.float32, device=eng.device) if X > 0 else None
+    chunk_days = max(1, chunk_rows // max(1, S))
+    for d0 in range(0, n_days, chunk_days):
+        nd = min(chunk_days, n_days - d0)
+        r = eng.decode(nd * S, T, ctx_len, ctx=ctx[d0:d0 + nd], ctx_div=S, zb=zm[d0:d0 + nd], lv=zl[d0:d0 + nd],
+                       z_div=S, seed=seed, S=S, day0=day_index0 + d0, out_mode=0)
+        out_s[d0:d0 + nd] = r["surf"].view(nd, S, horizon, Q, 5, 5)
+        if X > 0:
+            out_e[d0:d0 + nd] = r["ex"].view(nd, S, horizon, X)
+    return out_s, out_e
+
+
+def ar_offset_windows(eng: Engine, vol: torch.Tensor, ex: Optional[torch.Tensor], first_day: int, n_days: int,
+                      ctx_len: int, ar_steps: int, horizon: int, seed: int = 0,
+                      day_index0: Optional[int] = None, chunk_days: int = 4096):
+    """generate_vae_ar_sequences.py:47-152: one generate_autoregressive_offset rollout per day from
+    the window vol[day-C:day].  Returns (n_days, ar_steps*horizon, Q, 5, 5)[, (n_days, ar_steps*horizon, X)]."""
+    assert first_day >= ctx_len and first_day + n_days <= vol.shape[0]
+    vol = vol.to(device=eng.device, dtype=torch.float32).contiguous()
+    X = eng.X
+    if X > 0:
+        ex = ex.to(device=eng.device, dtype=torch.float32).contiguous()
+    if day_index0 is None:
+        day_index0 = first_day
+    outs_s, outs_e = [], []
+    for d0 in range(0, n_days, chunk_days):
+        nd = min(chunk_days, n_days - d0)
+        w0 = first_day + d0 - ctx_len
+        win = vol[w0:w0 + nd + ctx_len - 1].reshape(-1, 25).unfold(0, ctx_len, 1).permute(0, 2, 1)    # (nd, C, 25)
+        wex = ex[w0:w0 + nd + ctx_len - 1].unfold(0, ctx_len, 1).permute(0, 2, 1) if X > 0 else None
+        s, e = ar_offset_generate(eng, win.reshape(nd, ctx_len, 5, 5).contiguous(), None if wex is None else wex.contiguous(),
+                                  ar_steps, horizon, seed=seed, day0=day_index0 + d0)
+        outs_s.append(s)
+        outs_e.append(e)
+    return torch.cat(outs_s, dim=0), (torch.cat(outs_e, dim=0) if X > 0 else None)
+
+
 def ar_generate(eng: Engine, surf_ctx: torch.Tensor, ex_ctx: Optional[torch.Tensor], horizon: int,
                 n_samples: int = 1, eps: Optional[torch.Tensor] = None, seed: int = 0, day0: int = 0):
     """generate_autoregressive_sequence (cvae_with_mem_randomized.py:717-807) for D

@@ -209,63 +209,173 @@ class TrainEngine:
         if bias:
             gp.index_copy_(0, bpos, Gm.sum(dim=1))
 
+    # -- building blocks ----------------------------------------------------------------
+    class _Ctx:
+        """Per-call state shared by the forward / backward helpers."""
+
+    def _begin(self, surf, ex, dropout_p, dropout_seed):
+        c = TrainEngine._Ctx()
+        c.surf = surf.to(self.dev, torch.float32).contiguous()
+        c.B, c.T = c.surf.shape[:2]
+        c.ex = ex.to(self.dev, torch.float32).contiguous() if self.X > 0 else None
+        c.rt = (c.B + 31) // 32
+        c.packed = self.eng.packed
+        c.drop_p = float(dropout_p) if self.NL > 1 else 0.0
+        c.drop_seed = int(dropout_seed) & (2 ** 64 - 1)
+        c.blobT = None
+        return c
+
+    def _set_drop(self, c, s, sv, NI, NT, drop_id):
+        if c.drop_p > 0:
+            sv["hd"] = self._e(NI, 4 * NT, 64)
+            s.hd, s.drop_p, s.drop_seed, s.drop_id = sv["hd"].data_ptr(), c.drop_p, c.drop_seed, drop_id
+
+    def _enc_fwd(self, c, which, Tw, stream, drop_id=None):
+        """vsv_train_encode of the first Tw days: buffers come from the current stream's pool, the three
+        launches go to `stream`.  -> (out (B, Tw, nh), saved activations)."""
+        lay, NL, NTm = self.lay, self.NL, self.lay["NTm"]
+        e = lay["enc"][which]
+        NI = c.rt * Tw
+        sv = dict(emb_acts=self._e(self.n_conv[which], NI, 64, 64), xe=self._e(NI, e["kx"], 64),
+                  gates=self._e(NI, NL, 16 * NTm, 64), c=self._e(NI, NL, 4 * NTm, 64),
+                  h=self._e(NI, NL, 4 * NTm, 64), hout=self._e(NI, 4 * NTm, 64))
+        out = self._e(c.B, Tw, e["nh"])
+        s = _lib.VsvTrainSave()
+        for k, v in sv.items():
+            setattr(s, k, v.data_ptr())
+        self._set_drop(c, s, sv, NI, NTm, which if drop_id is None else drop_id)
+        sv["drop_id"] = which if drop_id is None else drop_id
+        X = self.X
+        with torch.cuda.stream(stream):
+            rc = self.lib.vsv_train_encode(C.byref(self.dims), c.packed.data_ptr(), which,
+                                           c.surf.data_ptr(), c.T * 25, 25, _ptr(c.ex), c.T * X, X,
+                                           c.B, Tw, out.data_ptr(), C.byref(s), self._stream())
+        _lib.check(rc, "vsv_train_encode")
+        return out, sv
+
+    def _blobT(self, c):
+        if c.blobT is None:
+            ext = torch.cat([self._z(1), c.packed])
+            c.blobT = ext[self._bwd_idx]
+        return c.blobT
+
+    def _dense_bwd(self, c, layers, n_inst_T, in_mode, in_t, in_f, want_dx):
+        a = _lib.VsvDenseBwd()
+        a.n_layers = len(layers)
+        for i, ly in enumerate(layers):
+            for k, v in ly.items():
+                setattr(a.layer[i], k, v)
+        a.n_rows, a.n_rowtiles, a.T = c.B, c.rt, n_inst_T
+        a.in_mode, a.in_, a.in_f = in_mode, in_t.data_ptr(), in_f
+        dx = self._e(c.rt * n_inst_T, 64, 64) if want_dx else None
+        a.dx_out = _ptr(dx)
+        _lib.check(self.lib.vsv_dense_backward(C.byref(a), self._stream()), "vsv_dense_backward")
+        return dx
+
+    def _lstm_bwd(self, c, prefix, hidden, NT, sv, Tw, t_out0, dh_top, nt_x, drop_id, dx_tile=None, dx_rows=None, dx_f=0):
+        NL = self.NL
+        blobT = self._blobT(c)
+        a = _lib.VsvLstmBwd()
+        a.drop_p, a.drop_seed, a.drop_id = c.drop_p, c.drop_seed, drop_id
+        for l in range(NL):
+            a.wT_hh[l] = self._wT(blobT, f"{prefix}.hh{l}")[0]
+            a.wT_in[l] = self._wT(blobT, f"{prefix}.in{l}")[0]
+        a.nt_x, a.n_rows, a.n_rowtiles, a.T, a.t_out0 = nt_x, c.B, c.rt, Tw, t_out0
+        a.sv_gates, a.sv_c, a.dh_top = sv["gates"].data_ptr(), sv["c"].data_ptr(), dh_top.data_ptr()
+        dg = self._e(c.rt * Tw, NL, 16 * NT, 64)
+        a.dgates, a.dx_tile, a.dx_rows, a.dx_f = dg.data_ptr(), _ptr(dx_tile), _ptr(dx_rows), dx_f
+        _lib.check(self.lib.vsv_lstm_backward(C.byref(a), hidden, NL, self._stream()), "vsv_lstm_backward")
+        return dg
+
+    def _lstm_wgrads(self, c, gp, secs, sv, dg, Tw, NT, x_tile):
+        """dW of the LSTM layers: X = [x | h_prev] (layer 0), [h0 | h1_prev] (layer 1)."""
+        NL, rt = self.NL, c.rt
+        h = sv["h"].view(rt, Tw, NL, 4 * NT, 64)
+        hprev = torch.cat([torch.zeros_like(h[:, :1]), h[:, :-1]], dim=1).reshape(rt * Tw, NL, 4 * NT, 64)
+        for l in range(NL):
+            # layer 1 read layer 0's h AFTER dropout when it is on
+            xin = x_tile if l == 0 else (sv["hd"] if c.drop_p > 0 else sv["h"][:, l - 1])
+            Xl = torch.cat([xin, hprev[:, l]], dim=1)
+            self._acc_layer(gp, secs[l], dg[:, l], Xl)
+
+    def _enc_bwd(self, c, gp, which, sv, Tw, d_out):
+        """Backward of one encoder stack from d(out) (B, Tw, nh): head, LSTM (BPTT), conv embedding;
+        accumulates the packed-blob gradient into gp."""
+        lay, NTm = self.lay, self.lay["NTm"]
+        blobT = self._blobT(c)
+        e = lay["enc"][which]
+        pf = f"e{which}"
+        rt = c.rt
+        gh = self._e(rt * Tw, 64, 64)
+        w, nq, nt = self._wT(blobT, f"{pf}.head")
+        dh = self._dense_bwd(c, [dict(wT=w, nqT=nq, ntT=nt, n_relu=0, g_out=gh.data_ptr())], Tw, 0, d_out,
+                             d_out.shape[-1], True)
+        self._acc_layer(gp, e["head"], gh[:, : 16 * e["head"].nt], sv["hout"])
+        dxt = self._e(rt * Tw, 64, 64)
+        dgl = self._lstm_bwd(c, pf, self.Hm, NTm, sv, Tw, 0, dh, e["kx"] // 16, sv["drop_id"], dx_tile=dxt)
+        self._lstm_wgrads(c, gp, e["lstm"], sv, dgl, Tw, NTm, sv["xe"])
+        nc = self.n_conv[which]
+        layers, gs = [], []
+        for li in range(nc - 1, -1, -1):
+            g = self._e(rt * Tw, 64, 64)
+            gs.append((li, g))
+            ly = dict(ntT=0, nqT=0, n_relu=e["conv"][li].n_relu, g_out=g.data_ptr(),
+                      act_out=(sv["xe"] if li == nc - 1 else sv["emb_acts"][li + 1]).data_ptr())
+            if li > 0:
+                ly["wT"], ly["nqT"], ly["ntT"] = self._wT(blobT, f"{pf}.conv{li}")
+            layers.append(ly)
+        self._dense_bwd(c, layers, Tw, 1, dxt, 0, False)
+        for li, g in gs:
+            cs = e["conv"][li]
+            self._acc_layer(gp, cs, g[:, : 16 * cs.nt], sv["emb_acts"][li][:, : 4 * cs.nq])
+
+    def encoder_pass(self, surf, ex, Tw, d_out_fn, which: int = 0, dropout_p: float = 0.0, dropout_seed: int = 0,
+                     drop_id: int = 3, want_grads: bool = True):
+        """One encoder stack alone (the conditional prior network runs in the posterior encoder's slot of
+        its own weight blob): forward on the first Tw days with saved activations, d_out = d_out_fn(out),
+        backward.  -> (out (B, Tw, nh), packed-blob gradient or None)."""
+        with torch.cuda.device(self.dev):
+            c = self._begin(surf, ex, dropout_p, dropout_seed)
+            out, sv = self._enc_fwd(c, which, Tw, torch.cuda.current_stream(self.dev), drop_id=drop_id)
+            if not want_grads:
+                return out, None
+            d_out = d_out_fn(out).to(torch.float32).contiguous()
+            gp = torch.zeros(c.packed.numel(), dtype=torch.float32, device=self.dev)
+            self._enc_bwd(c, gp, which, sv, Tw, d_out)
+        return out, gp
+
     # -- one forward/backward ----------------------------------------------------------
     def loss_and_grads(self, surf: torch.Tensor, ex: Optional[torch.Tensor], horizon: int, loss_cfg: dict,
                        eps: Optional[torch.Tensor] = None, seed: int = 0, want_grads: bool = True,
-                       dropout_p: float = 0.0, dropout_seed: int = 0):
+                       dropout_p: float = 0.0, dropout_seed: int = 0, kl_fn=None):
         """surf (B,T,5,5) [, ex (B,T,X)] -> (losses dict of 0-d float64 tensors, gradient of
         `loss` w.r.t. the PACKED blob or None).  loss_cfg: quantiles, quantile_weights, ex_n,
         ex_l2, ex_weight, kl_weight.  dropout_p > 0: nn.LSTM's inter-layer dropout (train mode) in
-        all three memories, masks keyed by dropout_seed (vsv_hip.h, vsv_train_save)."""
+        all three memories, masks keyed by dropout_seed (vsv_hip.h, vsv_train_save).
+        kl_fn(z_mean, z_log_var) -> (kl, d_zm, d_zl) replaces the N(0,1) KL term: kl is a 0-d tensor,
+        d_* the gradient of kl_weight * kl w.r.t. the posterior parameters (B,T,L) -- the conditional
+        prior's Gaussian-Gaussian KL (cvae_conditional_prior.py:65-115)."""
         eng, lib, lay = self.eng, self.lib, self.lay
         dev = self.dev
         L, X, Q, NL = self.L, self.X, self.Q, self.NL
         NTm, NTd = lay["NTm"], lay["NTd"]
-        surf = surf.to(dev, torch.float32).contiguous()
-        B, T = surf.shape[:2]
+        c = self._begin(surf, ex, dropout_p, dropout_seed)
+        surf, ex = c.surf, c.ex
+        B, T, rt = c.B, c.T, c.rt
         Cn = T - horizon
-        if X > 0:
-            ex = ex.to(dev, torch.float32).contiguous()
-        rt = (B + 31) // 32
         st = self._stream()
-        packed = eng.packed
-        drop_p = float(dropout_p) if NL > 1 else 0.0
-        drop_seed = int(dropout_seed) & (2 ** 64 - 1)
-
-        def set_drop(s, sv, NI, NT, drop_id):
-            if drop_p > 0:
-                sv["hd"] = self._e(NI, 4 * NT, 64)
-                s.hd, s.drop_p, s.drop_seed, s.drop_id = sv["hd"].data_ptr(), drop_p, drop_seed, drop_id
+        packed = c.packed
 
         main = torch.cuda.current_stream(dev)
         if eng._side is None:
             eng._side = torch.cuda.Stream(dev)
         side = eng._side
 
-        def run_encoder(which, Tw, stream):
-            """Buffers are allocated on the main stream; the three launches go to `stream`."""
-            e = lay["enc"][which]
-            NI = rt * Tw
-            sv = dict(emb_acts=self._e(self.n_conv[which], NI, 64, 64), xe=self._e(NI, e["kx"], 64),
-                      gates=self._e(NI, NL, 16 * NTm, 64), c=self._e(NI, NL, 4 * NTm, 64),
-                      h=self._e(NI, NL, 4 * NTm, 64), hout=self._e(NI, 4 * NTm, 64))
-            out = self._e(B, Tw, e["nh"])
-            s = _lib.VsvTrainSave()
-            for k, v in sv.items():
-                setattr(s, k, v.data_ptr())
-            set_drop(s, sv, NI, NTm, which)
-            with torch.cuda.stream(stream):
-                rc = lib.vsv_train_encode(C.byref(self.dims), packed.data_ptr(), which,
-                                          surf.data_ptr(), T * 25, 25, _ptr(ex), T * X, X,
-                                          B, Tw, out.data_ptr(), C.byref(s), self._stream())
-            _lib.check(rc, "vsv_train_encode")
-            return out, sv
-
         with torch.cuda.device(dev):
             # the two encoders are independent: context encoder on the side stream
             side.wait_stream(main)
-            ctx_out, sv_c = run_encoder(1, Cn, side)
-            enc_out, sv_e = run_encoder(0, T, main)
+            ctx_out, sv_c = self._enc_fwd(c, 1, Cn, side)
+            enc_out, sv_e = self._enc_fwd(c, 0, T, main)
             main.wait_stream(side)
             zm, zl = enc_out[..., :L].contiguous(), enc_out[..., L:].contiguous()
             # ---- decoder
@@ -277,7 +387,7 @@ class TrainEngine:
             s = _lib.VsvTrainSave()
             for k, v in sv_d.items():
                 setattr(s, k, v.data_ptr())
-            set_drop(s, sv_d, NI, NTd, 2)
+            self._set_drop(c, s, sv_d, NI, NTd, 2)
             din = _lib.VsvDecodeIn()
             din.ctx, din.ctx_rs, din.ctx_T, din.ctx_div = ctx_out.data_ptr(), Cn * L, Cn, 1
             din.zb, din.lv, din.z_rs, din.z_T, din.z_div = zm.data_ptr(), zl.data_ptr(), T * L, T, 1
@@ -294,6 +404,7 @@ class TrainEngine:
                                       z.data_ptr(), s_out.data_ptr(), _ptr(e_out), C.byref(s), st)
             _lib.check(rc, "vsv_train_decode")
             # ---- losses + output gradients
+            klw = float(loss_cfg["kl_weight"])
             la = _lib.VsvLoss()
             la.pred, la.target = s_out.data_ptr(), surf.data_ptr()
             la.B, la.H, la.T, la.Q = B, horizon, T, Q
@@ -307,60 +418,28 @@ class TrainEngine:
                 d_ex = self._e(B, horizon, X)
                 la.ex_pred, la.ex_target, la.d_ex = e_out.data_ptr(), ex.data_ptr(), d_ex.data_ptr()
                 la.X, la.ex_n, la.ex_l2 = X, int(loss_cfg["ex_n"]), int(loss_cfg["ex_l2"])
-            la.ex_weight, la.kl_weight = float(loss_cfg["ex_weight"]), float(loss_cfg["kl_weight"])
+            la.ex_weight, la.kl_weight = float(loss_cfg["ex_weight"]), (0.0 if kl_fn is not None else klw)
             la.zm, la.zl, la.L = zm.data_ptr(), zl.data_ptr(), L
             la.d_pred, la.d_zm, la.d_zl = d_pred.data_ptr(), d_zm.data_ptr(), d_zl.data_ptr()
             sums = torch.zeros(3, dtype=torch.float64, device=dev)
             la.sums = sums.data_ptr()
             _lib.check(lib.vsv_loss_grad(C.byref(la), st), "vsv_loss_grad")
             re_s, re_e, kl = sums[0], sums[1], sums[2]
+            if kl_fn is not None:
+                kl, g_zm, g_zl = kl_fn(zm, zl)
+                kl = kl.to(torch.float64)
+                d_zm = d_zm + g_zm
+                d_zl = d_zl + g_zl
             recon = re_s + loss_cfg["ex_weight"] * re_e if X > 0 else re_s
-            losses = {"loss": recon + loss_cfg["kl_weight"] * kl, "re_surface": re_s, "re_ex_feats": re_e,
+            losses = {"loss": recon + klw * kl, "re_surface": re_s, "re_ex_feats": re_e,
                       "reconstruction_loss": recon, "kl_loss": kl}
             outputs = {"surf": s_out, "ex": e_out, "z_mean": zm, "z_log_var": zl, "z": z}
             if not want_grads:
                 return losses, None, outputs
 
             # ---- backward
-            ext = torch.cat([self._z(1), packed])
-            blobT = ext[self._bwd_idx]
+            blobT = self._blobT(c)
             gp = torch.zeros(packed.numel(), dtype=torch.float32, device=dev)
-
-            def dense_bwd(layers, n_inst_T, in_mode, in_t, in_f, want_dx):
-                a = _lib.VsvDenseBwd()
-                a.n_layers = len(layers)
-                for i, ly in enumerate(layers):
-                    for k, v in ly.items():
-                        setattr(a.layer[i], k, v)
-                a.n_rows, a.n_rowtiles, a.T = B, rt, n_inst_T
-                a.in_mode, a.in_, a.in_f = in_mode, in_t.data_ptr(), in_f
-                dx = self._e(rt * n_inst_T, 64, 64) if want_dx else None
-                a.dx_out = _ptr(dx)
-                _lib.check(lib.vsv_dense_backward(C.byref(a), self._stream()), "vsv_dense_backward")
-                return dx
-
-            def lstm_bwd(prefix, hidden, NT, sv, Tw, t_out0, dh_top, nt_x, dx_tile=None, dx_rows=None, dx_f=0):
-                a = _lib.VsvLstmBwd()
-                a.drop_p, a.drop_seed, a.drop_id = drop_p, drop_seed, {"e0": 0, "e1": 1, "d": 2}[prefix]
-                for l in range(NL):
-                    a.wT_hh[l] = self._wT(blobT, f"{prefix}.hh{l}")[0]
-                    a.wT_in[l] = self._wT(blobT, f"{prefix}.in{l}")[0]
-                a.nt_x, a.n_rows, a.n_rowtiles, a.T, a.t_out0 = nt_x, B, rt, Tw, t_out0
-                a.sv_gates, a.sv_c, a.dh_top = sv["gates"].data_ptr(), sv["c"].data_ptr(), dh_top.data_ptr()
-                dg = self._e(rt * Tw, NL, 16 * NT, 64)
-                a.dgates, a.dx_tile, a.dx_rows, a.dx_f = dg.data_ptr(), _ptr(dx_tile), _ptr(dx_rows), dx_f
-                _lib.check(lib.vsv_lstm_backward(C.byref(a), hidden, NL, self._stream()), "vsv_lstm_backward")
-                return dg
-
-            def lstm_wgrads(secs, sv, dg, Tw, NT, x_tile):
-                """dW of the LSTM layers: X = [x | h_prev] (layer 0), [h0 | h1_prev] (layer 1)."""
-                h = sv["h"].view(rt, Tw, NL, 4 * NT, 64)
-                hprev = torch.cat([torch.zeros_like(h[:, :1]), h[:, :-1]], dim=1).reshape(rt * Tw, NL, 4 * NT, 64)
-                for l in range(NL):
-                    # layer 1 read layer 0's h AFTER dropout when it is on
-                    xin = x_tile if l == 0 else (sv["hd"] if drop_p > 0 else sv["h"][:, l - 1])
-                    Xl = torch.cat([xin, hprev[:, l]], dim=1)
-                    self._acc_layer(gp, secs[l], dg[:, l], Xl)
 
             # decoder head
             hd = d["head"][: d["n_head"]]
@@ -375,50 +454,24 @@ class TrainEngine:
                 if X > 0 and li == d["ex_layer"]:
                     ly["add"], ly["add_f0"], ly["add_n"] = d_ex.data_ptr(), d["ex_f0"], X
                 layers.append(ly)
-            dh_top = dense_bwd(layers, horizon, 0, d_pred, Q * 25, True)
+            dh_top = self._dense_bwd(c, layers, horizon, 0, d_pred, Q * 25, True)
             for li, g in gs:
                 self._acc_layer(gp, hd[li], g[:, : 16 * hd[li].nt], sv_d["head_acts"][li][:, : 4 * hd[li].nq])
             # decoder LSTM
             dx = self._e(B, T, 2 * L)
-            dg = lstm_bwd("d", lay["Hd"], NTd, sv_d, T, Cn, dh_top, 1, dx_rows=dx, dx_f=2 * L)
-            lstm_wgrads(d["lstm"], sv_d, dg, T, NTd, sv_d["xe"])
+            dg = self._lstm_bwd(c, "d", lay["Hd"], NTd, sv_d, T, Cn, dh_top, 1, 2, dx_rows=dx, dx_f=2 * L)
+            self._lstm_wgrads(c, gp, d["lstm"], sv_d, dg, T, NTd, sv_d["xe"])
             # reparameterisation (:199) and the context embedding
             dz = dx[..., L:]
             dzm_t = dz + d_zm
             dzl_t = dz * 0.5 * (z - zm) + d_zl
             d_ctx = dx[:, :Cn, :L].contiguous()
 
-            def encoder_bwd(which, sv, Tw, d_out):
-                e = lay["enc"][which]
-                pf = f"e{which}"
-                gh = self._e(rt * Tw, 64, 64)
-                w, nq, nt = self._wT(blobT, f"{pf}.head")
-                dh = dense_bwd([dict(wT=w, nqT=nq, ntT=nt, n_relu=0, g_out=gh.data_ptr())], Tw, 0, d_out,
-                               d_out.shape[-1], True)
-                self._acc_layer(gp, e["head"], gh[:, : 16 * e["head"].nt], sv["hout"])
-                dxt = self._e(rt * Tw, 64, 64)
-                dgl = lstm_bwd(pf, self.Hm, NTm, sv, Tw, 0, dh, e["kx"] // 16, dx_tile=dxt)
-                lstm_wgrads(e["lstm"], sv, dgl, Tw, NTm, sv["xe"])
-                nc = self.n_conv[which]
-                layers, gs = [], []
-                for li in range(nc - 1, -1, -1):
-                    g = self._e(rt * Tw, 64, 64)
-                    gs.append((li, g))
-                    ly = dict(ntT=0, nqT=0, n_relu=e["conv"][li].n_relu, g_out=g.data_ptr(),
-                              act_out=(sv["xe"] if li == nc - 1 else sv["emb_acts"][li + 1]).data_ptr())
-                    if li > 0:
-                        ly["wT"], ly["nqT"], ly["ntT"] = self._wT(blobT, f"{pf}.conv{li}")
-                    layers.append(ly)
-                dense_bwd(layers, Tw, 1, dxt, 0, False)
-                for li, g in gs:
-                    cs = e["conv"][li]
-                    self._acc_layer(gp, cs, g[:, : 16 * cs.nt], sv["emb_acts"][li][:, : 4 * cs.nq])
-
             d_enc = torch.cat([dzm_t, dzl_t], dim=-1).contiguous()
             side.wait_stream(main)
             with torch.cuda.stream(side):
-                encoder_bwd(1, sv_c, Cn, d_ctx)
-            encoder_bwd(0, sv_e, T, d_enc)
+                self._enc_bwd(c, gp, 1, sv_c, Cn, d_ctx)
+            self._enc_bwd(c, gp, 0, sv_e, T, d_enc)
             main.wait_stream(side)
         return losses, gp, outputs
 

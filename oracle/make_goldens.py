@@ -282,6 +282,133 @@ def case_multihorizon(name, cfg, seed, scale, B, T, horizons):
     save(name, cfg, d)
 
 
+def build_reference_cprior(cfg: dict, seed: int, scale: float, np_dtype):
+    """The reference's CVAEMemRandConditionalPrior with seeded base + prior-network weights."""
+    from vae.cvae_conditional_prior import CVAEMemRandConditionalPrior
+    tdtype = torch.float64 if np_dtype == np.float64 else torch.float32
+    torch.set_default_dtype(tdtype)
+    model = CVAEMemRandConditionalPrior(dict(cfg, use_conditional_prior=True))
+    W = dict(vo.init_weights(cfg, seed, scale, np_dtype))
+    W.update(vo.init_prior_weights(cfg, seed, scale, np_dtype))
+    sd = model.state_dict()
+    for k, v in W.items():
+        assert tuple(sd[k].shape) == v.shape, k
+        sd[k] = torch.from_numpy(v.copy())
+    model.load_state_dict(sd, strict=True)
+    model.eval()
+    return model
+
+
+def case_cprior_gen(name, cfg, seed, scale, np_dtype, B, C, H, sample_context, ar_phi):
+    """G8: CVAEMemRandConditionalPrior.get_surface_given_conditions(z=None) with the draws injected:
+    torch.randn((B,H,L)) [or H draws of (B,1,L) for AR(1)], the encoder's own randn_like (unused),
+    then randn_like for the sampled context latents (cvae_conditional_prior.py:166-222)."""
+    model = build_reference_cprior(cfg, seed, scale, np_dtype)
+    rng = np.random.Generator(np.random.PCG64(9000 + seed))
+    X, L = cfg["ex_feats_dim"], cfg["latent_dim"]
+    surf, ex = synth(rng, B, C, X, np_dtype)
+    innov = rng.standard_normal((B, H, L)).astype(np.float32)
+    eps_ctx = rng.standard_normal((B, C, L)).astype(np_dtype)
+    c = {"surface": torch.from_numpy(surf)}
+    if X:
+        c["ex_feats"] = torch.from_numpy(ex)
+    with NoiseQueue() as nq:
+        if ar_phi > 0:
+            for t in range(H):
+                nq.push(innov[:, t:t + 1])
+        else:
+            nq.push(innov)
+        nq.push(np.zeros((B, C, L), dtype=np_dtype))
+        if sample_context:
+            nq.push(eps_ctx)
+        out = model.get_surface_given_conditions(c, horizon=H, sample_context=sample_context, ar_phi=ar_phi)
+    pm, plv = model.prior_network(c)
+    d = dict(surface=surf, innov=innov, eps_ctx=eps_ctx, horizon=H, seed=seed, scale=scale,
+             sample_context=np.int64(sample_context), ar_phi=np.float64(ar_phi),
+             prior_mean=t2n(pm), prior_logvar=t2n(plv))
+    if X:
+        d["ex_feats"] = ex
+        d["surf_out"], d["ex_out"] = t2n(out[0]), t2n(out[1])
+    else:
+        d["surf_out"] = t2n(out)
+    save(name, cfg, d)
+
+
+def _all_grads(model, d):
+    grads = {n: t2n(p.grad).copy() for n, p in model.named_parameters()}
+    d["grad_total_norm"] = np.float64(np.sqrt(sum(float((g ** 2).sum()) for g in grads.values())))
+    for n, g in grads.items():
+        d["gnorm/" + n] = np.float64(np.sqrt((g ** 2).sum()))
+        flat = g.ravel()
+        idx = np.linspace(0, flat.size - 1, num=min(flat.size, 64)).astype(np.int64)
+        d["gidx/" + n] = idx
+        d["gval/" + n] = flat[idx]
+
+
+def case_cprior_train(name, cfg, seed, scale, B, T, horizon, horizons):
+    """G8: conditional-prior training.  test_step losses (eval), then train_step and
+    train_step_multihorizon (cached-encoder path) with SGD lr 0 and clip_grad_norm_ patched to a no-op,
+    so the un-clipped gradients of every parameter -- prior network included -- stay in .grad
+    (cvae_conditional_prior.py:241-458).  float64, dropout 0."""
+    np_dtype = np.float64
+    model = build_reference_cprior(cfg, seed, scale, np_dtype)
+    rng = np.random.Generator(np.random.PCG64(9500 + seed))
+    X, L = cfg["ex_feats_dim"], cfg["latent_dim"]
+    surf, ex = synth(rng, B, T, X, np_dtype)
+    eps = rng.standard_normal((B, T, L)).astype(np_dtype)
+    eps_h = rng.standard_normal((len(horizons), B, T, L)).astype(np_dtype)
+    x = {"surface": torch.from_numpy(surf)}
+    if X:
+        x["ex_feats"] = torch.from_numpy(ex)
+    model.horizon = horizon
+    with NoiseQueue() as nq:
+        nq.push(eps)
+        losses = model.test_step(x)
+    d = dict(surface=surf, eps=eps, eps_h=eps_h, horizon=horizon, horizons=np.asarray(horizons), seed=seed, scale=scale)
+    if X:
+        d["ex_feats"] = ex
+    for k, v in losses.items():
+        d["loss_" + k] = np.float64(t2n(v).reshape(-1)[0])
+    clip = torch.nn.utils.clip_grad_norm_
+    torch.nn.utils.clip_grad_norm_ = lambda *a, **k: None
+    try:
+        model.train()
+        opt = torch.optim.SGD(model.parameters(), lr=0.0)
+        with NoiseQueue() as nq:
+            nq.push(eps)
+            out = model.train_step(x, opt)
+        d["train_loss"] = np.float64(t2n(out["loss"]).reshape(-1)[0])
+        d1 = {}
+        _all_grads(model, d1)
+        d.update({"ts/" + k: v for k, v in d1.items()})
+        with NoiseQueue() as nq:
+            nq.push(np.zeros((B, T, L)))                     # the cached encoder call's own (unused) sample
+            for i in range(len(horizons)):
+                nq.push(eps_h[i])
+            out = model.train_step_multihorizon(x, opt, horizons=list(horizons))
+        d["mh_loss"] = np.float64(t2n(out["loss"]).reshape(-1)[0])
+        d["mh_horizon_losses"] = np.asarray([out["horizon_losses"][h] for h in horizons], dtype=np.float64)
+        d["mh_kl_loss"] = np.float64(t2n(out["kl_loss"]).reshape(-1)[0])
+        d2 = {}
+        _all_grads(model, d2)
+        d.update({"mh/" + k: v for k, v in d2.items()})
+    finally:
+        torch.nn.utils.clip_grad_norm_ = clip
+    save(name, cfg, d)
+
+
+def main_cprior():
+    f32, f64 = np.float32, np.float64
+    ex5 = vo.make_config(5, 3)
+    no_ex = vo.make_config(5, 0)
+    ex12 = vo.make_config(12, 3, quantile_loss_weights=[5.0, 1.0, 5.0], kl_weight=1e-3)
+    case_cprior_gen("g8_cprior_gen_ex5_C20_H7_f32", ex5, 40, 2.0, f32, 6, 20, 7, False, 0.0)
+    case_cprior_gen("g8_cprior_gen_noex_C5_H1_f64", no_ex, 41, 2.0, f64, 5, 5, 1, False, 0.0)
+    case_cprior_gen("g8_cprior_gen_ex12_C60_H30_sctx_ar_f32", ex12, 42, 2.0, f32, 4, 60, 30, True, 0.5)
+    case_cprior_train("g8_cprior_train_ex5_B6_T21_h3", ex5, 43, 2.0, 6, 21, 3, [1, 7, 14])
+    case_cprior_train("g8_cprior_train_ex12_B4_T40_h7", ex12, 44, 2.0, 4, 40, 7, [1, 7, 14, 30])
+
+
 def case_losses():
     """G3: QuantileLoss on small tensors incl. the reference's own KATs
     (test_code/test_quantile_decoder.py:58-66, 70-94)."""
@@ -344,6 +471,7 @@ def main():
     case_ar_offset("g7_aroff_ex12_C60_H60x3", ex12, 22, 2.0, 2, 60, 60, 3)
     case_losses()
     main_training()
+    main_cprior()
 
 
 def case_sampler():
@@ -385,5 +513,8 @@ if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "training":
         os.makedirs(OUT, exist_ok=True)
         main_training()
+    elif len(sys.argv) > 1 and sys.argv[1] == "cprior":
+        os.makedirs(OUT, exist_ok=True)
+        main_cprior()
     else:
         main()

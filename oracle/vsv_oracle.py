@@ -145,6 +145,47 @@ def init_weights(cfg: dict, seed: int = 0, scale: float = 1.0,
     return W
 
 
+def prior_state_dict_spec(cfg: dict) -> List[Tuple[str, Tuple[int, ...]]]:
+    """Parameter names and shapes of ConditionalPriorNetwork.state_dict() (keys carry the
+    "prior_network." prefix they have inside CVAEMemRandConditionalPrior): the context-encoder stack
+    under its own names, a compression Linear and the two prior heads
+    (/root/reference/vae/conditional_prior_network.py:62-82, 104-112, 159-166), compress_context=True."""
+    L, X, Hm, nl = cfg["latent_dim"], cfg["ex_feats_dim"], cfg["mem_hidden"], cfg["mem_layers"]
+    csh = list(cfg["ctx_surface_hidden"])
+    E = csh[-1] * 25 + X
+    spec: List[Tuple[str, Tuple[int, ...]]] = []
+    cin = 1
+    for i, co in enumerate(csh):
+        spec.append((f"prior_network.surface_embedding.prior_enc_conv_{i}.weight", (co, cin, 3, 3)))
+        spec.append((f"prior_network.surface_embedding.prior_enc_conv_{i}.bias", (co,)))
+        cin = co
+    for l in range(nl):
+        i = E if l == 0 else Hm
+        spec += [(f"prior_network.mem.weight_ih_l{l}", (4 * Hm, i)), (f"prior_network.mem.weight_hh_l{l}", (4 * Hm, Hm)),
+                 (f"prior_network.mem.bias_ih_l{l}", (4 * Hm,)), (f"prior_network.mem.bias_hh_l{l}", (4 * Hm,))]
+    spec += [("prior_network.compression.weight", (L, Hm)), ("prior_network.compression.bias", (L,)),
+             ("prior_network.prior_mean_layer.weight", (L, L)), ("prior_network.prior_mean_layer.bias", (L,)),
+             ("prior_network.prior_logvar_layer.weight", (L, L)), ("prior_network.prior_logvar_layer.bias", (L,))]
+    return spec
+
+
+def init_prior_weights(cfg: dict, seed: int = 0, scale: float = 1.0, dtype=np.float32) -> Weights:
+    """Deterministic prior-network weights, same recipe as init_weights (own PCG64 stream)."""
+    rng = np.random.Generator(np.random.PCG64(seed + 777_000))
+    spec = prior_state_dict_spec(cfg)
+    shapes = dict(spec)
+    W: Weights = {}
+    for name, shape in spec:
+        if ".mem." in name:
+            fan = shape[0] // 4
+        else:
+            ws = shape if name.endswith(".weight") else shapes[name[:-4] + "weight"]
+            fan = ws[1] * (9 if len(ws) == 4 else 1)
+        bound = scale / math.sqrt(fan)
+        W[name] = rng.uniform(-bound, bound, size=shape).astype(dtype)
+    return W
+
+
 # --------------------------------------------------------------------------
 # primitive ops (the torch.nn ops the reference calls)
 # --------------------------------------------------------------------------
@@ -279,6 +320,57 @@ def ctx_encoder_forward(W: Weights, cfg: dict, surface: np.ndarray,
     h, _ = lstm_forward(emb, W, "ctx_encoder.mem", cfg["mem_layers"])
     return linear(h, W["ctx_encoder.final_compression.weight"],
                   W["ctx_encoder.final_compression.bias"])
+
+
+def prior_network_forward(Wp: Weights, cfg: dict, surface: np.ndarray, ex_feats: Optional[np.ndarray] = None):
+    """ConditionalPriorNetwork.forward (/root/reference/vae/conditional_prior_network.py:168-209):
+    conv embedding [+ ex_feats] -> LSTM -> compression -> prior_mean / prior_logvar, each (B,C,L)."""
+    n = len(cfg["ctx_surface_hidden"])
+    emb = _embed(surface, Wp, "prior_network.surface_embedding", [f"prior_enc_conv_{i}" for i in range(n)])
+    if ex_feats is not None:
+        emb = np.concatenate([emb, ex_feats], axis=-1)
+    h, _ = lstm_forward(emb, Wp, "prior_network.mem", cfg["mem_layers"])
+    h = linear(h, Wp["prior_network.compression.weight"], Wp["prior_network.compression.bias"])
+    return (linear(h, Wp["prior_network.prior_mean_layer.weight"], Wp["prior_network.prior_mean_layer.bias"]),
+            linear(h, Wp["prior_network.prior_logvar_layer.weight"], Wp["prior_network.prior_logvar_layer.bias"]))
+
+
+def kl_divergence_gaussians(mu_q, logvar_q, mu_p, logvar_p) -> float:
+    """KL(q || p) of diagonal Gaussians, summed over the latent dims, mean over batch and time
+    (conditional_prior_network.py:212-233)."""
+    kl = 0.5 * (logvar_p - logvar_q + np.exp(logvar_q - logvar_p) + (mu_q - mu_p) ** 2 / np.exp(logvar_p) - 1)
+    return float(kl.sum(axis=-1).mean())
+
+
+def cond_prior_generate(W: Weights, Wp: Weights, cfg: dict, ctx_surface: np.ndarray, ctx_ex: Optional[np.ndarray],
+                        eps_future: np.ndarray, eps_ctx: Optional[np.ndarray] = None):
+    """CVAEMemRandConditionalPrior.get_surface_given_conditions with z=None
+    (/root/reference/vae/cvae_conditional_prior.py:166-239): future latents
+    prior_mean[:, -1] + exp(0.5 * prior_logvar[:, -1]) * eps_future (B,H,L) (iid or AR(1) noise, the
+    caller's choice), context latents = posterior mean, or sampled with eps_ctx (B,C,L) when given
+    (sample_context=True); decode and return the future part."""
+    B, C = ctx_surface.shape[:2]
+    H = eps_future.shape[1]
+    L = cfg["latent_dim"]
+    pm, plv = prior_network_forward(Wp, cfg, ctx_surface, ctx_ex)
+    zm, zl = encoder_forward(W, cfg, ctx_surface, ctx_ex)
+    z = np.zeros((B, C + H, L), dtype=ctx_surface.dtype)
+    z[:, C:] = pm[:, -1:] + np.exp(0.5 * plv[:, -1:]) * eps_future
+    z[:, :C] = zm if eps_ctx is None else zm + np.exp(0.5 * zl) * eps_ctx
+    ctx = ctx_encoder_forward(W, cfg, ctx_surface, ctx_ex)
+    ctx_pad = np.zeros((B, C + H, L), dtype=ctx_surface.dtype)
+    ctx_pad[:, :C] = ctx
+    s, e, _ = decoder_forward(W, cfg, np.concatenate([ctx_pad, z], axis=-1))
+    return s[:, C:], (None if e is None else e[:, C:])
+
+
+def ar1_noise(innov: np.ndarray, phi: float) -> np.ndarray:
+    """The AR(1) latent noise of cvae_conditional_prior.py:180-188 from its innovations (B,H,L):
+    eps_0 = innov_0, eps_t = phi * eps_{t-1} + sqrt(1 - phi^2) * innov_t."""
+    out = np.array(innov, copy=True)
+    for t in range(1, out.shape[1]):
+        out[:, t] = phi * out[:, t - 1] + math.sqrt(1 - phi ** 2) * innov[:, t]
+    return out
 
 
 def decoder_head(W: Weights, cfg: dict, h: np.ndarray):

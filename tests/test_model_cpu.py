@@ -138,3 +138,34 @@ def test_dataset_and_sampler_match_reference():
     # single-array dataset, float32 option
     ds32 = VolSurfaceDataSetRand(g["surface"], 2, 3, dtype=torch.float32)
     assert ds32[0]["surface"].dtype == torch.float32 and "ex_feats" not in ds32[0]
+
+
+def test_conditional_prior_contract_cpu():
+    """CVAEMemRandConditionalPrior: state_dict carries the reference's prior_network.* keys and shapes
+    (conditional_prior_network.py:62-82), the base keys are unchanged, and compute without a GPU raises."""
+    import torch
+    from oracle import vsv_oracle as vo
+    from vae.conditional_prior_network import kl_divergence_gaussians
+    from vae.cvae_conditional_prior import CVAEMemRandConditionalPrior
+    cfg = vo.make_config(12, 3, device="cpu")
+    cfg["use_conditional_prior"] = True
+    m = CVAEMemRandConditionalPrior(dict(cfg))
+    sd = m.state_dict()
+    spec = vo.prior_state_dict_spec(cfg)
+    assert [k for k in sd if k.startswith("prior_network.")] == [n for n, _ in spec]
+    assert all(tuple(sd[n].shape) == s for n, s in spec)
+    assert len(sd) == 58 + len(spec)
+    assert [n for n, _ in m._hip_named_params()] == [n for n, _ in vo.state_dict_spec(cfg)]
+    # the folded prior heads sit in the encoder's slots of the parameter list handed to the packer
+    named = dict(m._prior_named_params())
+    Wc, bc = m.prior_network.compression.weight, m.prior_network.compression.bias
+    Wm, bm = m.prior_network.prior_mean_layer.weight, m.prior_network.prior_mean_layer.bias
+    assert torch.allclose(named["encoder.z_mean_layer.weight"], Wm @ Wc)
+    assert torch.allclose(named["encoder.z_mean_layer.bias"], Wm @ bc + bm)
+    assert named["encoder.mem.weight_hh_l1"] is m.prior_network.mem.weight_hh_l1
+    with pytest.raises(RuntimeError):
+        m.get_surface_given_conditions({"surface": torch.zeros(1, 5, 5, 5), "ex_feats": torch.zeros(1, 5, 3)})
+    # KL of identical Gaussians is zero; a known value otherwise
+    z = torch.zeros(2, 3, 4)
+    assert float(kl_divergence_gaussians(z, z, z, z)) == 0.0
+    assert abs(float(kl_divergence_gaussians(z + 1, z, z, z)) - 2.0) < 1e-6      # 0.5 * sum_4 (1^2)

@@ -219,3 +219,41 @@ def test_dropout_mask_restatement_and_masked_port():
     port.drop_masks = {n: torch.ones(B, T, hd) for n, hd in (("encoder", 100), ("ctx_encoder", 100), ("decoder", 128))}
     b = port.losses(s, e, eps, h)["loss"]
     assert abs(float(a) - float(b)) <= 1e-6 * abs(float(a))
+
+
+# ---- conditional prior (goldens g8 from the reference's CVAEMemRandConditionalPrior) ----
+
+@pytest.mark.parametrize("name", golden_names("g8_cprior_gen"))
+def test_oracle_conditional_prior_generation(name):
+    g = load_golden(name)
+    cfg = cfg_of(g)
+    f64 = name.endswith("f64")
+    tol = 1e-9 if f64 else 2e-5
+    dt = np.float64 if f64 else np.float32
+    W = vo.init_weights(cfg, int(g["seed"]), float(g["scale"]), dt)
+    Wp = vo.init_prior_weights(cfg, int(g["seed"]), float(g["scale"]), dt)
+    surf, ex = g["surface"], g.get("ex_feats")
+    pm, plv = vo.prior_network_forward(Wp, cfg, surf, ex)
+    assert np.max(np.abs(pm - g["prior_mean"])) <= tol and np.max(np.abs(plv - g["prior_logvar"])) <= tol
+    phi = float(g["ar_phi"])
+    fut = g["innov"].astype(dt)
+    if phi > 0:
+        fut = vo.ar1_noise(fut, phi)
+    s, e = vo.cond_prior_generate(W, Wp, cfg, surf, ex, fut, g["eps_ctx"].astype(dt) if int(g["sample_context"]) else None)
+    assert np.max(np.abs(s - g["surf_out"])) <= tol
+    if ex is not None:
+        assert np.max(np.abs(e - g["ex_out"])) <= tol
+
+
+@pytest.mark.parametrize("name", golden_names("g8_cprior_train"))
+def test_oracle_conditional_prior_kl(name):
+    g = load_golden(name)
+    cfg = cfg_of(g)
+    W = vo.init_weights(cfg, int(g["seed"]), float(g["scale"]), np.float64)
+    Wp = vo.init_prior_weights(cfg, int(g["seed"]), float(g["scale"]), np.float64)
+    surf, ex, h = g["surface"], g.get("ex_feats"), int(g["horizon"])
+    C = surf.shape[1] - h
+    zm, zl = vo.encoder_forward(W, cfg, surf, ex)
+    pm, plv = vo.prior_network_forward(Wp, cfg, surf[:, :C], None if ex is None else ex[:, :C])
+    kl = vo.kl_divergence_gaussians(zm[:, :C], zl[:, :C], pm, plv)
+    assert abs(kl - float(g["loss_kl_loss"])) <= 1e-9 * max(1.0, abs(kl))

@@ -397,6 +397,44 @@ def case_cprior_train(name, cfg, seed, scale, B, T, horizon, horizons):
     save(name, cfg, d)
 
 
+def case_ar_train(name, cfg, seed, scale, B, C, horizon, offset, ar_steps):
+    """G9: vae.utils.train_autoregressive_step (reference vae/utils.py:426-623) with SGD lr 0: losses and
+    the gradients of every parameter, which flow through the fed-back p50 predictions.  float64, dropout 0."""
+    from vae.utils import train_autoregressive_step
+    np_dtype = np.float64
+    cfg = dict(cfg, context_len=C)
+    model, _ = build_reference(cfg, seed, scale, np_dtype)
+    model.train()
+    rng = np.random.Generator(np.random.PCG64(9800 + seed))
+    X, L = cfg["ex_feats_dim"], cfg["latent_dim"]
+    T = C + (ar_steps - 1) * offset + horizon
+    surf, ex = synth(rng, B, T, X, np_dtype)
+    eps = rng.standard_normal((ar_steps, B, C + horizon, L)).astype(np_dtype)
+    batch = {"surface": torch.from_numpy(surf)}
+    if X:
+        batch["ex_feats"] = torch.from_numpy(ex)
+    opt = torch.optim.SGD(model.parameters(), lr=0.0)
+    with NoiseQueue() as nq:
+        for k in range(ar_steps):
+            nq.push(eps[k])
+        out = train_autoregressive_step(model, batch, opt, ar_steps, horizon, offset)
+    d = dict(surface=surf, eps=eps, horizon=horizon, offset=offset, ar_steps=ar_steps, context_len=C, seed=seed, scale=scale,
+             loss=np.float64(out["loss"]), reconstruction_loss=np.float64(out["reconstruction_loss"]),
+             kl_loss=np.float64(out["kl_loss"]))
+    if X:
+        d["ex_feats"] = ex
+    _all_grads(model, d)
+    save(name, cfg, d)
+
+
+def main_ar_train():
+    ex5 = vo.make_config(5, 3, quantile_loss_weights=[5.0, 1.0, 5.0], kl_weight=1e-3)
+    no_ex = vo.make_config(5, 0)
+    case_ar_train("g9_artrain_ex5_C6_H6_off6", ex5, 50, 2.0, 4, 6, 6, 6, 3)
+    case_ar_train("g9_artrain_ex5_C6_H6_off3", ex5, 51, 2.0, 4, 6, 6, 3, 3)
+    case_ar_train("g9_artrain_noex_C8_H4_off4", no_ex, 52, 2.0, 3, 8, 4, 4, 3)
+
+
 def main_cprior():
     f32, f64 = np.float32, np.float64
     ex5 = vo.make_config(5, 3)
@@ -472,6 +510,7 @@ def main():
     case_losses()
     main_training()
     main_cprior()
+    main_ar_train()
 
 
 def case_sampler():
@@ -513,6 +552,9 @@ if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "training":
         os.makedirs(OUT, exist_ok=True)
         main_training()
+    elif len(sys.argv) > 1 and sys.argv[1] == "artrain":
+        os.makedirs(OUT, exist_ok=True)
+        main_ar_train()
     elif len(sys.argv) > 1 and sys.argv[1] == "cprior":
         os.makedirs(OUT, exist_ok=True)
         main_cprior()

@@ -414,6 +414,39 @@ def test_train_with_lstm_dropout_vs_autograd_oracle(L, X, B, T, h, p):
     assert abs(float(l0["loss"]) - float(losses["loss"])) > 1e-7
 
 
+@pytest.mark.parametrize("name", golden_names("g9_artrain"))
+def test_autoregressive_training_step_vs_reference(name):
+    """vae.utils.train_autoregressive_step (reference :426-623): losses and every parameter's gradient,
+    which flow through the fed-back p50 predictions into the earlier steps (goldens g9)."""
+    from vae.cvae_with_mem_randomized import CVAEMemRand
+    from vae.utils import train_autoregressive_step
+    g = load_golden(name)
+    cfg = cfg_of(g)
+    for k in ("ex_loss_on_ret_only", "ex_feats_loss_type", "kl_weight", "re_feat_weight"):
+        v = g["cfg_" + k]
+        cfg[k] = v.item() if v.dtype.kind != "U" else str(v)
+    cfg.update(device="cuda:0", context_len=int(g["context_len"]))
+    model = CVAEMemRand(dict(cfg))
+    W = vo.init_weights(cfg, int(g["seed"]), float(g["scale"]), np.float32)
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in W.items()}, strict=False)
+    model.train()
+    batch = {"surface": _t(g["surface"])}
+    if "ex_feats" in g:
+        batch["ex_feats"] = _t(g["ex_feats"])
+    opt = torch.optim.SGD(model.parameters(), lr=0.0)
+    K = int(g["ar_steps"])
+    out = train_autoregressive_step(model, batch, opt, K, int(g["horizon"]), int(g["offset"]),
+                                    _eps_steps=[_t(g["eps"][k]) for k in range(K)])
+    assert out["ar_steps"] == K and out["offset"] == int(g["offset"])
+    for k in ("loss", "reconstruction_loss", "kl_loss"):
+        assert isinstance(out[k], float) and abs(out[k] - float(g[k])) <= 1e-3 * abs(float(g[k])) + 1e-9, k
+    names = [n for n, _ in model.named_parameters()]
+    _check_grads(g, names, [p.grad for _, p in model.named_parameters()])
+    # too short a sequence is the reference's ValueError
+    with pytest.raises(ValueError):
+        train_autoregressive_step(model, {"surface": batch["surface"][:, :5]}, opt, K, int(g["horizon"]), int(g["offset"]))
+
+
 def test_model_class_training_api():
     """The drop-in class end to end on the GPU: the shapes the reference's own script test checks
     (test_code/test_quantile_decoder.py:34-50, 105-178), train_step / test_step dict contract,

@@ -183,10 +183,108 @@ def test(model, valid_dataloader: DataLoader, test_dataloader: DataLoader, model
     return dev_losses, test_losses
 
 
-def train_autoregressive_step(*args, **kwargs):
-    raise NotImplementedError("autoregressive TRAINING (reference vae/utils.py:426-623) is not part of this build "
-                              "yet (SURVEY.md 8f item 4); autoregressive GENERATION is (vsv.paths.ar_generate)")
+def _ar_context_plan(step: int, C: int, horizon: int, offset: int):
+    """Where every day of the context for AR step `step + 1` comes from, following the reference's
+    window assembly (vae/utils.py:537-610) literally: a list of (source, index) with source -1 = real
+    calendar day `index`, source j >= 0 = day `index` of step j's prediction.  Overlapping predictions
+    (offset < horizon) are concatenated in step order and the LAST C days are kept, duplicates included,
+    exactly as the reference does.  Also returns how the reference fills the context's ex_feats:
+    ("real", start) = real rows from `start`, padded with the last real row; ("last",) = the last real
+    context row repeated."""
+    start = (step + 1) * offset
+    if start + C <= C:
+        return [(-1, i) for i in range(start, start + C)], ("real", start)
+    plan = []
+    if start < C:
+        plan += [(-1, i) for i in range(start, C)]
+    for j in range(step + 1):
+        g0 = C + j * offset
+        lo, hi = max(g0, start), min(g0 + horizon, start + C)
+        if lo < hi:
+            plan += [(j, i) for i in range(lo - g0, hi - g0)]
+    if start < C:
+        return plan, ("real", start)
+    return plan[-C:], ("last",)
 
 
-def train_autoregressive_multi_offset(*args, **kwargs):
-    raise NotImplementedError("autoregressive TRAINING (reference vae/utils.py:626-669) is not part of this build yet")
+def train_autoregressive_step(model, batch, optimizer, ar_steps, horizon, offset, _eps_steps=None):
+    """Reference vae/utils.py:426-623: `ar_steps` teacher-forced forwards of `horizon` days whose context
+    slides by `offset` and is re-assembled from real days and the p50 channel of earlier predictions;
+    pinball (+ ex-feature) + N(0,1) KL per step, the MEAN over steps back-propagated THROUGH the fed-back
+    predictions (no detach, :526-527), optimizer.step() without clipping.  Returns floats.
+
+    On the HIP path the rollout runs twice: a forward pass to obtain the predictions, then, last step
+    first, one forward+backward per step (same Philox / dropout seeds, so the same numbers) that also
+    returns the gradient w.r.t. its input surfaces; the part that falls on predicted days is added to the
+    output gradient of the step that predicted them.  _eps_steps: injected posterior noise per step."""
+    import torch
+    optimizer.zero_grad()
+    surface = batch["surface"].to(model.device)
+    B, T = surface.shape[:2]
+    C = model.config.get("context_len", 60)
+    required_len = C + (ar_steps * offset)
+    if T < required_len:
+        raise ValueError(f"Sequence too short for offset={offset}, ar_steps={ar_steps}: "
+                         f"need {required_len} days, got {T} days")
+    has_ex = "ex_feats" in batch
+    ex_all = batch["ex_feats"].to(model.device) if has_ex else None
+    te = model._train_engine()
+    cfg = model._loss_cfg()
+    cfg["kl_weight"] = float(model.config["kl_weight"])
+    p = float(model.config.get("mem_dropout", 0) or 0) if model.training else 0.0
+    seeds = [(model._draw_seed(), model._draw_seed()) for _ in range(ar_steps)]
+
+    def run(k, ctx_s, ctx_e, want_grads, extra=None):
+        t0 = C + k * offset
+        s_in = torch.cat([ctx_s, surface[:, t0:t0 + horizon]], dim=1)
+        e_in = torch.cat([ctx_e, ex_all[:, t0:t0 + horizon]], dim=1) if has_ex else None
+        return te.loss_and_grads(s_in, e_in, horizon, cfg, eps=None if _eps_steps is None else _eps_steps[k],
+                                 seed=seeds[k][0], want_grads=want_grads, dropout_p=p, dropout_seed=seeds[k][1],
+                                 extra_d_pred=extra, want_input_grad=want_grads)
+
+    # ---- pass 1: predictions and contexts
+    ctx_s = surface[:, :C]
+    ctx_e = ex_all[:, :C] if has_ex else None
+    contexts, plans, preds = [(ctx_s, ctx_e)], [[(-1, i) for i in range(C)]], []
+    with torch.no_grad():
+        for k in range(ar_steps - 1):
+            _, _, out = run(k, ctx_s, ctx_e, False)
+            preds.append(out["surf"][:, :, 1])                              # p50 channel (B, horizon, 5, 5)
+            plan, ex_rule = _ar_context_plan(k, C, horizon, offset)
+            ctx_s = torch.stack([surface[:, i] if j < 0 else preds[j][:, i] for j, i in plan], dim=1)
+            if has_ex:
+                if ex_rule[0] == "real":
+                    real = ex_all[:, ex_rule[1]:C]
+                    ctx_e = real[:, :C] if real.shape[1] >= C else \
+                        torch.cat([real, real[:, -1:].repeat(1, C - real.shape[1], 1)], dim=1)
+                else:
+                    last = min(C - 1, ex_all.shape[1] - 1)
+                    ctx_e = ex_all[:, last:last + 1].repeat(1, C, 1)
+            contexts.append((ctx_s, ctx_e))
+            plans.append(plan)
+    # ---- pass 2: last step first; gradients flow back into the predictions that fed later contexts
+    Q = len(model.config["quantiles"])
+    extra = [None] * ar_steps
+    tot = dict(loss=0.0, recon=0.0, kl=0.0)
+    for k in range(ar_steps - 1, -1, -1):
+        losses, gp, out = run(k, contexts[k][0], contexts[k][1], True, extra[k])
+        model._accumulate_grads(gp, 1.0 / ar_steps)
+        tot["loss"] += float(losses["loss"])
+        tot["recon"] += float(losses["reconstruction_loss"])
+        tot["kl"] += float(losses["kl_loss"])
+        d_ctx = out["d_surface"][:, :len(plans[k])]
+        for pos, (j, i) in enumerate(plans[k]):
+            if j >= 0:
+                if extra[j] is None:
+                    extra[j] = torch.zeros((B, horizon, Q, 5, 5), dtype=torch.float32, device=d_ctx.device)
+                extra[j][:, i, 1] += d_ctx[:, pos]
+    optimizer.step()
+    return {"loss": tot["loss"] / ar_steps, "reconstruction_loss": tot["recon"] / ar_steps,
+            "kl_loss": tot["kl"] / ar_steps, "ar_steps": ar_steps, "offset": offset}
+
+
+def train_autoregressive_multi_offset(model, batch, optimizer, horizon, offsets, ar_steps=3):
+    """Reference vae/utils.py:626-669: one AR training step with an offset drawn from `offsets`."""
+    offset = random.choice(offsets)
+    return train_autoregressive_step(model=model, batch=batch, optimizer=optimizer, ar_steps=ar_steps,
+                                     horizon=horizon, offset=offset)

@@ -132,6 +132,8 @@ class TrainEngine:
         bb = _BwdBlob()
         for w in range(2):
             e = lay["enc"][w]
+            # conv 0 reads the 25 grid points in natural order: its transposed fragments give d(surface)
+            bb.add(f"e{w}.conv0", e["conv"][0], 0, 4 * e["conv"][0].nq, "nat", 1)
             for li in range(1, self.n_conv[w]):
                 bb.add(f"e{w}.conv{li}", e["conv"][li], 0, 4 * e["conv"][li].nq, "slot", e["conv"][li - 1].nt)
             kx = e["kx"]
@@ -298,9 +300,9 @@ class TrainEngine:
             Xl = torch.cat([xin, hprev[:, l]], dim=1)
             self._acc_layer(gp, secs[l], dg[:, l], Xl)
 
-    def _enc_bwd(self, c, gp, which, sv, Tw, d_out):
+    def _enc_bwd(self, c, gp, which, sv, Tw, d_out, want_dsurf=False):
         """Backward of one encoder stack from d(out) (B, Tw, nh): head, LSTM (BPTT), conv embedding;
-        accumulates the packed-blob gradient into gp."""
+        accumulates the packed-blob gradient into gp.  want_dsurf: also return d(surface) (B, Tw, 25)."""
         lay, NTm = self.lay, self.lay["NTm"]
         blobT = self._blobT(c)
         e = lay["enc"][which]
@@ -321,13 +323,19 @@ class TrainEngine:
             gs.append((li, g))
             ly = dict(ntT=0, nqT=0, n_relu=e["conv"][li].n_relu, g_out=g.data_ptr(),
                       act_out=(sv["xe"] if li == nc - 1 else sv["emb_acts"][li + 1]).data_ptr())
-            if li > 0:
+            if li > 0 or want_dsurf:
                 ly["wT"], ly["nqT"], ly["ntT"] = self._wT(blobT, f"{pf}.conv{li}")
             layers.append(ly)
-        self._dense_bwd(c, layers, Tw, 1, dxt, 0, False)
+        dxs = self._dense_bwd(c, layers, Tw, 1, dxt, 0, want_dsurf)
         for li, g in gs:
             cs = e["conv"][li]
             self._acc_layer(gp, cs, g[:, : 16 * cs.nt], sv["emb_acts"][li][:, : 4 * cs.nq])
+        if not want_dsurf:
+            return None
+        # tile-B [inst][slot][half*32 + m] -> (B, Tw, 25): grid point f sits at slot 4*(f>>3) + (f&3), half (f>>2)&1
+        f = torch.arange(25, device=self.dev)
+        t = dxs.view(rt, Tw, 64, 2, 32)[:, :, 4 * (f >> 3) + (f & 3), (f >> 2) & 1]      # (rt, Tw, 25, 32)
+        return t.permute(0, 3, 1, 2).reshape(rt * 32, Tw, 25)[: c.B]
 
     def encoder_pass(self, surf, ex, Tw, d_out_fn, which: int = 0, dropout_p: float = 0.0, dropout_seed: int = 0,
                      drop_id: int = 3, want_grads: bool = True):
@@ -347,14 +355,19 @@ class TrainEngine:
     # -- one forward/backward ----------------------------------------------------------
     def loss_and_grads(self, surf: torch.Tensor, ex: Optional[torch.Tensor], horizon: int, loss_cfg: dict,
                        eps: Optional[torch.Tensor] = None, seed: int = 0, want_grads: bool = True,
-                       dropout_p: float = 0.0, dropout_seed: int = 0, kl_fn=None):
+                       dropout_p: float = 0.0, dropout_seed: int = 0, kl_fn=None,
+                       extra_d_pred: Optional[torch.Tensor] = None, want_input_grad: bool = False):
         """surf (B,T,5,5) [, ex (B,T,X)] -> (losses dict of 0-d float64 tensors, gradient of
         `loss` w.r.t. the PACKED blob or None).  loss_cfg: quantiles, quantile_weights, ex_n,
         ex_l2, ex_weight, kl_weight.  dropout_p > 0: nn.LSTM's inter-layer dropout (train mode) in
         all three memories, masks keyed by dropout_seed (vsv_hip.h, vsv_train_save).
         kl_fn(z_mean, z_log_var) -> (kl, d_zm, d_zl) replaces the N(0,1) KL term: kl is a 0-d tensor,
         d_* the gradient of kl_weight * kl w.r.t. the posterior parameters (B,T,L) -- the conditional
-        prior's Gaussian-Gaussian KL (cvae_conditional_prior.py:65-115)."""
+        prior's Gaussian-Gaussian KL (cvae_conditional_prior.py:65-115).
+        extra_d_pred (B,H,Q,5,5): added to d(loss)/d(decoded surfaces) -- the gradient later steps of an
+        autoregressive rollout send back through their context (vae/utils.py:526-527, no detach).
+        want_input_grad: outputs["d_surface"] (B,T,5,5) = gradient w.r.t. the input surfaces (through both
+        encoders; the targets inside the loss are data, as in the reference)."""
         eng, lib, lay = self.eng, self.lib, self.lay
         dev = self.dev
         L, X, Q, NL = self.L, self.X, self.Q, self.NL
@@ -425,6 +438,8 @@ class TrainEngine:
             la.sums = sums.data_ptr()
             _lib.check(lib.vsv_loss_grad(C.byref(la), st), "vsv_loss_grad")
             re_s, re_e, kl = sums[0], sums[1], sums[2]
+            if extra_d_pred is not None:
+                d_pred = d_pred + extra_d_pred.to(dev, torch.float32).reshape(B, horizon, Q * 25)
             if kl_fn is not None:
                 kl, g_zm, g_zl = kl_fn(zm, zl)
                 kl = kl.to(torch.float64)
@@ -470,9 +485,12 @@ class TrainEngine:
             d_enc = torch.cat([dzm_t, dzl_t], dim=-1).contiguous()
             side.wait_stream(main)
             with torch.cuda.stream(side):
-                self._enc_bwd(c, gp, 1, sv_c, Cn, d_ctx)
-            self._enc_bwd(c, gp, 0, sv_e, T, d_enc)
+                ds_c = self._enc_bwd(c, gp, 1, sv_c, Cn, d_ctx, want_input_grad)
+            ds_e = self._enc_bwd(c, gp, 0, sv_e, T, d_enc, want_input_grad)
             main.wait_stream(side)
+            if want_input_grad:
+                ds_e[:, :Cn] += ds_c
+                outputs["d_surface"] = ds_e.view(B, T, 5, 5)
         return losses, gp, outputs
 
     def param_grads(self, gp: torch.Tensor) -> List[torch.Tensor]:

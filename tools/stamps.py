@@ -25,6 +25,9 @@ dev = torch.device("cuda", 0)
 eng = Engine(cfg, W, dev)
 v, e = synthetic_calendar(N, C, X)
 vol, ex = torch.from_numpy(v).to(dev), torch.from_numpy(e).to(dev)
+if os.environ.get("NOISE") == "0":              # diagnostic: no Philox work in the decode (std0 = 0)
+    _dec = eng.decode
+    eng.decode = lambda *a, **k: _dec(*a, **{**k, "std0": 0.0})
 for _ in range(3):
     paths.prior_mc_windows(eng, vol, ex, C, N, C, H, S, seed=0, chunk_days=500)
 torch.cuda.synchronize()

@@ -710,12 +710,14 @@ lstm_kernel(const LstmSeqArgs a) {
     if (XMODE == 1) {
         const vsv_decode_in& d = a.din;
         const uint32_t day_rel = row32 / div32(d.S);
-        di.ctx = d.ctx ? d.ctx + (long)(row32 / div32(d.ctx_div)) * d.ctx_rs : nullptr;
-        di.z_idx = (long)(row32 / div32(d.z_div)) * d.z_rs;
+        // (wave-uniform tests: a division costs ~25 instructions, and instruction issue is what the
+        // prologue is made of)
+        if (d.ctx) di.ctx = d.ctx + (long)(d.ctx_div == 1 ? row32 : row32 / div32(d.ctx_div)) * d.ctx_rs;
+        if (d.zb) di.z_idx = (long)(d.z_div == 1 ? row32 : row32 / div32(d.z_div)) * d.z_rs;
         di.eps = d.eps_in ? d.eps_in + (size_t)row * d.eps_T * a.L : nullptr;
         di.sample = row32 - day_rel * div32(d.S);
         di.day = (uint32_t)d.day0 + day_rel;
-        state_row = row32 / div32(d.state_div);
+        state_row = (d.state_div == d.S) ? day_rel : row32 / div32(d.state_div);
         if (d.gate_in) gate_in = d.gate_in + (size_t)state_row * NL * NT * 32;
     }
 
@@ -774,7 +776,8 @@ lstm_kernel(const LstmSeqArgs a) {
                 const float cq[4] = {cv[l][i].x, cv[l][i].y, cv[l][i].z, cv[l][i].w};
 #pragma unroll
                 for (int jj = 0; jj < 4; ++jj) {
-                    if (tval[i]) hb[(l * HPK + (toff[i] >> 4) + jj) * 64] = hq[jj];
+                    // (a shared first step never reads the old h: no need to stage it)
+                    if (tval[i] && !shared0) hb[(l * HPK + (toff[i] >> 4) + jj) * 64] = hq[jj];
                     c[l][i][jj] = tval[i] ? cq[jj] : 0.0f;
                 }
             }
@@ -782,10 +785,27 @@ lstm_kernel(const LstmSeqArgs a) {
     VSV_STAMP(17);
     // x part of layer 0 for step 0 (slots wave, wave+4, ...: the waves share the assembly)
     if (XMODE == 1) {
-        for (int s = wave; s < kx; s += NW) {
-            const float v = decoder_input(a, di, row, row_ok, true, 0, 2 * s + hh);
-            xs[s * 64] = v;
-            if (SAVE) a.sv_x[((size_t)(rowtile * a.T) * kx + s) * 64 + lane] = v;
+        const vsv_decode_in& d = a.din;
+        if (!SAVE && d.ctx_T <= 0 && d.z_T <= 0 && !d.eps_in && !a.z_out) {
+            // Monte-Carlo fast path (prior draw from a day's prefix state): the context half of the input
+            // is the zero padding, the latent half mu0 + std0 * Philox
+            for (int s = wave; s < kx; s += NW) {
+                const int f = 2 * s + hh - a.L;
+                float v = 0.0f;
+                if (f >= 0 && f < a.L) {
+                    v = d.mu0;
+                    if (d.std0 != 0.0f)
+                        v += d.std0 * philox_normal_elem((uint32_t)d.seed, (uint32_t)(d.seed >> 32), di.sample, di.day,
+                                                         (uint32_t)(d.step0 - d.eps_t0), f);
+                }
+                xs[s * 64] = v;
+            }
+        } else {
+            for (int s = wave; s < kx; s += NW) {
+                const float v = decoder_input(a, di, row, row_ok, true, 0, 2 * s + hh);
+                xs[s * 64] = v;
+                if (SAVE) a.sv_x[((size_t)(rowtile * a.T) * kx + s) * 64 + lane] = v;
+            }
         }
     }
     VSV_STAMP(18);

@@ -447,6 +447,42 @@ def test_autoregressive_training_step_vs_reference(name):
         train_autoregressive_step(model, {"surface": batch["surface"][:, :5]}, opt, K, int(g["horizon"]), int(g["offset"]))
 
 
+def test_fitted_gmm_prior_generation(tmp_path):
+    """prior_mode="fitted" (reference :583-640, :689-690): future latents from the GMM fitted to the
+    aggregated posterior (file format of analysis_code/fit_aggregated_posterior.py:139-155)."""
+    from vae.cvae_with_mem_randomized import CVAEMemRand
+    L, X, B, C, H = 5, 3, 6, 8, 4
+    cfg = vo.make_config(L, X, device="cuda:0")
+    W = vo.init_weights(cfg, 9, 2.0, np.float32)
+    model = CVAEMemRand(dict(cfg))
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in W.items()}, strict=False)
+    model.eval()
+    rng = np.random.default_rng(2)
+    c = {"surface": _t(0.2 + 0.1 * rng.standard_normal((B, C, 5, 5))), "ex_feats": _t(0.01 * rng.standard_normal((B, C, X)))}
+    with pytest.raises(ValueError):
+        model.get_surface_given_conditions(c, horizon=H, prior_mode="fitted")        # not loaded yet
+    # one (near-)degenerate component: every future latent equals its mean
+    mean = rng.standard_normal(L)
+    path = str(tmp_path / "gmm.pt")
+    torch.save({"means": torch.tensor(mean[None]), "covariances": (1e-16 * torch.eye(L, dtype=torch.float64))[None],
+                "weights": torch.tensor([1.0], dtype=torch.float64), "n_components": 1}, path)
+    model.load_fitted_prior(path)
+    s, e = model.get_surface_given_conditions(c, horizon=H, prior_mode="fitted")
+    z = torch.zeros((B, C + H, L), dtype=torch.float32)
+    z[:, C:] = torch.tensor(mean, dtype=torch.float32)
+    s2, e2 = model.get_surface_given_conditions(c, z=z.cuda(), horizon=H)
+    assert s.shape == (B, H, 3, 5, 5) and err(_n(s), _n(s2)) <= 1e-5 and err(_n(e), _n(e2)) <= 1e-5
+    # two well-separated components: the mixture weights and means show in the samples
+    torch.save({"means": torch.tensor([[-3.0] * L, [3.0] * L], dtype=torch.float64),
+                "covariances": torch.stack([0.01 * torch.eye(L, dtype=torch.float64)] * 2),
+                "weights": torch.tensor([0.25, 0.75], dtype=torch.float64), "n_components": 2}, path)
+    model.load_fitted_prior(path)
+    zs = model._sample_from_fitted_prior(500, 8)
+    assert zs.shape == (500, 8, L) and zs.dtype == torch.float64
+    frac_hi = float((zs[..., 0] > 0).double().mean())
+    assert abs(frac_hi - 0.75) < 0.03 and abs(float(zs[zs[..., 0] > 0].mean()) - 3.0) < 0.02
+
+
 def test_model_class_training_api():
     """The drop-in class end to end on the GPU: the shapes the reference's own script test checks
     (test_code/test_quantile_decoder.py:34-50, 105-178), train_step / test_step dict contract,

@@ -29,15 +29,17 @@
 extern "C" {
 #endif
 
-#define VSV_ABI_VERSION 4
+#define VSV_ABI_VERSION 5
 #define VSV_MAX_CONV 4
-#define VSV_MAX_CHAIN 6
+#define VSV_MAX_CHAIN 8
+#define VSV_MAX_INTERACT 3
 
 /* Model shape: the subset of the reference's config dict that fixes tensor
  * shapes (cvae_with_mem_randomized.py:969-1020; state_dict layout SURVEY.md
  * appendix A).  Only the production topology is implemented: conv surface
- * embedding on a 5x5 grid, LSTM memory, compress_context=True,
- * interaction_layers=None, ex_feats_hidden=None. */
+ * embedding on a 5x5 grid, LSTM memory, compress_context=True, ex_feats_hidden=None;
+ * interaction_layers 0..2 (the Linear+ReLU "interaction" stacks of :131-142, :283-294, :452-463,
+ * turned on by the v3 conditional-prior trainer). */
 typedef struct vsv_dims {
     int latent_dim;                    /* L: config["latent_dim"]            */
     int ex_feats_dim;                  /* X: config["ex_feats_dim"] (0 or >0) */
@@ -48,6 +50,7 @@ typedef struct vsv_dims {
     int n_ctx_conv;                    /* len(config["ctx_surface_hidden"])  */
     int ctx_surface_hidden[VSV_MAX_CONV];
     int n_quantiles;                   /* Q = len(config["quantiles"])       */
+    int interaction_layers;            /* config["interaction_layers"] or 0: n Linear+ReLU + 1 Linear, width kept */
 } vsv_dims;
 
 /* Raw parameters in PyTorch state_dict layout (HOST pointers, float32,
@@ -71,6 +74,10 @@ typedef struct vsv_raw_weights {
     const float *dec_deconv_w[VSV_MAX_CONV], *dec_deconv_b[VSV_MAX_CONV]; /* dec_deconv_i..., dec_final last */
     const float *dec_out_w, *dec_out_b;                   /* dec_output (Conv2d) */
     const float *ex_in_w, *ex_in_b, *ex_out_w, *ex_out_b; /* ex_feats_decoder_input / ex_feats_decoder (X>0) */
+    /* {enc,ctx,dec}_interact_linear_0.. and _final (interaction_layers + 1 Linears each, width x width) */
+    const float *enc_int_w[VSV_MAX_INTERACT], *enc_int_b[VSV_MAX_INTERACT];
+    const float *ctx_int_w[VSV_MAX_INTERACT], *ctx_int_b[VSV_MAX_INTERACT];
+    const float *dec_int_w[VSV_MAX_INTERACT], *dec_int_b[VSV_MAX_INTERACT];
 } vsv_raw_weights;
 
 int vsv_abi_version(void);

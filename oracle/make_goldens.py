@@ -435,6 +435,21 @@ def main_ar_train():
     case_ar_train("g9_artrain_noex_C8_H4_off4", no_ex, 52, 2.0, 3, 8, 4, 4, 3)
 
 
+def main_interaction():
+    """interaction_layers > 0 (the v3 conditional-prior trainer's setting, value 2): forward, prior
+    generation, train_step gradients, and the conditional-prior variant."""
+    f32, f64 = np.float32, np.float64
+    ex12i = vo.make_config(12, 3, interaction_layers=2, quantile_loss_weights=[5.0, 1.0, 5.0], kl_weight=1e-3)
+    noex1 = vo.make_config(5, 0, interaction_layers=1)
+    case_forward("g1_fwd_int2_ex12_T30_h7_f32", ex12i, 60, 2.0, f32, 4, 30, 7)
+    case_forward("g1_fwd_int1_noex_T9_h1_f64", noex1, 61, 2.0, f64, 3, 9, 1)
+    case_prior("g2_prior_int2_ex12_C20_H7_f32", ex12i, 62, 2.0, f32, 6, 20, 7)
+    case_grads("g4_grads_int2_ex12_B4_T20_h3", ex12i, 63, 2.0, 4, 20, 3, full=False)
+    case_grads("g4_grads_int1_noex_B5_T9_h2", noex1, 64, 2.0, 5, 9, 2, full=False)
+    case_cprior_gen("g8_cprior_gen_int2_ex12_C20_H7_f32", ex12i, 65, 2.0, f32, 4, 20, 7, True, 0.3)
+    case_cprior_train("g8_cprior_train_int2_ex12_B4_T24_h3", ex12i, 66, 2.0, 4, 24, 3, [1, 7])
+
+
 def main_cprior():
     f32, f64 = np.float32, np.float64
     ex5 = vo.make_config(5, 3)
@@ -472,6 +487,7 @@ def save(name, cfg, d):
     d["cfg_latent_dim"] = cfg["latent_dim"]
     d["cfg_ex_feats_dim"] = cfg["ex_feats_dim"]
     d["cfg_mem_layers"] = cfg["mem_layers"]
+    d["cfg_interaction_layers"] = int(cfg.get("interaction_layers") or 0)
     d["cfg_quantile_loss_weights"] = np.asarray(cfg.get("quantile_loss_weights") or [1.0, 1.0, 1.0])
     for k in ("ex_loss_on_ret_only", "ex_feats_loss_type", "kl_weight", "re_feat_weight"):
         d["cfg_" + k] = np.asarray(cfg[k])
@@ -511,6 +527,7 @@ def main():
     main_training()
     main_cprior()
     main_ar_train()
+    main_interaction()
 
 
 def case_sampler():
@@ -552,6 +569,9 @@ if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "training":
         os.makedirs(OUT, exist_ok=True)
         main_training()
+    elif len(sys.argv) > 1 and sys.argv[1] == "interaction":
+        os.makedirs(OUT, exist_ok=True)
+        main_interaction()
     elif len(sys.argv) > 1 and sys.argv[1] == "artrain":
         os.makedirs(OUT, exist_ok=True)
         main_ar_train()

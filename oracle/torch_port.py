@@ -85,10 +85,22 @@ class TorchPort(nn.Module):
                                 padding=1))                                           # :100-103, :252-255
         return x.reshape(B, T, -1)
 
+    def _interact(self, x, prefix, stem):
+        """The `interaction` Sequential (:131-142, :283-294, :452-463); Identity for interaction_layers None / 0."""
+        n = self.cfg.get("interaction_layers") or 0
+        if n <= 0:
+            return x
+        for i in range(n):
+            x = F.relu(F.linear(x, self.w(f"{prefix}.interaction.{stem}_interact_linear_{i}.weight"),
+                                self.w(f"{prefix}.interaction.{stem}_interact_linear_{i}.bias")))
+        return F.linear(x, self.w(f"{prefix}.interaction.{stem}_interact_linear_final.weight"),
+                        self.w(f"{prefix}.interaction.{stem}_interact_linear_final.bias"))
+
     def encoder(self, surf, ex):
         e = self._embed(surf, "encoder.surface_embedding", "enc_conv", len(self.cfg["surface_hidden"]))
         if ex is not None:
             e = torch.cat([e, ex], dim=-1)                                            # :188
+        e = self._interact(e, "encoder", "enc")
         h = self._mem("encoder", e)
         zm = F.linear(h, self.w("encoder.z_mean_layer.weight"), self.w("encoder.z_mean_layer.bias"))
         zl = F.linear(h, self.w("encoder.z_log_var_layer.weight"), self.w("encoder.z_log_var_layer.bias"))
@@ -99,6 +111,7 @@ class TorchPort(nn.Module):
                         len(self.cfg["ctx_surface_hidden"]))
         if ex is not None:
             e = torch.cat([e, ex], dim=-1)
+        e = self._interact(e, "ctx_encoder", "ctx")
         h = self._mem("ctx_encoder", e)
         return F.linear(h, self.w("ctx_encoder.final_compression.weight"),
                         self.w("ctx_encoder.final_compression.bias"))                # :343
@@ -106,6 +119,7 @@ class TorchPort(nn.Module):
     def decoder(self, dec_in):
         B, T = dec_in.shape[:2]
         h = self._mem("decoder", dec_in)                                              # :491
+        h = self._interact(h, "decoder", "dec")                                       # :492
         sh = self.cfg["surface_hidden"]
         s = F.linear(h, self.w("decoder.surface_decoder_input.weight"), self.w("decoder.surface_decoder_input.bias"))
         s = s.reshape(B * T, sh[-1], 5, 5)                                            # :501

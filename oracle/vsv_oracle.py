@@ -90,15 +90,27 @@ def state_dict_spec(cfg: dict) -> List[Tuple[str, Tuple[int, ...]]]:
             spec.append((f"{prefix}.bias_ih_l{l}", (4 * hid,)))
             spec.append((f"{prefix}.bias_hh_l{l}", (4 * hid,)))
 
+    n_int = cfg.get("interaction_layers") or 0
+
+    def interaction(prefix, stem, width):
+        # n Linear+ReLU and a final Linear, width kept (:131-142, :283-294, :452-463)
+        if n_int > 0:
+            for nm in [f"{stem}_interact_linear_{i}" for i in range(n_int)] + [f"{stem}_interact_linear_final"]:
+                spec.append((f"{prefix}.interaction.{nm}.weight", (width, width)))
+                spec.append((f"{prefix}.interaction.{nm}.bias", (width,)))
+
     conv_stack("encoder.surface_embedding", [f"enc_conv_{i}" for i in range(len(sh))], sh, 1)
+    interaction("encoder", "enc", E)
     lstm("encoder.mem", E, Hm)
     spec += [("encoder.z_mean_layer.weight", (L, Hm)), ("encoder.z_mean_layer.bias", (L,)),
              ("encoder.z_log_var_layer.weight", (L, Hm)), ("encoder.z_log_var_layer.bias", (L,))]
     conv_stack("ctx_encoder.ctx_surface_embedding", [f"ctx_enc_conv_{i}" for i in range(len(csh))], csh, 1)
+    interaction("ctx_encoder", "ctx", Ec)
     lstm("ctx_encoder.mem", Ec, Hm)
     spec += [("ctx_encoder.final_compression.weight", (L, Hm)),
              ("ctx_encoder.final_compression.bias", (L,))]
     lstm("decoder.mem", 2 * L, Hd)
+    interaction("decoder", "dec", Hd)
     spec += [("decoder.surface_decoder_input.weight", (sh[-1] * 25, Hd)),
              ("decoder.surface_decoder_input.bias", (sh[-1] * 25,))]
     # ConvTranspose2d weights are (in, out, kH, kW)
@@ -159,6 +171,10 @@ def prior_state_dict_spec(cfg: dict) -> List[Tuple[str, Tuple[int, ...]]]:
         spec.append((f"prior_network.surface_embedding.prior_enc_conv_{i}.weight", (co, cin, 3, 3)))
         spec.append((f"prior_network.surface_embedding.prior_enc_conv_{i}.bias", (co,)))
         cin = co
+    n_int = cfg.get("interaction_layers") or 0
+    if n_int > 0:
+        for nm in [f"prior_interact_linear_{i}" for i in range(n_int)] + ["prior_interact_linear_final"]:
+            spec += [(f"prior_network.interaction.{nm}.weight", (E, E)), (f"prior_network.interaction.{nm}.bias", (E,))]
     for l in range(nl):
         i = E if l == 0 else Hm
         spec += [(f"prior_network.mem.weight_ih_l{l}", (4 * Hm, i)), (f"prior_network.mem.weight_hh_l{l}", (4 * Hm, Hm)),
@@ -294,6 +310,19 @@ def _embed(surface: np.ndarray, W: Weights, prefix: str, names: Sequence[str]) -
     return x.reshape(B, T, -1)
 
 
+def _interact(x: np.ndarray, W: Weights, cfg: dict, prefix: str, stem: str) -> np.ndarray:
+    """The `interaction` Sequential (cvae_with_mem_randomized.py:131-142 and twins): n x (Linear, ReLU), Linear;
+    Identity when interaction_layers is None / 0."""
+    n = cfg.get("interaction_layers") or 0
+    if n <= 0:
+        return x
+    for i in range(n):
+        x = np.maximum(linear(x, W[f"{prefix}.interaction.{stem}_interact_linear_{i}.weight"],
+                              W[f"{prefix}.interaction.{stem}_interact_linear_{i}.bias"]), 0)
+    return linear(x, W[f"{prefix}.interaction.{stem}_interact_linear_final.weight"],
+                  W[f"{prefix}.interaction.{stem}_interact_linear_final.bias"])
+
+
 def encoder_forward(W: Weights, cfg: dict, surface: np.ndarray,
                     ex_feats: Optional[np.ndarray] = None):
     """CVAEMemRandEncoder.forward without the sampling line
@@ -302,6 +331,7 @@ def encoder_forward(W: Weights, cfg: dict, surface: np.ndarray,
     emb = _embed(surface, W, "encoder.surface_embedding", [f"enc_conv_{i}" for i in range(n)])
     if ex_feats is not None:
         emb = np.concatenate([emb, ex_feats], axis=-1)          # :188
+    emb = _interact(emb, W, cfg, "encoder", "enc")              # :190
     h, _ = lstm_forward(emb, W, "encoder.mem", cfg["mem_layers"])
     zm = linear(h, W["encoder.z_mean_layer.weight"], W["encoder.z_mean_layer.bias"])
     zl = linear(h, W["encoder.z_log_var_layer.weight"], W["encoder.z_log_var_layer.bias"])
@@ -317,6 +347,7 @@ def ctx_encoder_forward(W: Weights, cfg: dict, surface: np.ndarray,
                  [f"ctx_enc_conv_{i}" for i in range(n)])
     if ex_feats is not None:
         emb = np.concatenate([emb, ex_feats], axis=-1)
+    emb = _interact(emb, W, cfg, "ctx_encoder", "ctx")
     h, _ = lstm_forward(emb, W, "ctx_encoder.mem", cfg["mem_layers"])
     return linear(h, W["ctx_encoder.final_compression.weight"],
                   W["ctx_encoder.final_compression.bias"])
@@ -329,6 +360,7 @@ def prior_network_forward(Wp: Weights, cfg: dict, surface: np.ndarray, ex_feats:
     emb = _embed(surface, Wp, "prior_network.surface_embedding", [f"prior_enc_conv_{i}" for i in range(n)])
     if ex_feats is not None:
         emb = np.concatenate([emb, ex_feats], axis=-1)
+    emb = _interact(emb, Wp, cfg, "prior_network", "prior")
     h, _ = lstm_forward(emb, Wp, "prior_network.mem", cfg["mem_layers"])
     h = linear(h, Wp["prior_network.compression.weight"], Wp["prior_network.compression.bias"])
     return (linear(h, Wp["prior_network.prior_mean_layer.weight"], Wp["prior_network.prior_mean_layer.bias"]),
@@ -380,6 +412,7 @@ def decoder_head(W: Weights, cfg: dict, h: np.ndarray):
     B, T = h.shape[:2]
     sh = cfg["surface_hidden"]
     Q = len(cfg["quantiles"])
+    h = _interact(h, W, cfg, "decoder", "dec")                  # :492
     s = linear(h, W["decoder.surface_decoder_input.weight"], W["decoder.surface_decoder_input.bias"])
     s = s.reshape(B * T, sh[-1], 5, 5)
     for i in range(len(sh) - 1):

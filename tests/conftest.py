@@ -33,4 +33,10 @@ def cfg_of(g):
     w = [float(x) for x in g["cfg_quantile_loss_weights"]]
     if w != [1.0, 1.0, 1.0]:
         cfg["quantile_loss_weights"] = w
+    if "cfg_interaction_layers" in g and int(g["cfg_interaction_layers"]) > 0:
+        cfg["interaction_layers"] = int(g["cfg_interaction_layers"])
+    for k in ("ex_loss_on_ret_only", "ex_feats_loss_type", "kl_weight", "re_feat_weight"):
+        if "cfg_" + k in g:
+            v = g["cfg_" + k]
+            cfg[k] = v.item() if v.dtype.kind != "U" else str(v)
     return cfg

@@ -95,7 +95,7 @@ def test_library_exports_every_declared_symbol():
     L = vlib.load()
     for name in declared:
         assert hasattr(L, name), name
-    assert L.vsv_abi_version() == 4
+    assert L.vsv_abi_version() == 5
     # argument validation happens before any GPU work
     d = vlib.make_dims(5, 0, 100, 2, [5, 5, 5], [5, 5, 5], 3)
     assert L.vsv_packed_floats(C.byref(d)) > 0
@@ -169,3 +169,21 @@ def test_conditional_prior_contract_cpu():
     z = torch.zeros(2, 3, 4)
     assert float(kl_divergence_gaussians(z, z, z, z)) == 0.0
     assert abs(float(kl_divergence_gaussians(z + 1, z, z, z)) - 2.0) < 1e-6      # 0.5 * sum_4 (1^2)
+
+
+def test_interaction_layers_state_dict_keys():
+    """interaction_layers=2 (v3 conditional-prior trainer): parameter names and shapes of the three
+    `interaction` stacks and of the prior network's follow the reference (cvae_with_mem_randomized.py
+    :131-142, :283-294, :452-463; conditional_prior_network.py:131-143)."""
+    from oracle import vsv_oracle as vo
+    from vae.cvae_conditional_prior import CVAEMemRandConditionalPrior
+    cfg = vo.make_config(12, 3, device="cpu", interaction_layers=2)
+    cfg["use_conditional_prior"] = True
+    m = CVAEMemRandConditionalPrior(dict(cfg))
+    sd = m.state_dict()
+    want = vo.state_dict_spec(cfg) + vo.prior_state_dict_spec(cfg)
+    got = [(k, tuple(v.shape)) for k, v in sd.items() if not k.startswith("quantile_loss_fn")]
+    assert sorted(got) == sorted(want)
+    assert [k for k, _ in got if k.startswith("encoder.")] == [k for k, _ in want if k.startswith("encoder.")]
+    assert "decoder.interaction.dec_interact_linear_final.weight" in sd
+    assert "prior_network.interaction.prior_interact_linear_1.bias" in sd

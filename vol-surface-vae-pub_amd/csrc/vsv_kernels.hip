@@ -287,10 +287,11 @@ struct DenseChainArgs {
     long in_rs, in_ts;      // row-major strides (floats)
     int in_f;               // row-major: real features
     int in_ks;              // k-steps to fill (mode 0: multiple of 4; mode 1: k-steps per instance in `in`)
-    // injection into the LAST layer's output features [inj_f0, inj_f0+inj_n)
+    // injection into layer inj_layer's output features [inj_f0, inj_f0+inj_n) (the ex-features joining
+    // the conv embedding, torch.cat at cvae_with_mem_randomized.py:188; interaction Linears may follow)
     const float* inj;
     long inj_rs, inj_ts;
-    int inj_f0, inj_n;
+    int inj_f0, inj_n, inj_layer;
     // output of the last layer
     int out_mode;           // 0 tile-B, 1 row-major (row, t, f), 2 sample-minor (row/S, t, f, row%S)
     float* out;
@@ -365,7 +366,7 @@ __device__ __forceinline__ void dense_epilogue(const DenseChainArgs& a, const Ro
     for (int tt = 0; tt < NT; ++tt)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[tt][r] = (feat_of(tt, r, hh) < n_relu) ? fmaxf(acc[tt][r], 0.0f) : acc[tt][r];
-    const bool do_inj = last && io.inj != nullptr, do_aux = (li == a.aux_layer) && io.aux != nullptr;
+    const bool do_inj = (li == a.inj_layer) && io.inj != nullptr, do_aux = (li == a.aux_layer) && io.aux != nullptr;
     if (do_inj || do_aux) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
@@ -406,7 +407,8 @@ __device__ __forceinline__ void dense_layer(const DenseChainArgs& a, const Dense
     const bool last = (li == a.n_layers - 1);
     // row pointers only where a layer touches global memory, from an opaque lane (see late_rowio)
     RowIo io = {nullptr, 1, nullptr, nullptr};
-    if ((last && (a.inj != nullptr || a.out_mode != 0)) || li == a.aux_layer) io = late_rowio(a, rowtile, lane, t);
+    if ((last && a.out_mode != 0) || (li == a.inj_layer && a.inj != nullptr) || li == a.aux_layer)
+        io = late_rowio(a, rowtile, lane, t);
     dense_epilogue<NT>(a, io, li, last, acc, hh, ly.n_relu);
     if (!last) {
 #pragma unroll
@@ -1566,8 +1568,9 @@ extern "C" int vsv_encode(const vsv_dims* dims, const float* packed, int which,
 
     // 1. conv embedding of every (row, t): surface -> [conv+ReLU]* -> [emb | ex] in tile-B layout
     DenseChainArgs a = {};
-    a.n_layers = e.n_conv;
-    for (int i = 0; i < e.n_conv; ++i) fill_dense(a, i, packed, e.conv[i]);
+    a.n_layers = e.n_chain;
+    for (int i = 0; i < e.n_chain; ++i) fill_dense(a, i, packed, e.conv[i]);
+    a.inj_layer = e.n_conv - 1;
     a.n_rows = n_rows; a.n_rowtiles = rt; a.T = T;
     a.in_mode = 0; a.in = surf; a.in_rs = surf_row_stride; a.in_ts = surf_t_stride; a.in_f = 25;
     a.in_ks = 4 * e.conv[0].nq;
@@ -1785,8 +1788,9 @@ extern "C" int vsv_train_encode(const vsv_dims* dims, const float* packed, int w
     const long rt = (n_rows + 31) / 32;
 
     DenseChainArgs a = {};
-    a.n_layers = e.n_conv;
-    for (int i = 0; i < e.n_conv; ++i) fill_dense(a, i, packed, e.conv[i]);
+    a.n_layers = e.n_chain;
+    for (int i = 0; i < e.n_chain; ++i) fill_dense(a, i, packed, e.conv[i]);
+    a.inj_layer = e.n_conv - 1;
     a.n_rows = n_rows; a.n_rowtiles = rt; a.T = T;
     a.in_mode = 0; a.in = surf; a.in_rs = surf_row_stride; a.in_ts = surf_t_stride; a.in_f = 25;
     a.in_ks = 4 * e.conv[0].nq;

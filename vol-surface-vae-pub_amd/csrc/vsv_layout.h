@@ -23,7 +23,7 @@
 
 namespace vsv {
 
-constexpr int kMaxDenseLayers = 6;
+constexpr int kMaxDenseLayers = 8;
 constexpr int kMaxFeat = 128;      // widest activation vector (4 tiles of 32)
 constexpr int kHeadTiles = 4;      // decoder-head layers (all but the last) are padded to 4 tiles
 
@@ -36,13 +36,14 @@ struct Sec {                       // one packed layer
 };
 
 struct EncLayout {
-    int n_conv = 0;
-    Sec conv[VSV_MAX_CONV];
+    int n_conv = 0;                // conv layers
+    int n_chain = 0;               // conv layers + interaction Linears: the dense chain in front of the LSTM
+    Sec conv[kMaxDenseLayers];     // the chain; the ex-features are injected into the output of conv[n_conv-1]
     Sec lstm[2];                   // k-space: layer 0 = [x: kx | h0: 4*NTm], layer 1 = [h0 | h1]
     Sec head;                      // [z_mean; z_log_var] (which=0) or final_compression (which=1)
     int nh = 0;                    // head outputs: 2L or L
     int E = 0;                     // LSTM input features: c_last*25 + X
-    int kx = 0;                    // k-steps of the LSTM x part (PERM32 order): 16 * tiles of the last conv
+    int kx = 0;                    // k-steps of the LSTM x part (PERM32 order): 16 * tiles of the chain's last layer
     int ex_f0 = 0;                 // first ex-feature slot in the embedding (c_last*25)
 };
 
@@ -50,7 +51,7 @@ struct DecLayout {
     Sec lstm[2];                   // k-space: layer 0 = [x: kx | h0: 4*NTd], layer 1 = [h0 | h1]
     int kx = 0;                    // k-steps of [ctx | z] in natural order: ceil(2L/2) rounded up to 4
     int n_head = 0;
-    Sec head[kMaxDenseLayers];     // Linear, ConvT x n_conv, Conv
+    Sec head[kMaxDenseLayers];     // [interaction Linears,] Linear, ConvT x n_conv, Conv
     int ex_layer = -1;             // head layer whose features [ex_f0, ex_f0+X) are the ex output
     int ex_f0 = 0;
     int n_surf = 0;                // Q*25
@@ -58,6 +59,7 @@ struct DecLayout {
 
 struct Layout {
     int L = 0, X = 0, Hm = 0, NL = 0, Q = 0;
+    int NI = 0;                    // interaction Linears per module: 0, or interaction_layers + 1
     int Hd = 0;                    // decoder LSTM hidden = c_last*25 + X
     int NTm = 0, NTd = 0;          // gate tiles (8 hidden units each) of encoder / decoder LSTMs
     EncLayout enc[2];              // 0 = encoder, 1 = ctx_encoder

@@ -52,8 +52,12 @@ int make_layout(const vsv_dims& d, Layout& lay, const char** msg) {
     if (lay.NL < 1 || lay.NL > 2) return fail("mem_layers must be 1 or 2");
     if (lay.Hm < 4 || lay.Hm > 128) return fail("mem_hidden must be in [4,128]");
     if (lay.Q < 1 || lay.Q * 25 > kMaxFeat) return fail("n_quantiles*25 must be <= 128");
+    if (d.interaction_layers < 0 || d.interaction_layers + 1 > VSV_MAX_INTERACT) return fail("interaction_layers must be in [0,2]");
+    lay.NI = d.interaction_layers > 0 ? d.interaction_layers + 1 : 0;
     if (d.n_conv < 1 || d.n_conv > VSV_MAX_CONV || d.n_ctx_conv < 1 || d.n_ctx_conv > VSV_MAX_CONV)
         return fail("1..4 conv layers supported");
+    if (d.n_conv + lay.NI > kMaxDenseLayers || d.n_ctx_conv + lay.NI > kMaxDenseLayers || 2 + d.n_conv + lay.NI > kMaxDenseLayers)
+        return fail("too many conv + interaction layers for one dense chain (8)");
     for (int i = 0; i < d.n_conv; ++i)
         if (d.surface_hidden[i] < 1 || d.surface_hidden[i] * 25 + lay.X > kMaxFeat)
             return fail("surface_hidden[i]*25 + ex_feats_dim must be <= 128");
@@ -88,6 +92,13 @@ int make_layout(const vsv_dims& d, Layout& lay, const char** msg) {
         }
         e.E = ch[e.n_conv - 1] * 25 + lay.X;
         e.ex_f0 = ch[e.n_conv - 1] * 25;
+        e.n_chain = e.n_conv;
+        for (int j = 0; j < lay.NI; ++j) {
+            // interaction Linear j: E -> E, ReLU on all but the final one
+            const int nt = cdiv(e.E, 32);
+            e.conv[e.n_chain++] = alloc_sec(cur, 4 * nt_prev, nt, e.E, j < lay.NI - 1 ? e.E : 0);
+            nt_prev = nt;
+        }
         e.kx = 16 * nt_prev;
         e.lstm[0] = alloc_sec(cur, e.kx / 4 + lay.NTm, lay.NTm, 4 * lay.Hm, 0);
         if (lay.NL == 2) e.lstm[1] = alloc_sec(cur, 2 * lay.NTm, lay.NTm, 4 * lay.Hm, 0);
@@ -102,9 +113,11 @@ int make_layout(const vsv_dims& d, Layout& lay, const char** msg) {
     // All layers but the last are padded to kHeadTiles tiles (zero rows) so the fused
     // decoder kernel can chain them through registers with compile-time shapes.
     int nh = 0;
+    for (int j = 0; j < lay.NI; ++j)       // interaction Linears on the LSTM output: Hd -> Hd
+        dc.head[nh++] = alloc_sec(cur, j == 0 ? lay.NTd : 4 * kHeadTiles, kHeadTiles, lay.Hd, j < lay.NI - 1 ? lay.Hd : 0);
     {
         const int n_out = c_last * 25 + lay.X;
-        dc.head[nh++] = alloc_sec(cur, lay.NTd, kHeadTiles, n_out, 0);
+        dc.head[nh++] = alloc_sec(cur, lay.NI > 0 ? 4 * kHeadTiles : lay.NTd, kHeadTiles, n_out, 0);
     }
     int cin = c_last;
     for (int i = 0; i < d.n_conv; ++i) {
@@ -278,6 +291,15 @@ extern "C" int vsv_pack_weights(const vsv_dims* dims, const vsv_raw_weights* raw
             pack_sec(out, e.conv[i], out_nat32(n_out), i == 0 ? in_nat(n_in) : in_perm(n_in), W, B);
             cin = cout;
         }
+        for (int j = 0; j < lay.NI; ++j) {
+            const float* w = (which ? raw->ctx_int_w : raw->enc_int_w)[j];
+            const float* b = (which ? raw->ctx_int_b : raw->enc_int_b)[j];
+            if (!w || !b) { set_error("vsv_pack_weights: missing interaction weight"); return -1; }
+            const int E = e.E;
+            WFn W = [=](int r, int c) { return w[(size_t)r * E + c]; };
+            BFn B = [=](int r) { return b[r]; };
+            pack_sec(out, e.conv[e.n_conv + j], out_nat32(E), in_perm(E), W, B);
+        }
         const vsv_lstm_raw& mem = which ? raw->ctx_mem : raw->enc_mem;
         pack_lstm(out, e.lstm, mem, lay.NL, Hm, e.E, e.kx, in_perm(e.E));
         if (which == 0) {
@@ -298,13 +320,20 @@ extern "C" int vsv_pack_weights(const vsv_dims* dims, const vsv_raw_weights* raw
     pack_lstm(out, dc.lstm, raw->dec_mem, lay.NL, Hd, 2 * L, dc.kx, in_nat(2 * L));
     int hi = 0;
     const int c_last = d.surface_hidden[d.n_conv - 1];
+    for (int j = 0; j < lay.NI; ++j) {
+        const float *w = raw->dec_int_w[j], *b = raw->dec_int_b[j];
+        if (!w || !b) { set_error("vsv_pack_weights: missing decoder interaction weight"); return -1; }
+        WFn W = [=](int r, int c) { return w[(size_t)r * Hd + c]; };
+        BFn B = [=](int r) { return b[r]; };
+        pack_sec(out, dc.head[hi++], out_nat32(Hd), j == 0 ? in_nat(Hd) : in_perm(Hd), W, B);
+    }
     {   // Linear: rows [surface_decoder_input ; ex_feats_decoder_input]
         const int ns = c_last * 25;
         const float *ws = raw->dec_in_w, *bs = raw->dec_in_b, *we = raw->ex_in_w, *be = raw->ex_in_b;
         if (X > 0 && (!we || !be)) { set_error("vsv_pack_weights: missing ex_feats_decoder_input"); return -1; }
         WFn W = [=](int r, int c) { return r < ns ? ws[(size_t)r * Hd + c] : we[(size_t)(r - ns) * Hd + c]; };
         BFn B = [=](int r) { return r < ns ? bs[r] : be[r - ns]; };
-        pack_sec(out, dc.head[hi++], out_nat32(ns + X), in_nat(Hd), W, B);
+        pack_sec(out, dc.head[hi++], out_nat32(ns + X), lay.NI > 0 ? in_perm(Hd) : in_nat(Hd), W, B);
     }
     int cin = c_last;
     for (int i = 0; i < d.n_conv; ++i) {
@@ -338,9 +367,9 @@ extern "C" int vsv_pack_weights(const vsv_dims* dims, const vsv_raw_weights* raw
 }
 
 // Diagnostic: dump the blob layout as int64 records of 6 (w_off, b_off, nq, nt, n_relu, n_out).
-// Order: for which in {enc, ctx}: conv[0..3], lstm[0..1], head; then dec: lstm[0..1], head[0..5];
+// Order: for which in {enc, ctx}: chain[0..7], lstm[0..1], head; then dec: lstm[0..1], head[0..7];
 // then scalars: enc.kx, ctx.kx, enc.nh, ctx.nh, enc.E, enc.ex_f0, dec.kx, dec.n_head, dec.ex_layer,
-// dec.ex_f0, NTm, NTd, Hd.  Returns the number of int64 written (or needed when out is NULL).
+// dec.ex_f0, NTm, NTd, Hd, enc.n_chain, ctx.n_chain, NI.  Returns the number of int64 written (or needed when out is NULL).
 extern "C" int vsv_debug_layout(const vsv_dims* dims, long long* out, int cap) {
     Layout lay;
     const char* msg = nullptr;
@@ -354,14 +383,14 @@ extern "C" int vsv_debug_layout(const vsv_dims* dims, long long* out, int cap) {
         v.push_back(s.nt); v.push_back(s.n_relu); v.push_back(s.n_out);
     };
     for (int w = 0; w < 2; ++w) {
-        for (int i = 0; i < VSV_MAX_CONV; ++i) put(lay.enc[w].conv[i]);
+        for (int i = 0; i < kMaxDenseLayers; ++i) put(lay.enc[w].conv[i]);
         put(lay.enc[w].lstm[0]); put(lay.enc[w].lstm[1]); put(lay.enc[w].head);
     }
     put(lay.dec.lstm[0]); put(lay.dec.lstm[1]);
     for (int i = 0; i < kMaxDenseLayers; ++i) put(lay.dec.head[i]);
     const long long sc[] = {lay.enc[0].kx, lay.enc[1].kx, lay.enc[0].nh, lay.enc[1].nh, lay.enc[0].E,
                             lay.enc[0].ex_f0, lay.dec.kx, lay.dec.n_head, lay.dec.ex_layer, lay.dec.ex_f0,
-                            lay.NTm, lay.NTd, lay.Hd};
+                            lay.NTm, lay.NTd, lay.Hd, lay.enc[0].n_chain, lay.enc[1].n_chain, lay.NI};
     for (long long x : sc) v.push_back(x);
     if (out) {
         if (cap < (int)v.size()) { set_error("vsv_debug_layout: buffer too small"); return -1; }

@@ -39,9 +39,16 @@ class ConditionalPriorNetwork(nn.Module):
                 raise NotImplementedError("ctx_ex_feats_hidden must be None")
             self.ex_feats_embedding = nn.Identity()
             width += config["ex_feats_dim"]
-        if config["interaction_layers"] is not None and config["interaction_layers"] > 0:
-            raise NotImplementedError("interaction_layers > 0 is not built for gfx950 yet")
-        self.interaction = nn.Identity()
+        n_int = config["interaction_layers"]
+        if n_int is not None and n_int > 0:
+            inter = OrderedDict()
+            for i in range(n_int):
+                inter[f"prior_interact_linear_{i}"] = nn.Linear(width, width)
+                inter[f"prior_interaction_activation_{i}"] = nn.ReLU()
+            inter["prior_interact_linear_final"] = nn.Linear(width, width)
+            self.interaction = nn.Sequential(inter)
+        else:
+            self.interaction = nn.Identity()
         kind = {"lstm": nn.LSTM, "gru": nn.GRU}.get(config["mem_type"], nn.RNN)
         self.mem = kind(input_size=width, hidden_size=config["mem_hidden"], num_layers=config["mem_layers"],
                         batch_first=True, dropout=config["mem_dropout"])

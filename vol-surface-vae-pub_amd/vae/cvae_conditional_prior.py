@@ -52,6 +52,8 @@ class CVAEMemRandConditionalPrior(CVAEMemRand):
             conv = getattr(pn.surface_embedding, f"prior_enc_conv_{i}")
             sub[f"encoder.surface_embedding.enc_conv_{i}.weight"] = conv.weight
             sub[f"encoder.surface_embedding.enc_conv_{i}.bias"] = conv.bias
+        for n, p in pn.interaction.named_parameters():              # prior_interact_linear_* -> enc_interact_linear_*
+            sub["encoder.interaction." + n.replace("prior_interact", "enc_interact")] = p
         for n, p in pn.mem.named_parameters():
             sub[f"encoder.mem.{n}"] = p
         Wc, bc = pn.compression.weight, pn.compression.bias
@@ -216,6 +218,8 @@ class CVAEMemRandConditionalPrior(CVAEMemRand):
             conv = getattr(pn.surface_embedding, f"prior_enc_conv_{i}")
             pairs += [(conv.weight, g[f"encoder.surface_embedding.enc_conv_{i}.weight"]),
                       (conv.bias, g[f"encoder.surface_embedding.enc_conv_{i}.bias"])]
+        for n, p in pn.interaction.named_parameters():
+            pairs.append((p, g["encoder.interaction." + n.replace("prior_interact", "enc_interact")]))
         for n, p in pn.mem.named_parameters():
             pairs.append((p, g[f"encoder.mem.{n}"]))
         Wc, bc = pn.compression.weight.detach().float(), pn.compression.bias.detach().float()

@@ -9,8 +9,8 @@ give the model the reference's parameter names, shapes, default initialisation a
 checkpoint compatibility, but their own forward() is never called.  There is no
 CPU fallback: calling a compute method without a GPU raises.
 
-Implemented topology (what every config in the reference repo uses): conv surface
-embedding, mem_type="lstm", compress_context=True, interaction_layers=None,
+Implemented topology (what the configs in the reference repo use): conv surface
+embedding, mem_type="lstm", compress_context=True, interaction_layers None / 1 / 2,
 ex_feats_hidden=None.  Other switches parse and then raise NotImplementedError
 at the first compute call.
 """

@@ -21,8 +21,6 @@ def dims_from_config(cfg: dict) -> _lib.VsvDims:
         raise NotImplementedError("HIP path implements mem_type='lstm' only")
     if cfg.get("use_dense_surface", False):
         raise NotImplementedError("HIP path implements the conv surface embedding only")
-    if cfg.get("interaction_layers"):
-        raise NotImplementedError("HIP path implements interaction_layers=None only")
     if not cfg.get("compress_context", False):
         raise NotImplementedError("HIP path implements compress_context=True only")
     if cfg.get("ex_feats_hidden") is not None or cfg.get("ctx_ex_feats_hidden") is not None:
@@ -31,7 +29,7 @@ def dims_from_config(cfg: dict) -> _lib.VsvDims:
         raise NotImplementedError("HIP path implements the 5x5 grid only")
     return _lib.make_dims(cfg["latent_dim"], cfg["ex_feats_dim"], cfg["mem_hidden"], cfg["mem_layers"],
                           list(cfg["surface_hidden"]), list(cfg["ctx_surface_hidden"]),
-                          len(cfg.get("quantiles", [0.05, 0.5, 0.95])))
+                          len(cfg.get("quantiles", [0.05, 0.5, 0.95])), cfg.get("interaction_layers") or 0)
 
 
 def _fp(a: np.ndarray):
@@ -75,6 +73,15 @@ def pack_state_dict(dims: _lib.VsvDims, sd: Dict[str, np.ndarray]) -> np.ndarray
         raw.dec_deconv_w[i] = get(f"decoder.surface_decoder.{nm}.weight")
         raw.dec_deconv_b[i] = get(f"decoder.surface_decoder.{nm}.bias")
     raw.dec_out_w, raw.dec_out_b = get("decoder.surface_decoder.dec_output.weight"), get("decoder.surface_decoder.dec_output.bias")
+    if dims.interaction_layers > 0:
+        # n Linear+ReLU and a final Linear per module (reference :131-142, :283-294, :452-463)
+        for dst_w, dst_b, mod, pf in ((raw.enc_int_w, raw.enc_int_b, "encoder", "enc"),
+                                      (raw.ctx_int_w, raw.ctx_int_b, "ctx_encoder", "ctx"),
+                                      (raw.dec_int_w, raw.dec_int_b, "decoder", "dec")):
+            names = [f"{pf}_interact_linear_{i}" for i in range(dims.interaction_layers)] + [f"{pf}_interact_linear_final"]
+            for i, nm in enumerate(names):
+                dst_w[i] = get(f"{mod}.interaction.{nm}.weight")
+                dst_b[i] = get(f"{mod}.interaction.{nm}.bias")
     if dims.ex_feats_dim > 0:
         raw.ex_in_w, raw.ex_in_b = get("decoder.ex_feats_decoder_input.weight"), get("decoder.ex_feats_decoder_input.bias")
         raw.ex_out_w, raw.ex_out_b = get("decoder.ex_feats_decoder.weight"), get("decoder.ex_feats_decoder.bias")

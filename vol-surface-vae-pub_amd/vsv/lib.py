@@ -14,6 +14,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("VSV_LIB") or os.path.join(os.path.dirname(_HERE), "lib", "libvsv_hip.so")   # VSV_LIB: A/B builds
 
 VSV_MAX_CONV = 4
+VSV_MAX_INTERACT = 3
 
 
 class VsvDims(C.Structure):
@@ -21,7 +22,7 @@ class VsvDims(C.Structure):
         ("latent_dim", C.c_int), ("ex_feats_dim", C.c_int), ("mem_hidden", C.c_int),
         ("mem_layers", C.c_int), ("n_conv", C.c_int), ("surface_hidden", C.c_int * VSV_MAX_CONV),
         ("n_ctx_conv", C.c_int), ("ctx_surface_hidden", C.c_int * VSV_MAX_CONV),
-        ("n_quantiles", C.c_int),
+        ("n_quantiles", C.c_int), ("interaction_layers", C.c_int),
     ]
 
 
@@ -45,6 +46,9 @@ class VsvRawWeights(C.Structure):
         ("dec_deconv_w", _FP * VSV_MAX_CONV), ("dec_deconv_b", _FP * VSV_MAX_CONV),
         ("dec_out_w", _FP), ("dec_out_b", _FP),
         ("ex_in_w", _FP), ("ex_in_b", _FP), ("ex_out_w", _FP), ("ex_out_b", _FP),
+        ("enc_int_w", _FP * VSV_MAX_INTERACT), ("enc_int_b", _FP * VSV_MAX_INTERACT),
+        ("ctx_int_w", _FP * VSV_MAX_INTERACT), ("ctx_int_b", _FP * VSV_MAX_INTERACT),
+        ("dec_int_w", _FP * VSV_MAX_INTERACT), ("dec_int_b", _FP * VSV_MAX_INTERACT),
     ]
 
 
@@ -60,7 +64,7 @@ class VsvDecodeIn(C.Structure):
     ]
 
 
-VSV_MAX_CHAIN = 6
+VSV_MAX_CHAIN = 8
 
 
 class VsvTrainSave(C.Structure):
@@ -158,7 +162,7 @@ def load() -> C.CDLL:
             fn = getattr(lib, name)
             fn.restype = res
             fn.argtypes = args
-        if lib.vsv_abi_version() != 4:
+        if lib.vsv_abi_version() != 5:
             raise RuntimeError("libvsv_hip.so ABI version mismatch")
         _lib = lib
     return _lib
@@ -177,8 +181,11 @@ def check(rc: int, what: str) -> None:
 
 
 def make_dims(latent_dim, ex_feats_dim, mem_hidden, mem_layers, surface_hidden, ctx_surface_hidden,
-              n_quantiles) -> VsvDims:
+              n_quantiles, interaction_layers=0) -> VsvDims:
     d = VsvDims()
+    d.interaction_layers = int(interaction_layers or 0)
+    if d.interaction_layers + 1 > VSV_MAX_INTERACT:
+        raise NotImplementedError("at most 2 interaction layers are supported by the HIP path")
     d.latent_dim, d.ex_feats_dim, d.mem_hidden, d.mem_layers = latent_dim, ex_feats_dim, mem_hidden, mem_layers
     if len(surface_hidden) > VSV_MAX_CONV or len(ctx_surface_hidden) > VSV_MAX_CONV:
         raise NotImplementedError("at most 4 conv layers are supported by the HIP path")

@@ -35,17 +35,20 @@ def read_layout(dims) -> dict:
     buf = (C.c_longlong * n)()
     assert L.vsv_debug_layout(C.byref(dims), buf, n) == n
     v = np.array(buf[:], dtype=np.int64)
-    recs = v[: 6 * 22].reshape(22, 6)
+    MC = 8                                                     # kMaxDenseLayers
+    nrec = 2 * (MC + 3) + 2 + MC
+    recs = v[: 6 * nrec].reshape(nrec, 6)
     lay = {"enc": []}
     for w in range(2):
-        base = w * 7
-        lay["enc"].append(dict(conv=[_Sec(recs[base + i]) for i in range(4)],
-                               lstm=[_Sec(recs[base + 4]), _Sec(recs[base + 5])], head=_Sec(recs[base + 6])))
-    lay["dec"] = dict(lstm=[_Sec(recs[14]), _Sec(recs[15])], head=[_Sec(recs[16 + i]) for i in range(6)])
-    sc = [int(x) for x in v[6 * 22:]]
+        base = w * (MC + 3)
+        lay["enc"].append(dict(conv=[_Sec(recs[base + i]) for i in range(MC)],
+                               lstm=[_Sec(recs[base + MC]), _Sec(recs[base + MC + 1])], head=_Sec(recs[base + MC + 2])))
+    d0 = 2 * (MC + 3)
+    lay["dec"] = dict(lstm=[_Sec(recs[d0]), _Sec(recs[d0 + 1])], head=[_Sec(recs[d0 + 2 + i]) for i in range(MC)])
+    sc = [int(x) for x in v[6 * nrec:]]
     (lay["enc"][0]["kx"], lay["enc"][1]["kx"], lay["enc"][0]["nh"], lay["enc"][1]["nh"], lay["E"], lay["ex_f0"],
      lay["dec"]["kx"], lay["dec"]["n_head"], lay["dec"]["ex_layer"], lay["dec"]["ex_f0"],
-     lay["NTm"], lay["NTd"], lay["Hd"]) = sc
+     lay["NTm"], lay["NTd"], lay["Hd"], lay["enc"][0]["n_chain"], lay["enc"][1]["n_chain"], lay["NI"]) = sc
     return lay
 
 
@@ -124,7 +127,8 @@ class TrainEngine:
         self.dims = eng.dims
         self.lay = lay = read_layout(eng.dims)
         self.NL = eng.dims.mem_layers
-        self.n_conv = [eng.dims.n_conv, eng.dims.n_ctx_conv]
+        # dense chain in front of each encoder's LSTM: conv layers [+ interaction Linears]
+        self.n_conv = [lay["enc"][0]["n_chain"], lay["enc"][1]["n_chain"]]
         self.L, self.X, self.Q = eng.L, eng.X, eng.Q
         self.Hm = eng.dims.mem_hidden
         NTm, NTd = lay["NTm"], lay["NTd"]

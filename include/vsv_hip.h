@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define VSV_ABI_VERSION 5
+#define VSV_ABI_VERSION 6
 #define VSV_MAX_CONV 4
 #define VSV_MAX_CHAIN 8
 #define VSV_MAX_INTERACT 3
@@ -37,7 +37,7 @@ extern "C" {
 /* Model shape: the subset of the reference's config dict that fixes tensor
  * shapes (cvae_with_mem_randomized.py:969-1020; state_dict layout SURVEY.md
  * appendix A).  Only the production topology is implemented: conv surface
- * embedding on a 5x5 grid, LSTM memory, compress_context=True, ex_feats_hidden=None;
+ * embedding on a 5x5 grid, LSTM or GRU memory, compress_context=True, ex_feats_hidden=None;
  * interaction_layers 0..2 (the Linear+ReLU "interaction" stacks of :131-142, :283-294, :452-463,
  * turned on by the v3 conditional-prior trainer). */
 typedef struct vsv_dims {
@@ -51,10 +51,12 @@ typedef struct vsv_dims {
     int ctx_surface_hidden[VSV_MAX_CONV];
     int n_quantiles;                   /* Q = len(config["quantiles"])       */
     int interaction_layers;            /* config["interaction_layers"] or 0: n Linear+ReLU + 1 Linear, width kept */
+    int mem_type;                      /* config["mem_type"]: 0 "lstm" (nn.LSTM), 1 "gru" (nn.GRU), :154-159 */
 } vsv_dims;
 
 /* Raw parameters in PyTorch state_dict layout (HOST pointers, float32,
- * contiguous).  Names follow SURVEY.md appendix A. */
+ * contiguous).  Names follow SURVEY.md appendix A.  With mem_type 1 the memory
+ * tensors have nn.GRU's shapes (3*hidden rows: r, z, n). */
 typedef struct vsv_lstm_raw {
     const float *w_ih[2], *w_hh[2], *b_ih[2], *b_hh[2];   /* per layer */
 } vsv_lstm_raw;
@@ -266,6 +268,7 @@ typedef struct vsv_lstm_bwd {
     float drop_p;                           /* as in vsv_train_save: masks d(layer 0 output) coming from layer 1 */
     uint64_t drop_seed;
     int drop_id;
+    int gru;                                /* 1: the saved gates are nn.GRU's (r, z, n, W_hn h + b_hn) */
 } vsv_lstm_bwd;
 int vsv_lstm_backward(const vsv_lstm_bwd *d, int hidden, int layers, void *stream);
 

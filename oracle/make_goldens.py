@@ -450,6 +450,27 @@ def main_interaction():
     case_cprior_train("g8_cprior_train_int2_ex12_B4_T24_h3", ex12i, 66, 2.0, 4, 24, 3, [1, 7])
 
 
+def main_gru():
+    """mem_type="gru" (nn.GRU memories, :154-159 / :306-311 / :475-480): forward, prior generation,
+    train_step gradients, one-layer, and the conditional-prior variant."""
+    f32, f64 = np.float32, np.float64
+    ex5 = vo.make_config(5, 3, mem_type="gru")
+    noex = vo.make_config(5, 0, mem_type="gru")
+    ex12 = vo.make_config(12, 3, mem_type="gru", quantile_loss_weights=[5.0, 1.0, 5.0], kl_weight=1e-3)
+    one = vo.make_config(5, 0, mem_layers=1, mem_type="gru")
+    case_forward("g1_fwd_gru_ex5_T21_h1_f32", ex5, 70, 2.0, f32, 4, 21, 1)
+    case_forward("g1_fwd_gru_noex_T9_h3_f64", noex, 71, 2.0, f64, 3, 9, 3)
+    case_forward("g1_fwd_gru_1layer_T6_h1_f32", one, 72, 1.0, f32, 2, 6, 1)
+    case_prior("g2_prior_gru_ex12_C20_H7_f32", ex12, 73, 2.0, f32, 6, 20, 7)
+    case_prior("g2_prior_gru_noex_C5_H1_f64", noex, 74, 2.0, f64, 8, 5, 1)
+    case_grads("g4_grads_gru_ex5_B6_T21_h3", ex5, 75, 2.0, 6, 21, 3, full=False)
+    case_grads("g4_grads_gru_ex12_B4_T20_h7", ex12, 76, 2.0, 4, 20, 7, full=False)
+    case_grads("g4_grads_gru_1layer_B5_T9_h2", one, 77, 2.0, 5, 9, 2, full=False)
+    case_ar("g6_ar_gru_ex5_C20_H30", ex5, 78, 2.0, 4, 20, 30)
+    case_cprior_gen("g8_cprior_gen_gru_ex5_C20_H7_f32", ex5, 79, 2.0, f32, 4, 20, 7, True, 0.3)
+    case_cprior_train("g8_cprior_train_gru_ex5_B4_T24_h3", ex5, 80, 2.0, 4, 24, 3, [1, 7])
+
+
 def main_cprior():
     f32, f64 = np.float32, np.float64
     ex5 = vo.make_config(5, 3)
@@ -488,6 +509,7 @@ def save(name, cfg, d):
     d["cfg_ex_feats_dim"] = cfg["ex_feats_dim"]
     d["cfg_mem_layers"] = cfg["mem_layers"]
     d["cfg_interaction_layers"] = int(cfg.get("interaction_layers") or 0)
+    d["cfg_mem_type"] = np.asarray(cfg.get("mem_type", "lstm"))
     d["cfg_quantile_loss_weights"] = np.asarray(cfg.get("quantile_loss_weights") or [1.0, 1.0, 1.0])
     for k in ("ex_loss_on_ret_only", "ex_feats_loss_type", "kl_weight", "re_feat_weight"):
         d["cfg_" + k] = np.asarray(cfg[k])
@@ -528,6 +550,7 @@ def main():
     main_cprior()
     main_ar_train()
     main_interaction()
+    main_gru()
 
 
 def case_sampler():
@@ -572,6 +595,9 @@ if __name__ == "__main__":
     elif len(sys.argv) > 1 and sys.argv[1] == "interaction":
         os.makedirs(OUT, exist_ok=True)
         main_interaction()
+    elif len(sys.argv) > 1 and sys.argv[1] == "gru":
+        os.makedirs(OUT, exist_ok=True)
+        main_gru()
     elif len(sys.argv) > 1 and sys.argv[1] == "artrain":
         os.makedirs(OUT, exist_ok=True)
         main_ar_train()

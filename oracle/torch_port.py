@@ -35,7 +35,8 @@ class TorchPort(nn.Module):
                                    for k, v in W.items() if ".mem." not in k})
         self.mems = nn.ModuleDict()
         for name, inp, hid in (("encoder", E, Hm), ("ctx_encoder", E, Hm), ("decoder", 2 * self.L, self.Hd)):
-            m = nn.LSTM(inp, hid, num_layers=self.nl, batch_first=True, dropout=dropout)   # :155, :307, :476
+            kind = nn.GRU if cfg.get("mem_type", "lstm") == "gru" else nn.LSTM            # :154-159
+            m = kind(inp, hid, num_layers=self.nl, batch_first=True, dropout=dropout)     # :155, :307, :476
             m = m.to(dtype)
             with torch.no_grad():
                 for l in range(self.nl):
@@ -61,7 +62,10 @@ class TorchPort(nn.Module):
         for l in range(self.nl):
             ws = [getattr(m, f"{p}_l{l}") for p in ("weight_ih", "weight_hh", "bias_ih", "bias_hh")]
             z = torch.zeros(1, B, m.hidden_size, dtype=x.dtype)
-            h = torch._VF.lstm(h, (z, z), ws, True, 1, 0.0, False, False, True)[0]
+            if isinstance(m, nn.GRU):
+                h = torch._VF.gru(h, z, ws, True, 1, 0.0, False, False, True)[0]
+            else:
+                h = torch._VF.lstm(h, (z, z), ws, True, 1, 0.0, False, False, True)[0]
             if l + 1 < self.nl:
                 h = h * self.drop_masks[name][:, : h.shape[1]]
         return h

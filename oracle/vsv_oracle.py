@@ -82,13 +82,15 @@ def state_dict_spec(cfg: dict) -> List[Tuple[str, Tuple[int, ...]]]:
             spec.append((f"{prefix}.{nm}.bias", (co,)))
             cin = co
 
+    ng = 3 if cfg.get("mem_type", "lstm") == "gru" else 4     # gate row blocks: nn.GRU [r; z; n], nn.LSTM [i; f; g; o]
+
     def lstm(prefix, inp, hid):
         for l in range(nl):
             i = inp if l == 0 else hid
-            spec.append((f"{prefix}.weight_ih_l{l}", (4 * hid, i)))
-            spec.append((f"{prefix}.weight_hh_l{l}", (4 * hid, hid)))
-            spec.append((f"{prefix}.bias_ih_l{l}", (4 * hid,)))
-            spec.append((f"{prefix}.bias_hh_l{l}", (4 * hid,)))
+            spec.append((f"{prefix}.weight_ih_l{l}", (ng * hid, i)))
+            spec.append((f"{prefix}.weight_hh_l{l}", (ng * hid, hid)))
+            spec.append((f"{prefix}.bias_ih_l{l}", (ng * hid,)))
+            spec.append((f"{prefix}.bias_hh_l{l}", (ng * hid,)))
 
     n_int = cfg.get("interaction_layers") or 0
 
@@ -141,8 +143,7 @@ def init_weights(cfg: dict, seed: int = 0, scale: float = 1.0,
     Hm = cfg["mem_hidden"]
     for name, shape in state_dict_spec(cfg):
         if ".mem." in name:
-            hid = shape[0] // 4
-            fan = hid
+            fan = dict(state_dict_spec(cfg))[name.rsplit(".", 1)[0] + "." + "weight_hh_l" + name[-1]][1]   # hidden size
         elif len(shape) == 4:
             # Conv2d fan_in = Cin*9; ConvTranspose2d (in,out,k,k) fan uses dim 1
             fan = shape[1] * 9
@@ -175,10 +176,11 @@ def prior_state_dict_spec(cfg: dict) -> List[Tuple[str, Tuple[int, ...]]]:
     if n_int > 0:
         for nm in [f"prior_interact_linear_{i}" for i in range(n_int)] + ["prior_interact_linear_final"]:
             spec += [(f"prior_network.interaction.{nm}.weight", (E, E)), (f"prior_network.interaction.{nm}.bias", (E,))]
+    ng = 3 if cfg.get("mem_type", "lstm") == "gru" else 4
     for l in range(nl):
         i = E if l == 0 else Hm
-        spec += [(f"prior_network.mem.weight_ih_l{l}", (4 * Hm, i)), (f"prior_network.mem.weight_hh_l{l}", (4 * Hm, Hm)),
-                 (f"prior_network.mem.bias_ih_l{l}", (4 * Hm,)), (f"prior_network.mem.bias_hh_l{l}", (4 * Hm,))]
+        spec += [(f"prior_network.mem.weight_ih_l{l}", (ng * Hm, i)), (f"prior_network.mem.weight_hh_l{l}", (ng * Hm, Hm)),
+                 (f"prior_network.mem.bias_ih_l{l}", (ng * Hm,)), (f"prior_network.mem.bias_hh_l{l}", (ng * Hm,))]
     spec += [("prior_network.compression.weight", (L, Hm)), ("prior_network.compression.bias", (L,)),
              ("prior_network.prior_mean_layer.weight", (L, L)), ("prior_network.prior_mean_layer.bias", (L,)),
              ("prior_network.prior_logvar_layer.weight", (L, L)), ("prior_network.prior_logvar_layer.bias", (L,))]
@@ -193,7 +195,7 @@ def init_prior_weights(cfg: dict, seed: int = 0, scale: float = 1.0, dtype=np.fl
     W: Weights = {}
     for name, shape in spec:
         if ".mem." in name:
-            fan = shape[0] // 4
+            fan = shapes[name.rsplit(".", 1)[0] + ".weight_hh_l" + name[-1]][1]      # hidden size
         else:
             ws = shape if name.endswith(".weight") else shapes[name[:-4] + "weight"]
             fan = ws[1] * (9 if len(ws) == 4 else 1)
@@ -247,7 +249,9 @@ def lstm_forward(x: np.ndarray, W: Weights, prefix: str, n_layers: int,
     """nn.LSTM(batch_first=True), eval mode (no inter-layer dropout).
     Gate row blocks [i; f; g; o]; c' = f*c + i*g; h' = o*tanh(c').
     x (B,T,I) -> (B,T,H), final [(h,c)] per layer.  Call sites:
-    cvae_with_mem_randomized.py:155, 193, 307, 342, 476, 491."""
+    cvae_with_mem_randomized.py:155, 193, 307, 342, 476, 491.
+    mem_type "gru" (weights with 3H rows, :156-157): nn.GRU, row blocks [r; z; n],
+    n = tanh(W_in x + b_in + r * (W_hn h + b_hn)), h' = (1 - z) * n + z * h; the returned state is (h, h)."""
     B, T, _ = x.shape
     inp = x
     finals = []
@@ -255,8 +259,24 @@ def lstm_forward(x: np.ndarray, W: Weights, prefix: str, n_layers: int,
     for l in range(n_layers):
         w_ih = W[f"{prefix}.weight_ih_l{l}"]
         w_hh = W[f"{prefix}.weight_hh_l{l}"]
-        bias = W[f"{prefix}.bias_ih_l{l}"] + W[f"{prefix}.bias_hh_l{l}"]
         Hh = w_hh.shape[1]
+        if w_hh.shape[0] == 3 * Hh:
+            assert not return_cache
+            b_ih, b_hh = W[f"{prefix}.bias_ih_l{l}"], W[f"{prefix}.bias_hh_l{l}"]
+            h = np.zeros((B, Hh), dtype=x.dtype) if state is None else np.broadcast_to(state[l][0], (B, Hh)).copy()
+            xproj = inp @ w_ih.T + b_ih
+            out = np.empty((B, T, Hh), dtype=x.dtype)
+            for t in range(T):
+                hp = h @ w_hh.T + b_hh
+                r = _sigmoid(xproj[:, t, :Hh] + hp[:, :Hh])
+                z = _sigmoid(xproj[:, t, Hh:2 * Hh] + hp[:, Hh:2 * Hh])
+                n = np.tanh(xproj[:, t, 2 * Hh:] + r * hp[:, 2 * Hh:])
+                h = (1 - z) * n + z * h
+                out[:, t] = h
+            finals.append((h, h))
+            inp = out
+            continue
+        bias = W[f"{prefix}.bias_ih_l{l}"] + W[f"{prefix}.bias_hh_l{l}"]
         if state is None:
             h = np.zeros((B, Hh), dtype=x.dtype)
             c = np.zeros((B, Hh), dtype=x.dtype)

@@ -35,6 +35,8 @@ def cfg_of(g):
         cfg["quantile_loss_weights"] = w
     if "cfg_interaction_layers" in g and int(g["cfg_interaction_layers"]) > 0:
         cfg["interaction_layers"] = int(g["cfg_interaction_layers"])
+    if "cfg_mem_type" in g:
+        cfg["mem_type"] = str(g["cfg_mem_type"])
     for k in ("ex_loss_on_ret_only", "ex_feats_loss_type", "kl_weight", "re_feat_weight"):
         if "cfg_" + k in g:
             v = g["cfg_" + k]

@@ -77,11 +77,12 @@ def test_forward_vs_reference(name):
         assert err(_n(e), g["ex_recon"]) <= TOL
 
 
-@pytest.mark.parametrize("L,X,D,S,C,H", [(5, 0, 3, 40, 20, 1), (12, 3, 5, 24, 60, 7), (5, 3, 2, 1000, 5, 2)])
-def test_prior_mc_vs_oracle_ragged_tiles(L, X, D, S, C, H):
+@pytest.mark.parametrize("L,X,D,S,C,H,mem", [(5, 0, 3, 40, 20, 1, "lstm"), (12, 3, 5, 24, 60, 7, "lstm"),
+                                             (5, 3, 2, 1000, 5, 2, "lstm"), (5, 3, 3, 300, 7, 4, "gru")])
+def test_prior_mc_vs_oracle_ragged_tiles(L, X, D, S, C, H, mem):
     """rows = D*S is not a multiple of the 16-row tile and tiles straddle days."""
     from vsv import paths
-    cfg = vo.make_config(L, X)
+    cfg = vo.make_config(L, X, mem_type=mem)
     eng, W = _engine(cfg, 77, 2.0)
     rng = np.random.default_rng(5)
     surf = (0.2 + 0.1 * rng.standard_normal((D, C, 5, 5))).astype(np.float32)
@@ -106,8 +107,9 @@ def test_fused_mc_decode_many_rows_vs_oracle():
     """> 32768 rows: the one-wave-per-tile schedule with the fused decoder head (the
     MC production path), ragged last tile, tiles straddling days, both output layouts."""
     from vsv import paths
-    for L, X, D, S, C, H in ((12, 3, 37, 1000, 4, 2), (5, 0, 67, 500, 3, 1)):
-        cfg = vo.make_config(L, X)
+    for L, X, D, S, C, H, mem in ((12, 3, 37, 1000, 4, 2, "lstm"), (5, 0, 67, 500, 3, 1, "lstm"),
+                                  (5, 3, 35, 1000, 3, 3, "gru")):
+        cfg = vo.make_config(L, X, mem_type=mem)
         eng, W = _engine(cfg, 21, 2.0)
         rng = np.random.default_rng(17)
         surf = (0.2 + 0.1 * rng.standard_normal((D, C, 5, 5))).astype(np.float32)
@@ -356,8 +358,9 @@ def test_multihorizon_losses_and_gradients_vs_reference():
     _check_grads(g, [n for n, _ in vo.state_dict_spec(cfg)], te.param_grads(gp_sum))
 
 
-@pytest.mark.parametrize("L,X,B,T,h,p", [(5, 3, 37, 12, 3, 0.25), (12, 3, 8, 30, 7, 0.3), (5, 0, 64, 6, 1, 0.2)])
-def test_train_with_lstm_dropout_vs_autograd_oracle(L, X, B, T, h, p):
+@pytest.mark.parametrize("L,X,B,T,h,p,mem", [(5, 3, 37, 12, 3, 0.25, "lstm"), (12, 3, 8, 30, 7, 0.3, "lstm"),
+                                             (5, 0, 64, 6, 1, 0.2, "lstm"), (5, 3, 20, 14, 4, 0.3, "gru")])
+def test_train_with_lstm_dropout_vs_autograd_oracle(L, X, B, T, h, p, mem):
     """nn.LSTM's inter-layer dropout (train mode, mem_dropout 0.2-0.3 in every production config).  The
     reference draws its masks from torch's generator inside nn.LSTM, so they cannot be reproduced: the
     HIP path's Philox masks are (a) checked against their numpy restatement and for their keep rate,
@@ -366,7 +369,7 @@ def test_train_with_lstm_dropout_vs_autograd_oracle(L, X, B, T, h, p):
     from oracle.torch_port import TorchPort
     from vsv.engine import Engine
     from vsv.train import TrainEngine
-    cfg = vo.make_config(L, X)
+    cfg = vo.make_config(L, X, mem_type=mem)
     cfg.update(ex_loss_on_ret_only=True, ex_feats_loss_type="l2", kl_weight=1e-3, re_feat_weight=1.0)
     W = vo.init_weights(cfg, 21, 1.5, np.float32)
     eng = Engine(cfg, W, "cuda:0")

@@ -95,7 +95,7 @@ def test_library_exports_every_declared_symbol():
     L = vlib.load()
     for name in declared:
         assert hasattr(L, name), name
-    assert L.vsv_abi_version() == 5
+    assert L.vsv_abi_version() == 6
     # argument validation happens before any GPU work
     d = vlib.make_dims(5, 0, 100, 2, [5, 5, 5], [5, 5, 5], 3)
     assert L.vsv_packed_floats(C.byref(d)) > 0
@@ -187,3 +187,26 @@ def test_interaction_layers_state_dict_keys():
     assert [k for k, _ in got if k.startswith("encoder.")] == [k for k, _ in want if k.startswith("encoder.")]
     assert "decoder.interaction.dec_interact_linear_final.weight" in sd
     assert "prior_network.interaction.prior_interact_linear_1.bias" in sd
+
+
+def test_mem_type_gru_accepted_rnn_rejected():
+    """mem_type "gru" maps to vsv_dims.mem_type 1 and packs into the same blob size as "lstm" (four gate
+    slots per unit: r, z, n_x, n_h); nn.RNN memories are not built and must be refused, not approximated."""
+    import ctypes as C
+    from oracle import vsv_oracle as vo
+    from vsv import lib as L_
+    from vsv.engine import dims_from_config, pack_state_dict
+    d0 = dims_from_config(vo.make_config(5, 3))
+    d1 = dims_from_config(vo.make_config(5, 3, mem_type="gru"))
+    assert (d0.mem_type, d1.mem_type) == (0, 1)
+    lib = L_.load()
+    assert lib.vsv_packed_floats(C.byref(d0)) == lib.vsv_packed_floats(C.byref(d1))
+    with pytest.raises(NotImplementedError):
+        dims_from_config(vo.make_config(5, 3, mem_type="rnn"))
+    cfg = vo.make_config(5, 3, mem_type="gru")
+    W = vo.init_weights(cfg, 3, 1.0, np.float32)
+    assert W["encoder.mem.weight_hh_l0"].shape == (300, 100)
+    blob = pack_state_dict(d1, W)
+    # every parameter value lands in the blob exactly once except the summed r/z biases
+    tot = sum(float(np.abs(v).sum()) for k, v in W.items() if "bias" not in k and not k.startswith("quantile_loss_fn"))
+    assert np.isfinite(blob).all() and float(np.abs(blob).sum()) >= tot * (1 - 1e-5)

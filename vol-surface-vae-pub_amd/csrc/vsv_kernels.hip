@@ -501,6 +501,7 @@ struct LstmSeqArgs {
     // which is also saved ([inst][4*NT][64]) as the X of layer 1's weight gradient
     DropArgs drop;
     float* sv_hd;
+    int gru;                // memory cell: 0 nn.LSTM, 1 nn.GRU
 };
 
 // per-thread constants of the decoder input assembly
@@ -547,7 +548,27 @@ __device__ __forceinline__ float decoder_input(const LstmSeqArgs& a, const DecIn
 
 // LSTM cell: lane holds gates (i,f,g,o) of unit 8t + 2jj + hh in acc[i][4jj .. 4jj+3]
 template <bool KEEP, int OWN>
-__device__ __forceinline__ void lstm_cell(f32x16 (&acc)[OWN], float (&c)[OWN][4], float (&hn)[OWN][4]) {
+__device__ __forceinline__ void lstm_cell(f32x16 (&acc)[OWN], float (&c)[OWN][4], float (&hn)[OWN][4], bool gru) {
+    if (gru) {
+        // nn.GRU: slots (r, z, n_x, n_h); n = tanh(n_x + r * n_h), h' = (1 - z) * n + z * h.  The `c`
+        // registers carry this lane's units of h.  KEEP leaves (r, z, n, n_h) for the backward pass.
+#pragma unroll
+        for (int i = 0; i < OWN; ++i) {
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) {
+                const float r = fast_sigmoid(acc[i][4 * jj + 0]);
+                const float z = fast_sigmoid(acc[i][4 * jj + 1]);
+                const float n = fast_tanh(acc[i][4 * jj + 2] + r * acc[i][4 * jj + 3]);
+                const float h = n + z * (c[i][jj] - n);
+                c[i][jj] = h;
+                hn[i][jj] = h;
+                if (KEEP) {
+                    acc[i][4 * jj + 0] = r; acc[i][4 * jj + 1] = z; acc[i][4 * jj + 2] = n;
+                }
+            }
+        }
+        return;
+    }
 #pragma unroll
     for (int i = 0; i < OWN; ++i) {
 #pragma unroll
@@ -869,7 +890,7 @@ lstm_kernel(const LstmSeqArgs a) {
                 if (l == NL - 1 && head_now) head_preload<NT>(a, wq, bq, opaque<OWN == 4>(lane), wave);
             }
             VSV_STAMP(2 + 3 * l);
-            lstm_cell<SAVE, OWN>(acc, c[l], hn);
+            lstm_cell<SAVE, OWN>(acc, c[l], hn, a.gru != 0);
             VSV_STAMP(3 + 3 * l);
             if (SAVE) {
                 const size_t il = (size_t)(rowtile * a.T + t) * NL + l;
@@ -1161,7 +1182,19 @@ __global__ void __launch_bounds__(256, 1) lstm_bwd_kernel(const LstmBwdArgs a) {
                 for (int r = 0; r < 4; ++r) {
                     const int reg = 4 * jq + r;
                     float di = 0.0f, df = 0.0f, dgg = 0.0f, dog = 0.0f;
-                    if (tg < NT) {
+                    if (tg < NT && a.gru) {
+                        // nn.GRU: saved slots (r, z, n, n_h); sv_c holds h.  dc carries dh' * z, the direct path
+                        const int gs = 16 * tg + 4 * r, cs = 4 * tg + r;
+                        const float rg = sg[(gs + 0) * 64], zg = sg[(gs + 1) * 64], ng = sg[(gs + 2) * 64], nh = sg[(gs + 3) * 64];
+                        const float hp = scp ? scp[cs * 64] : 0.0f;
+                        const float dh = acc[0][reg] + dc[l][reg];
+                        const float dnp = dh * (1.0f - zg) * (1.0f - ng * ng);
+                        di = dnp * nh * rg * (1.0f - rg);                       // d r_pre
+                        df = dh * (hp - ng) * zg * (1.0f - zg);                 // d z_pre
+                        dgg = dnp;                                              // d n_x
+                        dog = dnp * rg;                                         // d n_h
+                        dc[l][reg] = dh * zg;
+                    } else if (tg < NT) {
                         const int gs = 16 * tg + 4 * r, cs = 4 * tg + r;
                         const float ig = sg[(gs + 0) * 64], fg = sg[(gs + 1) * 64], gg = sg[(gs + 2) * 64], og = sg[(gs + 3) * 64];
                         const float cn = sc[cs * 64];
@@ -1582,6 +1615,7 @@ extern "C" int vsv_encode(const vsv_dims* dims, const float* packed, int which,
 
     // 2. LSTM over time, top-layer h of every step -> hbuf (tile-B)
     LstmSeqArgs l = {};
+    l.gru = lay.gru;
     for (int i = 0; i < lay.NL; ++i) { l.w[i] = packed + e.lstm[i].w_off; l.b[i] = packed + e.lstm[i].b_off; }
     l.kx = e.kx; l.n_rows = n_rows; l.n_rowtiles = rt; l.T = T;
     l.x_tileb = xe; l.L = lay.L;
@@ -1641,6 +1675,7 @@ extern "C" int vsv_decode(const vsv_dims* dims, const float* packed, const vsv_d
     const long rt = (n_rows + 31) / 32;
 
     LstmSeqArgs l = {};
+    l.gru = lay.gru;
     for (int i = 0; i < lay.NL; ++i) { l.w[i] = packed + dc.lstm[i].w_off; l.b[i] = packed + dc.lstm[i].b_off; }
     l.kx = dc.kx; l.n_rows = n_rows; l.n_rowtiles = rt; l.T = T;
     l.L = lay.L; l.din = *in; l.z_out = z_out;
@@ -1802,6 +1837,7 @@ extern "C" int vsv_train_encode(const vsv_dims* dims, const float* packed, int w
     if (rc) return rc;
 
     LstmSeqArgs l = {};
+    l.gru = lay.gru;
     for (int i = 0; i < lay.NL; ++i) { l.w[i] = packed + e.lstm[i].w_off; l.b[i] = packed + e.lstm[i].b_off; }
     l.kx = e.kx; l.n_rows = n_rows; l.n_rowtiles = rt; l.T = T;
     l.x_tileb = sv->xe; l.L = lay.L;
@@ -1838,6 +1874,7 @@ extern "C" int vsv_train_decode(const vsv_dims* dims, const float* packed, const
     const int touts = T - t_out0;
 
     LstmSeqArgs l = {};
+    l.gru = lay.gru;
     for (int i = 0; i < lay.NL; ++i) { l.w[i] = packed + dc.lstm[i].w_off; l.b[i] = packed + dc.lstm[i].b_off; }
     l.kx = dc.kx; l.n_rows = n_rows; l.n_rowtiles = rt; l.T = T;
     l.L = lay.L; l.din = *in; l.z_out = z_out;

@@ -54,6 +54,8 @@ int make_layout(const vsv_dims& d, Layout& lay, const char** msg) {
     if (lay.Q < 1 || lay.Q * 25 > kMaxFeat) return fail("n_quantiles*25 must be <= 128");
     if (d.interaction_layers < 0 || d.interaction_layers + 1 > VSV_MAX_INTERACT) return fail("interaction_layers must be in [0,2]");
     lay.NI = d.interaction_layers > 0 ? d.interaction_layers + 1 : 0;
+    if (d.mem_type < 0 || d.mem_type > 1) return fail("mem_type must be 0 (lstm) or 1 (gru)");
+    lay.gru = d.mem_type;
     if (d.n_conv < 1 || d.n_conv > VSV_MAX_CONV || d.n_ctx_conv < 1 || d.n_ctx_conv > VSV_MAX_CONV)
         return fail("1..4 conv layers supported");
     if (d.n_conv + lay.NI > kMaxDenseLayers || d.n_ctx_conv + lay.NI > kMaxDenseLayers || 2 + d.n_conv + lay.NI > kMaxDenseLayers)
@@ -200,6 +202,39 @@ static std::vector<float> conv_matrix(const float* w, int cin, int cout, bool tr
     return M;
 }
 
+// nn.GRU in the four gate slots of a hidden unit: (r, z, n_x, n_h).  r and z sum their input and
+// recurrent parts like an LSTM gate; the candidate's two halves stay apart -- n_x = W_in x + b_in has
+// zero recurrent columns, n_h = W_hn h + b_hn zero input columns -- because the cell needs
+// n = tanh(n_x + r * n_h).  Row code g*H + u as for the LSTM (g = slot).
+static void pack_gru(float* blob, const Sec* secs, const vsv_lstm_raw& raw, int NL, int H, int in0,
+                     int kx, const InMap& x_map) {
+    const int NT = (H + 7) / 8;
+    for (int l = 0; l < NL; ++l) {
+        const float *wih = raw.w_ih[l], *whh = raw.w_hh[l], *bih = raw.b_ih[l], *bhh = raw.b_hh[l];
+        const int n_in = (l == 0) ? in0 : H;
+        const int kin = (l == 0) ? kx : 4 * NT;
+        const InMap imap = (l == 0) ? x_map : in_nat(H);
+        const InMap hmap = in_nat(H);
+        InMap fi = [=](int s, int hh) {
+            if (s < kin) return imap(s, hh);
+            const int c = hmap(s - kin, hh);
+            return c < 0 ? -1 : n_in + c;
+        };
+        WFn W = [=](int r, int c) {
+            const int g = r / H, u = r % H;
+            const int src = (g < 2 ? g : 2) * H + u;                    // row of the 3H-row matrices
+            if (c < n_in) return g == 3 ? 0.0f : wih[(size_t)src * n_in + c];
+            return g == 2 ? 0.0f : whh[(size_t)src * H + (c - n_in)];
+        };
+        BFn B = [=](int r) {
+            const int g = r / H, u = r % H;
+            if (g < 2) return bih[g * H + u] + bhh[g * H + u];
+            return g == 2 ? bih[2 * H + u] : bhh[2 * H + u];
+        };
+        pack_sec(blob, secs[l], out_gate(H), fi, W, B);
+    }
+}
+
 static void pack_lstm(float* blob, const Sec* secs, const vsv_lstm_raw& raw, int NL, int H, int in0,
                       int kx, const InMap& x_map) {
     const int NT = (H + 7) / 8;
@@ -301,7 +336,7 @@ extern "C" int vsv_pack_weights(const vsv_dims* dims, const vsv_raw_weights* raw
             pack_sec(out, e.conv[e.n_conv + j], out_nat32(E), in_perm(E), W, B);
         }
         const vsv_lstm_raw& mem = which ? raw->ctx_mem : raw->enc_mem;
-        pack_lstm(out, e.lstm, mem, lay.NL, Hm, e.E, e.kx, in_perm(e.E));
+        (lay.gru ? pack_gru : pack_lstm)(out, e.lstm, mem, lay.NL, Hm, e.E, e.kx, in_perm(e.E));
         if (which == 0) {
             const float *wm = raw->z_mean_w, *bm = raw->z_mean_b, *wv = raw->z_log_var_w, *bv = raw->z_log_var_b;
             WFn W = [=](int r, int c) { return r < L ? wm[(size_t)r * Hm + c] : wv[(size_t)(r - L) * Hm + c]; };
@@ -317,7 +352,7 @@ extern "C" int vsv_pack_weights(const vsv_dims* dims, const vsv_raw_weights* raw
 
     const DecLayout& dc = lay.dec;
     const int Hd = lay.Hd;
-    pack_lstm(out, dc.lstm, raw->dec_mem, lay.NL, Hd, 2 * L, dc.kx, in_nat(2 * L));
+    (lay.gru ? pack_gru : pack_lstm)(out, dc.lstm, raw->dec_mem, lay.NL, Hd, 2 * L, dc.kx, in_nat(2 * L));
     int hi = 0;
     const int c_last = d.surface_hidden[d.n_conv - 1];
     for (int j = 0; j < lay.NI; ++j) {

@@ -17,8 +17,8 @@ from . import lib as _lib
 def dims_from_config(cfg: dict) -> _lib.VsvDims:
     """vsv_dims from a reference model config dict
     (keys as validated by cvae_with_mem_randomized.py:969-1020)."""
-    if cfg.get("mem_type", "lstm") != "lstm":
-        raise NotImplementedError("HIP path implements mem_type='lstm' only")
+    if cfg.get("mem_type", "lstm") not in ("lstm", "gru"):
+        raise NotImplementedError("HIP path implements mem_type 'lstm' and 'gru' (nn.RNN is not built)")
     if cfg.get("use_dense_surface", False):
         raise NotImplementedError("HIP path implements the conv surface embedding only")
     if not cfg.get("compress_context", False):
@@ -29,7 +29,8 @@ def dims_from_config(cfg: dict) -> _lib.VsvDims:
         raise NotImplementedError("HIP path implements the 5x5 grid only")
     return _lib.make_dims(cfg["latent_dim"], cfg["ex_feats_dim"], cfg["mem_hidden"], cfg["mem_layers"],
                           list(cfg["surface_hidden"]), list(cfg["ctx_surface_hidden"]),
-                          len(cfg.get("quantiles", [0.05, 0.5, 0.95])), cfg.get("interaction_layers") or 0)
+                          len(cfg.get("quantiles", [0.05, 0.5, 0.95])), cfg.get("interaction_layers") or 0,
+                          cfg.get("mem_type", "lstm"))
 
 
 def _fp(a: np.ndarray):

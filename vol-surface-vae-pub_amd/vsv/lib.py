@@ -22,7 +22,7 @@ class VsvDims(C.Structure):
         ("latent_dim", C.c_int), ("ex_feats_dim", C.c_int), ("mem_hidden", C.c_int),
         ("mem_layers", C.c_int), ("n_conv", C.c_int), ("surface_hidden", C.c_int * VSV_MAX_CONV),
         ("n_ctx_conv", C.c_int), ("ctx_surface_hidden", C.c_int * VSV_MAX_CONV),
-        ("n_quantiles", C.c_int), ("interaction_layers", C.c_int),
+        ("n_quantiles", C.c_int), ("interaction_layers", C.c_int), ("mem_type", C.c_int),
     ]
 
 
@@ -90,7 +90,7 @@ class VsvLstmBwd(C.Structure):
                 ("n_rows", C.c_long), ("n_rowtiles", C.c_long), ("T", C.c_int), ("t_out0", C.c_int),
                 ("sv_gates", C.c_void_p), ("sv_c", C.c_void_p), ("dh_top", C.c_void_p),
                 ("dgates", C.c_void_p), ("dx_tile", C.c_void_p), ("dx_rows", C.c_void_p), ("dx_f", C.c_int),
-                ("drop_p", C.c_float), ("drop_seed", C.c_uint64), ("drop_id", C.c_int)]
+                ("drop_p", C.c_float), ("drop_seed", C.c_uint64), ("drop_id", C.c_int), ("gru", C.c_int)]
 
 
 class VsvLoss(C.Structure):
@@ -162,7 +162,7 @@ def load() -> C.CDLL:
             fn = getattr(lib, name)
             fn.restype = res
             fn.argtypes = args
-        if lib.vsv_abi_version() != 5:
+        if lib.vsv_abi_version() != 6:
             raise RuntimeError("libvsv_hip.so ABI version mismatch")
         _lib = lib
     return _lib
@@ -181,8 +181,11 @@ def check(rc: int, what: str) -> None:
 
 
 def make_dims(latent_dim, ex_feats_dim, mem_hidden, mem_layers, surface_hidden, ctx_surface_hidden,
-              n_quantiles, interaction_layers=0) -> VsvDims:
+              n_quantiles, interaction_layers=0, mem_type="lstm") -> VsvDims:
     d = VsvDims()
+    if mem_type not in ("lstm", "gru"):
+        raise NotImplementedError("HIP path implements mem_type 'lstm' and 'gru' (nn.RNN is not built)")
+    d.mem_type = 1 if mem_type == "gru" else 0
     d.interaction_layers = int(interaction_layers or 0)
     if d.interaction_layers + 1 > VSV_MAX_INTERACT:
         raise NotImplementedError("at most 2 interaction layers are supported by the HIP path")

@@ -283,6 +283,7 @@ class TrainEngine:
         blobT = self._blobT(c)
         a = _lib.VsvLstmBwd()
         a.drop_p, a.drop_seed, a.drop_id = c.drop_p, c.drop_seed, drop_id
+        a.gru = self.dims.mem_type
         for l in range(NL):
             a.wT_hh[l] = self._wT(blobT, f"{prefix}.hh{l}")[0]
             a.wT_in[l] = self._wT(blobT, f"{prefix}.in{l}")[0]

@@ -353,8 +353,18 @@ class CVAEMemRand(BaseVAE):
             raise ValueError(f"Insufficient sequence length: T={T}, horizon={self.horizon}, "
                              f"resulting in C={C}. Need at least C >= 1.")
         eng = self._engine()
-        s, e, zm, zl, z = paths.forward(eng, surf, ex, self.horizon, seed=self._draw_seed())
         dt = self._param_dtype()
+        p = float(self.config.get("mem_dropout", 0) or 0) if self.training and self.config["mem_layers"] > 1 else 0.0
+        params = self._hip_named_params()
+        if (torch.is_grad_enabled() and any(q.requires_grad for _, q in params)) or p > 0:
+            # the outputs carry an autograd graph like the reference's: forward with saved activations,
+            # the backward kernels run when the caller's loss.backward() reaches them (vsv/autograd.py)
+            from vsv.autograd import CVAEForward
+            s, e, zm, zl, z = CVAEForward.apply(self._train_engine(), surf, ex, self.horizon, None,
+                                                self._draw_seed(), p, self._draw_seed() if p > 0 else 0,
+                                                *[q for _, q in params])
+        else:
+            s, e, zm, zl, z = paths.forward(eng, surf, ex, self.horizon, seed=self._draw_seed())
         if ex is not None:
             return s.to(dt), e.to(dt), zm.to(dt), zl.to(dt), z.to(dt)
         return s.to(dt), zm.to(dt), zl.to(dt), z.to(dt)

@@ -358,42 +358,31 @@ class TrainEngine:
         return out, gp
 
     # -- one forward/backward ----------------------------------------------------------
-    def loss_and_grads(self, surf: torch.Tensor, ex: Optional[torch.Tensor], horizon: int, loss_cfg: dict,
-                       eps: Optional[torch.Tensor] = None, seed: int = 0, want_grads: bool = True,
-                       dropout_p: float = 0.0, dropout_seed: int = 0, kl_fn=None,
-                       extra_d_pred: Optional[torch.Tensor] = None, want_input_grad: bool = False):
-        """surf (B,T,5,5) [, ex (B,T,X)] -> (losses dict of 0-d float64 tensors, gradient of
-        `loss` w.r.t. the PACKED blob or None).  loss_cfg: quantiles, quantile_weights, ex_n,
-        ex_l2, ex_weight, kl_weight.  dropout_p > 0: nn.LSTM's inter-layer dropout (train mode) in
-        all three memories, masks keyed by dropout_seed (vsv_hip.h, vsv_train_save).
-        kl_fn(z_mean, z_log_var) -> (kl, d_zm, d_zl) replaces the N(0,1) KL term: kl is a 0-d tensor,
-        d_* the gradient of kl_weight * kl w.r.t. the posterior parameters (B,T,L) -- the conditional
-        prior's Gaussian-Gaussian KL (cvae_conditional_prior.py:65-115).
-        extra_d_pred (B,H,Q,5,5): added to d(loss)/d(decoded surfaces) -- the gradient later steps of an
-        autoregressive rollout send back through their context (vae/utils.py:526-527, no detach).
-        want_input_grad: outputs["d_surface"] (B,T,5,5) = gradient w.r.t. the input surfaces (through both
-        encoders; the targets inside the loss are data, as in the reference)."""
+    def forward_saved(self, surf: torch.Tensor, ex: Optional[torch.Tensor], horizon: int,
+                      eps: Optional[torch.Tensor] = None, seed: int = 0,
+                      dropout_p: float = 0.0, dropout_seed: int = 0):
+        """CVAEMemRand.forward (:1022-1074) keeping what the backward kernels need.  -> call state `c`
+        with c.outputs = {"surf" (B,H,Q,5,5), "ex" (B,H,X) | None, "z_mean", "z_log_var", "z" (B,T,L)}.
+        dropout_p > 0: nn.LSTM's inter-layer dropout (train mode) in all three memories, masks keyed
+        by dropout_seed (vsv_hip.h, vsv_train_save)."""
         eng, lib, lay = self.eng, self.lib, self.lay
         dev = self.dev
         L, X, Q, NL = self.L, self.X, self.Q, self.NL
-        NTm, NTd = lay["NTm"], lay["NTd"]
+        NTd = lay["NTd"]
         c = self._begin(surf, ex, dropout_p, dropout_seed)
-        surf, ex = c.surf, c.ex
         B, T, rt = c.B, c.T, c.rt
-        Cn = T - horizon
+        c.horizon = horizon
+        Cn = c.Cn = T - horizon
         st = self._stream()
-        packed = c.packed
-
         main = torch.cuda.current_stream(dev)
         if eng._side is None:
             eng._side = torch.cuda.Stream(dev)
         side = eng._side
-
         with torch.cuda.device(dev):
             # the two encoders are independent: context encoder on the side stream
             side.wait_stream(main)
-            ctx_out, sv_c = self._enc_fwd(c, 1, Cn, side)
-            enc_out, sv_e = self._enc_fwd(c, 0, T, main)
+            ctx_out, c.sv_c = self._enc_fwd(c, 1, Cn, side)
+            enc_out, c.sv_e = self._enc_fwd(c, 0, T, main)
             main.wait_stream(side)
             zm, zl = enc_out[..., :L].contiguous(), enc_out[..., L:].contiguous()
             # ---- decoder
@@ -418,9 +407,99 @@ class TrainEngine:
             z = self._e(B, T, L)
             s_out = self._e(B, horizon, Q, 5, 5)
             e_out = self._e(B, horizon, X) if X > 0 else None
-            rc = lib.vsv_train_decode(C.byref(self.dims), packed.data_ptr(), C.byref(din), B, T, Cn,
+            rc = lib.vsv_train_decode(C.byref(self.dims), c.packed.data_ptr(), C.byref(din), B, T, Cn,
                                       z.data_ptr(), s_out.data_ptr(), _ptr(e_out), C.byref(s), st)
             _lib.check(rc, "vsv_train_decode")
+        c.sv_d = sv_d
+        c.outputs = {"surf": s_out, "ex": e_out, "z_mean": zm, "z_log_var": zl, "z": z}
+        return c
+
+    def backward_saved(self, c, d_pred: torch.Tensor, d_ex: Optional[torch.Tensor], d_zm: Optional[torch.Tensor],
+                       d_zl: Optional[torch.Tensor], d_z: Optional[torch.Tensor] = None,
+                       want_input_grad: bool = False):
+        """Backward of forward_saved from the gradients w.r.t. its five outputs (None = zero): decoder
+        head, decoder BPTT, reparameterisation (:199), both encoder stacks.  -> gradient w.r.t. the
+        PACKED blob; want_input_grad: c.outputs["d_surface"] (B,T,5,5) as well."""
+        lay, dev = self.lay, self.dev
+        L, X, Q = self.L, self.X, self.Q
+        NTd = lay["NTd"]
+        B, T, rt, Cn, horizon = c.B, c.T, c.rt, c.Cn, c.horizon
+        sv_d, d = c.sv_d, lay["dec"]
+        NIo = rt * horizon
+        zm, z = c.outputs["z_mean"], c.outputs["z"]
+        main = torch.cuda.current_stream(dev)
+        side = self.eng._side
+        with torch.cuda.device(dev):
+            d_pred = d_pred.to(dev, torch.float32).reshape(B, horizon, Q * 25).contiguous()
+            if X > 0:
+                d_ex = self._z(B, horizon, X) if d_ex is None else d_ex.to(dev, torch.float32).contiguous()
+            blobT = self._blobT(c)
+            gp = torch.zeros(c.packed.numel(), dtype=torch.float32, device=dev)
+
+            # decoder head
+            hd = d["head"][: d["n_head"]]
+            layers, gs = [], []
+            for li in range(d["n_head"] - 1, -1, -1):
+                g = self._e(NIo, 64, 64)
+                gs.append((li, g))
+                w, nq, nt = self._wT(blobT, f"d.head{li}")
+                ly = dict(wT=w, nqT=nq, ntT=nt, n_relu=hd[li].n_relu, g_out=g.data_ptr())
+                if li < d["n_head"] - 1 and hd[li].n_relu > 0:
+                    ly["act_out"] = sv_d["head_acts"][li + 1].data_ptr()
+                if X > 0 and li == d["ex_layer"]:
+                    ly["add"], ly["add_f0"], ly["add_n"] = d_ex.data_ptr(), d["ex_f0"], X
+                layers.append(ly)
+            dh_top = self._dense_bwd(c, layers, horizon, 0, d_pred, Q * 25, True)
+            for li, g in gs:
+                self._acc_layer(gp, hd[li], g[:, : 16 * hd[li].nt], sv_d["head_acts"][li][:, : 4 * hd[li].nq])
+            # decoder LSTM
+            dx = self._e(B, T, 2 * L)
+            dg = self._lstm_bwd(c, "d", lay["Hd"], NTd, sv_d, T, Cn, dh_top, 1, 2, dx_rows=dx, dx_f=2 * L)
+            self._lstm_wgrads(c, gp, d["lstm"], sv_d, dg, T, NTd, sv_d["xe"])
+            # reparameterisation (:199) and the context embedding
+            dz = dx[..., L:]
+            if d_z is not None:
+                dz = dz + d_z.to(dev, torch.float32)
+            dzm_t = dz if d_zm is None else dz + d_zm
+            dzl_t = dz * 0.5 * (z - zm)
+            if d_zl is not None:
+                dzl_t = dzl_t + d_zl
+            d_ctx = dx[:, :Cn, :L].contiguous()
+
+            d_enc = torch.cat([dzm_t, dzl_t], dim=-1).contiguous()
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                ds_c = self._enc_bwd(c, gp, 1, c.sv_c, Cn, d_ctx, want_input_grad)
+            ds_e = self._enc_bwd(c, gp, 0, c.sv_e, T, d_enc, want_input_grad)
+            main.wait_stream(side)
+            if want_input_grad:
+                ds_e[:, :Cn] += ds_c
+                c.outputs["d_surface"] = ds_e.view(B, T, 5, 5)
+        return gp
+
+    def loss_and_grads(self, surf: torch.Tensor, ex: Optional[torch.Tensor], horizon: int, loss_cfg: dict,
+                       eps: Optional[torch.Tensor] = None, seed: int = 0, want_grads: bool = True,
+                       dropout_p: float = 0.0, dropout_seed: int = 0, kl_fn=None,
+                       extra_d_pred: Optional[torch.Tensor] = None, want_input_grad: bool = False):
+        """surf (B,T,5,5) [, ex (B,T,X)] -> (losses dict of 0-d float64 tensors, gradient of
+        `loss` w.r.t. the PACKED blob or None, outputs).  loss_cfg: quantiles, quantile_weights, ex_n,
+        ex_l2, ex_weight, kl_weight.  dropout_*: see forward_saved.
+        kl_fn(z_mean, z_log_var) -> (kl, d_zm, d_zl) replaces the N(0,1) KL term: kl is a 0-d tensor,
+        d_* the gradient of kl_weight * kl w.r.t. the posterior parameters (B,T,L) -- the conditional
+        prior's Gaussian-Gaussian KL (cvae_conditional_prior.py:65-115).
+        extra_d_pred (B,H,Q,5,5): added to d(loss)/d(decoded surfaces) -- the gradient later steps of an
+        autoregressive rollout send back through their context (vae/utils.py:526-527, no detach).
+        want_input_grad: outputs["d_surface"] (B,T,5,5) = gradient w.r.t. the input surfaces (through both
+        encoders; the targets inside the loss are data, as in the reference)."""
+        lib, dev = self.lib, self.dev
+        L, X, Q = self.L, self.X, self.Q
+        c = self.forward_saved(surf, ex, horizon, eps, seed, dropout_p, dropout_seed)
+        surf, ex = c.surf, c.ex
+        B, T = c.B, c.T
+        outputs = c.outputs
+        s_out, e_out, zm, zl = outputs["surf"], outputs["ex"], outputs["z_mean"], outputs["z_log_var"]
+        st = self._stream()
+        with torch.cuda.device(dev):
             # ---- losses + output gradients
             klw = float(loss_cfg["kl_weight"])
             la = _lib.VsvLoss()
@@ -453,49 +532,9 @@ class TrainEngine:
             recon = re_s + loss_cfg["ex_weight"] * re_e if X > 0 else re_s
             losses = {"loss": recon + klw * kl, "re_surface": re_s, "re_ex_feats": re_e,
                       "reconstruction_loss": recon, "kl_loss": kl}
-            outputs = {"surf": s_out, "ex": e_out, "z_mean": zm, "z_log_var": zl, "z": z}
             if not want_grads:
                 return losses, None, outputs
-
-            # ---- backward
-            blobT = self._blobT(c)
-            gp = torch.zeros(packed.numel(), dtype=torch.float32, device=dev)
-
-            # decoder head
-            hd = d["head"][: d["n_head"]]
-            layers, gs = [], []
-            for li in range(d["n_head"] - 1, -1, -1):
-                g = self._e(NIo, 64, 64)
-                gs.append((li, g))
-                w, nq, nt = self._wT(blobT, f"d.head{li}")
-                ly = dict(wT=w, nqT=nq, ntT=nt, n_relu=hd[li].n_relu, g_out=g.data_ptr())
-                if li < d["n_head"] - 1 and hd[li].n_relu > 0:
-                    ly["act_out"] = sv_d["head_acts"][li + 1].data_ptr()
-                if X > 0 and li == d["ex_layer"]:
-                    ly["add"], ly["add_f0"], ly["add_n"] = d_ex.data_ptr(), d["ex_f0"], X
-                layers.append(ly)
-            dh_top = self._dense_bwd(c, layers, horizon, 0, d_pred, Q * 25, True)
-            for li, g in gs:
-                self._acc_layer(gp, hd[li], g[:, : 16 * hd[li].nt], sv_d["head_acts"][li][:, : 4 * hd[li].nq])
-            # decoder LSTM
-            dx = self._e(B, T, 2 * L)
-            dg = self._lstm_bwd(c, "d", lay["Hd"], NTd, sv_d, T, Cn, dh_top, 1, 2, dx_rows=dx, dx_f=2 * L)
-            self._lstm_wgrads(c, gp, d["lstm"], sv_d, dg, T, NTd, sv_d["xe"])
-            # reparameterisation (:199) and the context embedding
-            dz = dx[..., L:]
-            dzm_t = dz + d_zm
-            dzl_t = dz * 0.5 * (z - zm) + d_zl
-            d_ctx = dx[:, :Cn, :L].contiguous()
-
-            d_enc = torch.cat([dzm_t, dzl_t], dim=-1).contiguous()
-            side.wait_stream(main)
-            with torch.cuda.stream(side):
-                ds_c = self._enc_bwd(c, gp, 1, sv_c, Cn, d_ctx, want_input_grad)
-            ds_e = self._enc_bwd(c, gp, 0, sv_e, T, d_enc, want_input_grad)
-            main.wait_stream(side)
-            if want_input_grad:
-                ds_e[:, :Cn] += ds_c
-                outputs["d_surface"] = ds_e.view(B, T, 5, 5)
+            gp = self.backward_saved(c, d_pred, d_ex, d_zm, d_zl, None, want_input_grad)
         return losses, gp, outputs
 
     def param_grads(self, gp: torch.Tensor) -> List[torch.Tensor]:

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define VSV_ABI_VERSION 6
+#define VSV_ABI_VERSION 7
 #define VSV_MAX_CONV 4
 #define VSV_MAX_CHAIN 8
 #define VSV_MAX_INTERACT 3
@@ -217,6 +217,8 @@ typedef struct vsv_train_save {
     float drop_p;
     uint64_t drop_seed;
     int drop_id;
+    const uint64_t* drop_seed_dev;  /* non-null: the kernels read the seed from this device word at start instead
+                                     * of drop_seed, so a captured HIP graph draws fresh masks on every replay */
 } vsv_train_save;
 
 /* vsv_encode / vsv_decode (out_mode 0, zero initial state, head not fused) that also fill `sv`. */
@@ -269,6 +271,7 @@ typedef struct vsv_lstm_bwd {
     uint64_t drop_seed;
     int drop_id;
     int gru;                                /* 1: the saved gates are nn.GRU's (r, z, n, W_hn h + b_hn) */
+    const uint64_t* drop_seed_dev;          /* as in vsv_train_save */
 } vsv_lstm_bwd;
 int vsv_lstm_backward(const vsv_lstm_bwd *d, int hidden, int layers, void *stream);
 

@@ -239,7 +239,12 @@ struct DropArgs {
     float p, scale;             // p = 0: no dropout
     uint32_t k0, k1;            // seed
     uint32_t id;
+    const uint32_t* key_dev;    // non-null: the seed's two words are read from device memory at kernel start
 };
+__device__ __forceinline__ DropArgs resolve_drop(DropArgs d) {
+    if (d.key_dev) { d.k0 = d.key_dev[0]; d.k1 = d.key_dev[1]; }       // uniform address: scalar loads
+    return d;
+}
 __device__ __forceinline__ void dropout_factors(const DropArgs& d, uint32_t row, uint32_t t, int tile, int hh, int layer,
                                                 float (&f)[4]) {
     uint32_t c0 = row, c1 = t, c2 = (uint32_t)(2 * tile + hh), c3 = 0x44520000u | (d.id << 8) | (uint32_t)layer;
@@ -708,6 +713,7 @@ lstm_kernel(const LstmSeqArgs a) {
     float* const xs = xs0 + lane;                                 // prologue / epilogue views
     float* const hb = hb0 + lane;
     const bool dropping = SAVE && NL > 1 && a.drop.p > 0.0f;      // wave-uniform; the dropped h lives at ha0
+    const DropArgs drop = (SAVE && dropping) ? resolve_drop(a.drop) : a.drop;
 
     // gate tiles of this wave; out-of-range ones are computed on a clamped tile and never stored
     // (opaque<OWN == 4>: the one-wave-per-gate-tile schedule has registers to spare, and pinning its
@@ -915,7 +921,7 @@ lstm_kernel(const LstmSeqArgs a) {
 #pragma unroll
                 for (int i = 0; i < OWN; ++i) {
                     float fct[4];
-                    dropout_factors(a.drop, row32, (uint32_t)t, toff[i] >> 6, hh, l, fct);
+                    dropout_factors(drop, row32, (uint32_t)t, toff[i] >> 6, hh, l, fct);
 #pragma unroll
                     for (int jj = 0; jj < 4; ++jj) hd[i][jj] = hn[i][jj] * fct[jj];
                     if (tval[i]) {
@@ -1156,8 +1162,9 @@ __global__ void __launch_bounds__(256, 1) lstm_bwd_kernel(const LstmBwdArgs a) {
                 gemm_seg<1>(acc, (const float4*)a.wT_in[l + 1], lane, toff1, 4 * 64, dg + (size_t)(l + 1) * GK * 64, 4 * NT);
                 if (a.drop_p > 0.0f) {
                     // layer l+1 read the dropped copy of this layer's h: same Philox factors as the forward
-                    const DropArgs da = {a.drop_p, 1.0f / (1.0f - a.drop_p), (uint32_t)a.drop_seed,
-                                         (uint32_t)(a.drop_seed >> 32), (uint32_t)a.drop_id};
+                    const DropArgs da = resolve_drop(DropArgs{a.drop_p, 1.0f / (1.0f - a.drop_p), (uint32_t)a.drop_seed,
+                                                              (uint32_t)(a.drop_seed >> 32), (uint32_t)a.drop_id,
+                                                              (const uint32_t*)a.drop_seed_dev});
                     const uint32_t rowc = (uint32_t)(row_ok ? row_raw : a.n_rows - 1);
 #pragma unroll
                     for (int jq = 0; jq < 4; ++jq) {
@@ -1540,13 +1547,13 @@ static int launch_lstm(const LstmSeqArgs& a, int NT, int NL, bool head, hipStrea
 static thread_local hipEvent_t g_prof_ev[2] = {nullptr, nullptr};
 
 static int fill_dropout(LstmSeqArgs& l, const vsv_train_save* sv, int NL, const char* who) {
-    l.drop = DropArgs{0.0f, 1.0f, 0u, 0u, 0u};
+    l.drop = DropArgs{0.0f, 1.0f, 0u, 0u, 0u, nullptr};
     l.sv_hd = nullptr;
     if (!(sv->drop_p > 0.0f) || NL < 2) return 0;              // nn.LSTM applies dropout between layers only
     if (sv->drop_p >= 1.0f) { set_error("%s: dropout probability must be < 1", who); return -1; }
     if (!sv->hd) { set_error("%s: dropout needs the hd save buffer", who); return -1; }
     l.drop = DropArgs{sv->drop_p, 1.0f / (1.0f - sv->drop_p), (uint32_t)sv->drop_seed, (uint32_t)(sv->drop_seed >> 32),
-                      (uint32_t)sv->drop_id};
+                      (uint32_t)sv->drop_id, (const uint32_t*)sv->drop_seed_dev};
     l.sv_hd = sv->hd;
     return 0;
 }
@@ -1786,7 +1793,7 @@ extern "C" int vsv_dropout_mask(float p, uint64_t seed, int id, int layer, long 
     if (!(p >= 0.0f && p < 1.0f) || n_rows < 0 || T < 0 || hidden < 1) { set_error("vsv_dropout_mask: bad arguments"); return -1; }
     const long total = n_rows * T * (2 * ((hidden + 7) / 8));
     if (total == 0) return 0;
-    const DropArgs d = {p, 1.0f / (1.0f - p), (uint32_t)seed, (uint32_t)(seed >> 32), (uint32_t)id};
+    const DropArgs d = {p, 1.0f / (1.0f - p), (uint32_t)seed, (uint32_t)(seed >> 32), (uint32_t)id, nullptr};
     hipLaunchKernelGGL(dropout_mask_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
                        d, layer, n_rows, T, hidden, out);
     return launch_check("dropout_mask_kernel");

@@ -276,9 +276,10 @@ class CVAEMemRand(BaseVAE):
     def _hip_named_params(self):
         return [(n, p) for n, p in self.named_parameters()]
 
-    def _engine(self):
+    def _engine(self, pack: bool = True):
         """The kernel engine with weights packed from the CURRENT parameters
-        (re-packed on device whenever a parameter changed)."""
+        (re-packed on device whenever a parameter changed; pack=False leaves the blob alone --
+        the graphed training step packs inside its HIP graph)."""
         from vsv.engine import Engine
         dev = torch.device(self.device)
         if dev.type != "cuda" or not torch.cuda.is_available():
@@ -290,6 +291,8 @@ class CVAEMemRand(BaseVAE):
         if eng is None:
             eng = Engine(self.config, None, dev)
             self.__dict__["_vsv_engine"] = eng
+        if not pack:
+            return eng
         params = self._hip_named_params()
         key = tuple((p.data_ptr(), p._version) for _, p in params)
         if key != self.__dict__["_vsv_key"]:
@@ -508,11 +511,11 @@ class CVAEMemRand(BaseVAE):
                 "reconstruction_loss": recon_err, "kl_loss": kl}
 
     # -- training ------------------------------------------------------------------------
-    def _train_engine(self):
+    def _train_engine(self, pack: bool = True):
         """The training engine (forward with saved activations, loss + BPTT kernels,
         parameter-gradient assembly), built once per model."""
         from vsv.train import TrainEngine
-        eng = self._engine()
+        eng = self._engine(pack)
         te = self.__dict__.get("_vsv_train_engine")
         if te is None or te.eng is not eng:
             te = TrainEngine(eng, [(n, tuple(p.shape)) for n, p in self._hip_named_params()])
@@ -533,9 +536,21 @@ class CVAEMemRand(BaseVAE):
         if T - horizon < 1:
             raise ValueError(f"Insufficient sequence length: T={T}, horizon={horizon}, "
                              f"resulting in C={T - horizon}. Need at least C >= 1.")
-        te = self._train_engine()
         # nn.LSTM applies its inter-layer dropout in train mode only (and only with > 1 layer)
         p = float(self.config.get("mem_dropout", 0) or 0) if self.training else 0.0
+        if want_grads and self._use_graphs():
+            # one HIP-graph replay per step (vsv/graphed.py): weight packing, noise, forward, loss, backward
+            from vsv.graphed import GraphCache
+            te = self._train_engine(pack=False)
+            cache = self.__dict__.setdefault("_vsv_graphs", GraphCache())
+            params = self._hip_named_params()
+            g = cache.get(te, params, surf, ex, horizon, self._loss_cfg(), p if self.config["mem_layers"] > 1 else 0.0)
+            losses, grads = g.run(surf, ex)
+            self.__dict__["_vsv_key"] = tuple((q.data_ptr(), q._version) for _, q in params)
+            if ex is None:
+                losses["re_ex_feats"] = torch.zeros(1)
+            return losses, grads
+        te = self._train_engine()
         losses, gp, _ = te.loss_and_grads(surf, ex, horizon, self._loss_cfg(), seed=self._draw_seed(),
                                           want_grads=want_grads, dropout_p=p,
                                           dropout_seed=self._draw_seed() if p > 0 else 0)
@@ -543,11 +558,30 @@ class CVAEMemRand(BaseVAE):
             losses["re_ex_feats"] = torch.zeros(1)
         return losses, gp
 
-    def _accumulate_grads(self, gp, weight=1.0):
+    def _use_graphs(self) -> bool:
+        """HIP-graph replay of the training step unless config["hip_graphs"] is False or VSV_NO_GRAPHS=1."""
+        import os
+        return bool(self.config.get("hip_graphs", True)) and os.environ.get("VSV_NO_GRAPHS", "0") != "1"
+
+    def _accumulate_grads(self, gp, weight=1.0, alias=False):
+        """Add weight * gradient to .grad of the parameters.  gp: gradient w.r.t. the packed blob (eager path)
+        or the list of parameter gradients the graphed step returned (static graph memory: alias=True lets
+        .grad point at it directly -- train_step, one replay per step --, otherwise it is copied out)."""
         te = self.__dict__["_vsv_train_engine"]
-        for (_, p), g in zip(self._hip_named_params(), te.param_grads(gp)):
-            g = (g * weight if weight != 1.0 else g).to(p.dtype)
-            p.grad = g.clone() if p.grad is None else p.grad + g
+        params = [p for _, p in self._hip_named_params()]
+        graphed = isinstance(gp, (list, tuple))
+        grads = gp if graphed else te.param_grads(gp)
+        if weight != 1.0:
+            grads = torch._foreach_mul(list(grads), weight)
+            graphed = False                                  # fresh tensors
+        for p, g in zip(params, grads):
+            g = g.to(p.dtype)
+            if p.grad is None:
+                # eager-path gradients and scaled copies are fresh tensors; graph outputs are copied out
+                # unless aliasing was allowed
+                p.grad = g.clone() if (graphed and not alias and g.dtype == torch.float32) else g
+            else:
+                p.grad = p.grad + g
 
     def test_step(self, x):
         """Reference :1265-1308: forward + losses, returns a dict of tensors."""
@@ -560,7 +594,7 @@ class CVAEMemRand(BaseVAE):
         Returns a dict of tensors."""
         optimizer.zero_grad()
         losses, gp = self._loss_terms(x, self.horizon, True)
-        self._accumulate_grads(gp)
+        self._accumulate_grads(gp, alias=True)
         torch.nn.utils.clip_grad_norm_(self.parameters(), max_norm=1.0)
         optimizer.step()
         return losses

@@ -1,0 +1,99 @@
+"""HIP-graph replay of the training step's device work.
+
+One train_step issues ~250 launches (the vsv_* kernels plus the small torch ops that assemble the
+weight gradients); at batch 64 they are short, so issued one by one the step is bound by the host.
+GraphedLossGrads captures, once per input shape, everything between "parameters + batch" and
+"loss terms + parameter gradients" into one HIP graph (torch.cuda.CUDAGraph: the vsv_* launches go to
+torch's capturing stream like any other kernel, the side stream forks and joins inside the capture)
+and replays it per step.  What varies between replays lives in device memory:
+  * the batch                      -> copied into static input buffers before the replay,
+  * the parameters                 -> packed into the kernels' blob INSIDE the graph,
+  * the latent noise               -> torch.randn inside the graph (torch advances its Philox offset
+                                      per replay; the reference draws torch.randn_like here, :199),
+  * the nn.LSTM dropout mask seed  -> a device word filled by Tensor.random_() inside the graph and read
+                                      by the kernels through vsv_train_save.drop_seed_dev.
+Clipping and the optimizer stay outside (they belong to the caller's optimizer object).
+"""
+from __future__ import annotations
+
+from collections import OrderedDict
+from typing import Dict, List, Optional
+
+import torch
+
+
+class GraphedLossGrads:
+    """Captured (pack weights -> forward -> loss -> backward -> parameter gradients) for one shape."""
+
+    def __init__(self, te, named_params, B: int, T: int, has_ex: bool, horizon: int, loss_cfg: dict,
+                 dropout_p: float):
+        self.te, self.eng = te, te.eng
+        self.params = [p for _, p in named_params]
+        self.named = list(named_params)
+        self.horizon, self.loss_cfg, self.p = int(horizon), dict(loss_cfg), float(dropout_p)
+        dev = te.dev
+        self.surf = torch.zeros(B, T, 5, 5, dtype=torch.float32, device=dev)
+        self.ex = torch.zeros(B, T, te.X, dtype=torch.float32, device=dev) if has_ex else None
+        self.shape = (B, T)
+        cur = torch.cuda.current_stream(dev)
+        warm = torch.cuda.Stream(dev)
+        warm.wait_stream(cur)
+        with torch.cuda.stream(warm):           # eager passes: index maps, hipBLASLt workspaces, allocator pools
+            for _ in range(2):
+                self._body()
+        cur.wait_stream(warm)
+        torch.cuda.synchronize(dev)
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph, capture_error_mode="thread_local"):
+            self.loss_vec, self.grads, self.packed = self._body()
+
+    def _body(self):
+        te, eng = self.te, self.eng
+        B, T = self.shape
+        with torch.no_grad():
+            eng.set_weights_from_params(self.named)
+            eps = torch.randn(B, T, te.L, dtype=torch.float32, device=te.dev)
+            seed = 0
+            if self.p > 0:
+                seed = torch.empty(1, dtype=torch.int64, device=te.dev).random_()
+            losses, gp, _ = te.loss_and_grads(self.surf, self.ex, self.horizon, self.loss_cfg, eps=eps,
+                                              dropout_p=self.p, dropout_seed=seed)
+            grads = te.param_grads(gp)
+            vec = torch.stack([losses[k].to(torch.float64) for k in
+                               ("loss", "re_surface", "re_ex_feats", "reconstruction_loss", "kl_loss")])
+        return vec, grads, eng.packed
+
+    def run(self, surf: torch.Tensor, ex: Optional[torch.Tensor]):
+        """-> (losses dict of 0-d float64 tensors (own memory), parameter gradients in parameter order:
+        views of the graph's static output, valid until this object's next run)."""
+        self.surf.copy_(surf, non_blocking=True)
+        if self.ex is not None:
+            self.ex.copy_(ex, non_blocking=True)
+        self.graph.replay()
+        self.eng.packed = self.packed            # what the blob now holds: the parameters as of this replay
+        v = self.loss_vec.clone()
+        losses = {"loss": v[0], "re_surface": v[1], "re_ex_feats": v[2], "reconstruction_loss": v[3], "kl_loss": v[4]}
+        return losses, self.grads
+
+
+class GraphCache:
+    """Shape-keyed cache of GraphedLossGrads (least recently used out beyond `capacity`)."""
+
+    def __init__(self, capacity: int = 64):
+        self.capacity = capacity
+        self._d: "OrderedDict[tuple, GraphedLossGrads]" = OrderedDict()
+
+    def get(self, te, named_params, surf, ex, horizon, loss_cfg: Dict, dropout_p: float) -> GraphedLossGrads:
+        B, T = surf.shape[:2]
+        key = (B, T, ex is not None, int(horizon), float(dropout_p),
+               tuple(sorted((k, tuple(v) if isinstance(v, (list, tuple)) else v) for k, v in loss_cfg.items())),
+               tuple(p.data_ptr() for _, p in named_params), id(te))
+        g = self._d.get(key)
+        if g is None:
+            g = GraphedLossGrads(te, named_params, B, T, ex is not None, horizon, loss_cfg, dropout_p)
+            self._d[key] = g
+            while len(self._d) > self.capacity:
+                self._d.popitem(last=False)
+        else:
+            self._d.move_to_end(key)
+        return g

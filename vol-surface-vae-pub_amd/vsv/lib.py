@@ -69,7 +69,7 @@ VSV_MAX_CHAIN = 8
 
 class VsvTrainSave(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in ("emb_acts", "xe", "gates", "c", "h", "hout", "head_acts", "hd")] + \
-               [("drop_p", C.c_float), ("drop_seed", C.c_uint64), ("drop_id", C.c_int)]
+               [("drop_p", C.c_float), ("drop_seed", C.c_uint64), ("drop_id", C.c_int), ("drop_seed_dev", C.c_void_p)]
 
 
 class VsvDenseBwdLayer(C.Structure):
@@ -90,7 +90,8 @@ class VsvLstmBwd(C.Structure):
                 ("n_rows", C.c_long), ("n_rowtiles", C.c_long), ("T", C.c_int), ("t_out0", C.c_int),
                 ("sv_gates", C.c_void_p), ("sv_c", C.c_void_p), ("dh_top", C.c_void_p),
                 ("dgates", C.c_void_p), ("dx_tile", C.c_void_p), ("dx_rows", C.c_void_p), ("dx_f", C.c_int),
-                ("drop_p", C.c_float), ("drop_seed", C.c_uint64), ("drop_id", C.c_int), ("gru", C.c_int)]
+                ("drop_p", C.c_float), ("drop_seed", C.c_uint64), ("drop_id", C.c_int), ("gru", C.c_int),
+                ("drop_seed_dev", C.c_void_p)]
 
 
 class VsvLoss(C.Structure):
@@ -162,7 +163,7 @@ def load() -> C.CDLL:
             fn = getattr(lib, name)
             fn.restype = res
             fn.argtypes = args
-        if lib.vsv_abi_version() != 6:
+        if lib.vsv_abi_version() != 7:
             raise RuntimeError("libvsv_hip.so ABI version mismatch")
         _lib = lib
     return _lib

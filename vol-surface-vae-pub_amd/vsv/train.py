@@ -227,7 +227,9 @@ class TrainEngine:
         c.rt = (c.B + 31) // 32
         c.packed = self.eng.packed
         c.drop_p = float(dropout_p) if self.NL > 1 else 0.0
-        c.drop_seed = int(dropout_seed) & (2 ** 64 - 1)
+        # an int, or a 1-element int64 tensor on the device the kernels read at launch (HIP-graph replays)
+        c.drop_seed_dev = dropout_seed if torch.is_tensor(dropout_seed) else None
+        c.drop_seed = 0 if c.drop_seed_dev is not None else int(dropout_seed) & (2 ** 64 - 1)
         c.blobT = None
         return c
 
@@ -235,6 +237,7 @@ class TrainEngine:
         if c.drop_p > 0:
             sv["hd"] = self._e(NI, 4 * NT, 64)
             s.hd, s.drop_p, s.drop_seed, s.drop_id = sv["hd"].data_ptr(), c.drop_p, c.drop_seed, drop_id
+            s.drop_seed_dev = _ptr(c.drop_seed_dev)
 
     def _enc_fwd(self, c, which, Tw, stream, drop_id=None):
         """vsv_train_encode of the first Tw days: buffers come from the current stream's pool, the three
@@ -283,6 +286,7 @@ class TrainEngine:
         blobT = self._blobT(c)
         a = _lib.VsvLstmBwd()
         a.drop_p, a.drop_seed, a.drop_id = c.drop_p, c.drop_seed, drop_id
+        a.drop_seed_dev = _ptr(c.drop_seed_dev)
         a.gru = self.dims.mem_type
         for l in range(NL):
             a.wT_hh[l] = self._wT(blobT, f"{prefix}.hh{l}")[0]

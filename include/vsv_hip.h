@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define VSV_ABI_VERSION 7
+#define VSV_ABI_VERSION 8
 #define VSV_MAX_CONV 4
 #define VSV_MAX_CHAIN 8
 #define VSV_MAX_INTERACT 3
@@ -274,6 +274,29 @@ typedef struct vsv_lstm_bwd {
     const uint64_t* drop_seed_dev;          /* as in vsv_train_save */
 } vsv_lstm_bwd;
 int vsv_lstm_backward(const vsv_lstm_bwd *d, int hidden, int layers, void *stream);
+
+/* Weight gradients of dense / LSTM layers (autograd's dW = dY^T . X for nn.Linear, the conv layers'
+ * expanded matrices and nn.LSTM / nn.GRU, reached from loss.backward() at :1127): for each problem,
+ *   gp[position of W[n][k]] = sum over instances and rows of G[inst][a][row] * X[inst][k][row]
+ *   gp[position of b[n]]    = sum of G[inst][a][row]                          (bias != 0)
+ * with G the gradients the backward kernels wrote in tile-B layout read as [inst][a = 2*slot+half][32 rows]
+ * (n = the feature slot order puts at a), X the layer's saved input in its k order: x[0] (n_b[0] columns)
+ * followed by x[1] (n_b[1] columns, may be 0); shift[j] = 1 reads x[j] of the previous time step of the
+ * same row tile (instances are [tile][t], t < T; zeros at t = 0) -- the recurrent input h_{t-1}.
+ * Positions follow the packed layout of a section at (w_off, b_off) with nt output tiles. */
+#define VSV_MAX_WGRAD 16
+typedef struct vsv_wgrad_prob {
+    const float *g;  long g_stride;  int n_a;     /* n_a = 32 * (output tiles used), stride in floats per instance */
+    const float *x[2];  long x_stride[2];  int n_b[2];  int shift[2];
+    int n_inst, T;
+    long w_off, b_off;  int nt;  int bias;
+} vsv_wgrad_prob;
+typedef struct vsv_wgrad {
+    int n;
+    float *gp;                                    /* gradient w.r.t. the packed blob (vsv_packed_floats) */
+    vsv_wgrad_prob p[VSV_MAX_WGRAD];
+} vsv_wgrad;
+int vsv_weight_grads(const vsv_wgrad *d, void *stream);
 
 /* Loss terms of train_step (:1113-1125) and their gradients: pinball over the quantile
  * channels (QuantileLoss, :28-45; qw = weights / sum(weights)), ex-feature MSE ("l2") or L1

@@ -1925,6 +1925,139 @@ extern "C" int vsv_dense_backward(const vsv_dense_bwd* d, void* stream) {
     return launch_check("dense_bwd_kernel");
 }
 
+// ---------------------------------------------------------------------------
+// weight gradients: dW = G^T . X over the (row, t) instances the backward kernels left in HBM,
+// written straight to the packed-blob gradient.  G [inst][a][32 rows] (a = 2*slot + half, the tile-B
+// layout read as a plain array) and X [inst][b][32 rows] are both K-contiguous per output index, so
+// lane (i = lane & 31, kh = lane >> 5) of a 32x32x2 MFMA loads 16 consecutive rows of its a (and of
+// its b) per instance as four float4 and the 32 rows go through 16 MFMAs (k pair j = rows j, 16 + j).
+// One wave per (32 a) x (64 b) tile of one problem; up to VSV_MAX_WGRAD problems (layers) per launch.
+// ---------------------------------------------------------------------------
+struct WgradArgs {
+    vsv_wgrad w;
+    int tile0[VSV_MAX_WGRAD + 1];
+};
+
+__global__ void __launch_bounds__(256) wgrad_kernel(const WgradArgs a) {
+    typedef const __attribute__((address_space(4))) WgradArgs* KP;
+    const KP kp = (KP)__builtin_amdgcn_kernarg_segment_ptr();
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int tile = blockIdx.x * 4 + wave;
+    const int n = kp->w.n;
+    if (tile >= kp->tile0[n]) return;
+    int pi = 0;
+    while (pi + 1 < n && tile >= kp->tile0[pi + 1]) ++pi;                     // wave-uniform
+    const float* g = kp->w.p[pi].g;
+    const long g_stride = kp->w.p[pi].g_stride;
+    const int B0 = kp->w.p[pi].n_b[0], B1 = kp->w.p[pi].n_b[1];
+    const int NI = kp->w.p[pi].n_inst, Tw = kp->w.p[pi].T;
+    const int nbg = (B0 + B1 + 63) / 64;
+    const int lt = tile - kp->tile0[pi];
+    const int at = lt / nbg, bg = lt - at * nbg;
+    const int i32 = lane & 31, kh = lane >> 5;
+
+    const float* ga = g + (size_t)(at * 32 + i32) * 32 + kh * 16;
+    const float* xb[2];
+    long xs[2];
+    int sh[2];
+    bool ok[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int b = bg * 64 + j * 32 + i32;
+        ok[j] = b < B0 + B1;
+        const int seg = (b >= B0) ? 1 : 0;
+        const int bl = seg ? b - B0 : b;
+        xb[j] = (seg ? kp->w.p[pi].x[1] : kp->w.p[pi].x[0]) + (size_t)bl * 32 + kh * 16;
+        xs[j] = seg ? kp->w.p[pi].x_stride[1] : kp->w.p[pi].x_stride[0];
+        sh[j] = seg ? kp->w.p[pi].shift[1] : kp->w.p[pi].shift[0];
+    }
+    f32x16 acc[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[j][r] = 0.0f;
+    float bsum = 0.0f;
+    const float4 z4 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    int t = 0;
+    for (int i = 0; i < NI; ++i) {
+        float4 av[4], bv[2][4];
+        const float4* gp4 = (const float4*)(ga + (size_t)i * g_stride);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) av[q] = gp4[q];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            // shift: the instance one step earlier in time (h_{t-1}); zeros at t = 0
+            const bool live = ok[j] && !(sh[j] && t == 0);
+            const float4* xp = (const float4*)(xb[j] + (size_t)(i - sh[j]) * xs[j]);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) bv[j][q] = live ? xp[q] : z4;
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const float aq[4] = {av[q].x, av[q].y, av[q].z, av[q].w};
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const float bq[4] = {bv[j][q].x, bv[j][q].y, bv[j][q].z, bv[j][q].w};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc[j] = mfma32(aq[e], bq[e], acc[j]);
+            }
+            bsum += (aq[0] + aq[1]) + (aq[2] + aq[3]);
+        }
+        if (++t == Tw) t = 0;
+    }
+    float* gpo = kp->w.gp;
+    const long w_off = kp->w.p[pi].w_off;
+    const int nt = kp->w.p[pi].nt;
+    // D register r of lane: a = 32*at + 8*(r>>2) + 4*kh + (r&3), b = 64*bg + 32*j + i32
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        if (!ok[j]) continue;
+        const int b = bg * 64 + j * 32 + i32;
+        const long colpart = w_off + (long)(b >> 3) * nt * 256 + (b & 1) * 128 + ((b >> 1) & 3);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int av_ = at * 32 + 8 * (r >> 2) + 4 * kh + (r & 3);
+            const int s_ = av_ >> 1, hh = av_ & 1;
+            const int nf = 32 * (s_ >> 4) + 8 * ((s_ >> 2) & 3) + 4 * hh + (s_ & 3);      // slot order -> feature
+            gpo[colpart + (long)(nf >> 5) * 256 + (nf & 31) * 4] = acc[j][r];
+        }
+    }
+    if (bg == 0 && kp->w.p[pi].bias) {
+        bsum += __shfl_xor(bsum, 32);
+        if (kh == 0) {
+            const int av_ = at * 32 + i32;
+            const int s_ = av_ >> 1, hh = av_ & 1;
+            const int nf = 32 * (s_ >> 4) + 8 * ((s_ >> 2) & 3) + 4 * hh + (s_ & 3);
+            const int tq = nf >> 5, iq = nf & 31;
+            gpo[kp->w.p[pi].b_off + (tq * 2 + ((iq >> 2) & 1)) * 16 + 4 * (iq >> 3) + (iq & 3)] = bsum;
+        }
+    }
+}
+
+extern "C" int vsv_weight_grads(const vsv_wgrad* d, void* stream) {
+    if (!d || !d->gp) { set_error("vsv_weight_grads: null pointer"); return -1; }
+    if (d->n < 1 || d->n > VSV_MAX_WGRAD) { set_error("vsv_weight_grads: 1..%d problems per launch", VSV_MAX_WGRAD); return -1; }
+    WgradArgs a;
+    a.w = *d;
+    long tiles = 0;
+    for (int i = 0; i < d->n; ++i) {
+        const vsv_wgrad_prob& p = d->p[i];
+        if (!p.g || !p.x[0] || (p.n_b[1] > 0 && !p.x[1])) { set_error("vsv_weight_grads: problem %d: null pointer", i); return -1; }
+        if (p.n_a < 32 || p.n_a % 32 || p.n_b[0] < 1 || p.n_b[1] < 0 || p.n_inst < 1 || p.T < 1 || p.n_inst % p.T ||
+            p.nt < 1 || p.n_a > 32 * p.nt || p.g_stride < (long)p.n_a * 32 || p.x_stride[0] < (long)p.n_b[0] * 32 ||
+            (p.n_b[1] > 0 && p.x_stride[1] < (long)p.n_b[1] * 32) || (p.shift[0] | p.shift[1]) & ~1) {
+            set_error("vsv_weight_grads: problem %d has an unsupported shape", i); return -1;
+        }
+        a.tile0[i] = (int)tiles;
+        tiles += (long)(p.n_a / 32) * ((p.n_b[0] + p.n_b[1] + 63) / 64);
+        if (tiles > 0x3fffffffL) { set_error("vsv_weight_grads: too many tiles"); return -2; }
+    }
+    for (int i = d->n; i <= VSV_MAX_WGRAD; ++i) a.tile0[i] = (int)tiles;
+    hipLaunchKernelGGL(wgrad_kernel, dim3((unsigned)((tiles + 3) / 4)), dim3(256), 0, (hipStream_t)stream, a);
+    return launch_check("wgrad_kernel");
+}
+
 template <int NT, int NL>
 static int launch_lstm_bwd(const vsv_lstm_bwd& a, hipStream_t st) {
     const size_t lds = (size_t)NL * 16 * NT * 64 * sizeof(float);

@@ -94,6 +94,20 @@ class VsvLstmBwd(C.Structure):
                 ("drop_seed_dev", C.c_void_p)]
 
 
+VSV_MAX_WGRAD = 16
+
+
+class VsvWgradProb(C.Structure):
+    _fields_ = [("g", C.c_void_p), ("g_stride", C.c_long), ("n_a", C.c_int),
+                ("x", C.c_void_p * 2), ("x_stride", C.c_long * 2), ("n_b", C.c_int * 2), ("shift", C.c_int * 2),
+                ("n_inst", C.c_int), ("T", C.c_int),
+                ("w_off", C.c_long), ("b_off", C.c_long), ("nt", C.c_int), ("bias", C.c_int)]
+
+
+class VsvWgrad(C.Structure):
+    _fields_ = [("n", C.c_int), ("gp", C.c_void_p), ("p", VsvWgradProb * VSV_MAX_WGRAD)]
+
+
 class VsvLoss(C.Structure):
     _fields_ = [("pred", C.c_void_p), ("target", C.c_void_p),
                 ("B", C.c_int), ("H", C.c_int), ("T", C.c_int), ("Q", C.c_int),
@@ -136,6 +150,7 @@ SIGNATURES = {
     "vsv_dense_backward": (C.c_int, [C.POINTER(VsvDenseBwd), C.c_void_p]),
     "vsv_lstm_backward": (C.c_int, [C.POINTER(VsvLstmBwd), C.c_int, C.c_int, C.c_void_p]),
     "vsv_loss_grad": (C.c_int, [C.POINTER(VsvLoss), C.c_void_p]),
+    "vsv_weight_grads": (C.c_int, [C.POINTER(VsvWgrad), C.c_void_p]),
     "vsv_debug_layout": (C.c_int, [C.POINTER(VsvDims), C.POINTER(C.c_longlong), C.c_int]),
     "vsv_philox_normal": (C.c_int, [C.c_uint64, C.c_long, C.c_long, C.c_long, C.c_int, C.c_int,
                                     C.c_int, C.c_void_p, C.c_void_p]),
@@ -163,7 +178,7 @@ def load() -> C.CDLL:
             fn = getattr(lib, name)
             fn.restype = res
             fn.argtypes = args
-        if lib.vsv_abi_version() != 7:
+        if lib.vsv_abi_version() != 8:
             raise RuntimeError("libvsv_hip.so ABI version mismatch")
         _lib = lib
     return _lib

@@ -5,9 +5,10 @@ Division of labour (DESIGN.md "Training"): the recurrent and element-wise work
 -- LSTM forward/backward through time, conv/linear chains forward/backward,
 losses -- runs in the hand-written kernels behind the C ABI
 (vsv_train_encode / vsv_train_decode / vsv_loss_grad / vsv_dense_backward /
-vsv_lstm_backward).  What is left are plain matrix products dW = G^T . X over
-tensors those kernels leave in HBM; they run as library GEMMs (torch.matmul ->
-rocBLAS) and are scattered onto the parameters through the same index maps that
+vsv_lstm_backward).  The matrix products dW = G^T . X over the tensors those
+kernels leave in HBM run in one more kernel (vsv_weight_grads: every layer of a
+step in one or two launches, written at the packed positions), and the packed
+gradient is scattered onto the parameters through the same index maps that
 define the weight packing, so Toeplitz-expanded conv weights, interleaved LSTM
 gates and summed biases all come out as gradients of the original parameters.
 """
@@ -171,7 +172,6 @@ class TrainEngine:
         self._idx_b = torch.from_numpy(ib[nz]).to(self.dev)
         self._sizes = [int(np.prod(s)) for _, s in named_shapes]
         self._shapes = [tuple(s) for _, s in named_shapes]
-        self._pos_cache: Dict[tuple, tuple] = {}
 
     # -- helpers -----------------------------------------------------------------------
     def _stream(self):
@@ -187,33 +187,33 @@ class TrainEngine:
         off, nq, nt = self.bb.off[name]
         return blobT.data_ptr() + 4 * off, nq, nt
 
-    def _wmap(self, sec: _Sec, n_out_slots: int, k_steps: int):
-        """(rows a = 2*slot+half of G, cols b = 2*kstep+half of X) -> blob positions; bias positions."""
-        key = (sec.w_off, n_out_slots, k_steps)
-        if key not in self._pos_cache:
-            a = np.arange(2 * n_out_slots)
-            n = _slot_feature(a >> 1, a & 1)
-            k = np.arange(2 * k_steps)
-            pos = _wpos(sec, n[:, None], k[None, :])
-            self._pos_cache[key] = (torch.from_numpy(pos.reshape(-1).astype(np.int64)).to(self.dev),
-                                    torch.from_numpy(_bpos(sec, n).astype(np.int64)).to(self.dev))
-        return self._pos_cache[key]
+    def _acc_layer(self, c, sec, G, X, bias=True, X1=None, T=1):
+        """Queue gp[blob positions of sec] = G^T . [X | X1 shifted one step] (and the bias row sums) for
+        vsv_weight_grads (flushed by _wg_flush once every G has been written).  G (NI, so, 64) slot order,
+        X (NI, ks, 64) in the layer's k order, X1 (NI, ks1, 64) the recurrent input's source (h of the same
+        step; the kernel reads the previous step's).  Views are fine: pointer and instance stride are passed."""
+        for t in (G, X) + (() if X1 is None else (X1,)):
+            assert t.dim() == 3 and t.shape[2] == 64 and t.stride(2) == 1 and t.stride(1) == 64 and t.dtype == torch.float32
+        c.wg.append((sec, G, X, X1, bool(bias), int(T)))
 
-    @staticmethod
-    def _mat(t: torch.Tensor) -> torch.Tensor:
-        """tile-B (NI, slots, 64) -> (2*slots, NI*32): row a = 2*slot + half."""
-        ni, ns, _ = t.shape
-        return t.reshape(ni, ns, 2, 32).permute(1, 2, 0, 3).reshape(2 * ns, ni * 32)
-
-    def _acc_layer(self, gp, sec, G, X, bias=True):
-        """gp[blob positions] += G^T . X (and the bias row sums).  G (NI, so, 64) slot order,
-        X (NI, ks, 64) in the layer's k order."""
-        Gm, Xm = self._mat(G), self._mat(X)
-        pos, bpos = self._wmap(sec, G.shape[1], X.shape[1])
-        # every blob position belongs to exactly one (layer, row, column): plain copies, no atomics
-        gp.index_copy_(0, pos, (Gm @ Xm.t()).reshape(-1))
-        if bias:
-            gp.index_copy_(0, bpos, Gm.sum(dim=1))
+    def _wg_flush(self, c, gp):
+        """One vsv_weight_grads launch per VSV_MAX_WGRAD queued layers, on the current stream."""
+        q, c.wg = c.wg, []
+        for o in range(0, len(q), _lib.VSV_MAX_WGRAD):
+            a = _lib.VsvWgrad()
+            a.gp = gp.data_ptr()
+            part = q[o:o + _lib.VSV_MAX_WGRAD]
+            a.n = len(part)
+            for i, (sec, G, X, X1, bias, T) in enumerate(part):
+                p = a.p[i]
+                p.g, p.g_stride, p.n_a = G.data_ptr(), G.stride(0), 2 * G.shape[1]
+                p.x[0], p.x_stride[0], p.n_b[0], p.shift[0] = X.data_ptr(), X.stride(0), 2 * X.shape[1], 0
+                if X1 is not None:
+                    p.x[1], p.x_stride[1], p.n_b[1], p.shift[1] = X1.data_ptr(), X1.stride(0), 2 * X1.shape[1], 1
+                p.n_inst, p.T = G.shape[0], T
+                p.w_off, p.b_off, p.nt, p.bias = sec.w_off, sec.b_off, sec.nt, int(bias)
+            _lib.check(self.lib.vsv_weight_grads(C.byref(a), self._stream()), "vsv_weight_grads")
+        c.wg_keep = q                                        # operands stay referenced until the next flush
 
     # -- building blocks ----------------------------------------------------------------
     class _Ctx:
@@ -231,6 +231,7 @@ class TrainEngine:
         c.drop_seed_dev = dropout_seed if torch.is_tensor(dropout_seed) else None
         c.drop_seed = 0 if c.drop_seed_dev is not None else int(dropout_seed) & (2 ** 64 - 1)
         c.blobT = None
+        c.wg = []
         return c
 
     def _set_drop(self, c, s, sv, NI, NT, drop_id):
@@ -300,14 +301,10 @@ class TrainEngine:
 
     def _lstm_wgrads(self, c, gp, secs, sv, dg, Tw, NT, x_tile):
         """dW of the LSTM layers: X = [x | h_prev] (layer 0), [h0 | h1_prev] (layer 1)."""
-        NL, rt = self.NL, c.rt
-        h = sv["h"].view(rt, Tw, NL, 4 * NT, 64)
-        hprev = torch.cat([torch.zeros_like(h[:, :1]), h[:, :-1]], dim=1).reshape(rt * Tw, NL, 4 * NT, 64)
-        for l in range(NL):
+        for l in range(self.NL):
             # layer 1 read layer 0's h AFTER dropout when it is on
             xin = x_tile if l == 0 else (sv["hd"] if c.drop_p > 0 else sv["h"][:, l - 1])
-            Xl = torch.cat([xin, hprev[:, l]], dim=1)
-            self._acc_layer(gp, secs[l], dg[:, l], Xl)
+            self._acc_layer(c, secs[l], dg[:, l], xin, X1=sv["h"][:, l], T=Tw)
 
     def _enc_bwd(self, c, gp, which, sv, Tw, d_out, want_dsurf=False):
         """Backward of one encoder stack from d(out) (B, Tw, nh): head, LSTM (BPTT), conv embedding;
@@ -321,7 +318,7 @@ class TrainEngine:
         w, nq, nt = self._wT(blobT, f"{pf}.head")
         dh = self._dense_bwd(c, [dict(wT=w, nqT=nq, ntT=nt, n_relu=0, g_out=gh.data_ptr())], Tw, 0, d_out,
                              d_out.shape[-1], True)
-        self._acc_layer(gp, e["head"], gh[:, : 16 * e["head"].nt], sv["hout"])
+        self._acc_layer(c, e["head"], gh[:, : 16 * e["head"].nt], sv["hout"])
         dxt = self._e(rt * Tw, 64, 64)
         dgl = self._lstm_bwd(c, pf, self.Hm, NTm, sv, Tw, 0, dh, e["kx"] // 16, sv["drop_id"], dx_tile=dxt)
         self._lstm_wgrads(c, gp, e["lstm"], sv, dgl, Tw, NTm, sv["xe"])
@@ -338,7 +335,7 @@ class TrainEngine:
         dxs = self._dense_bwd(c, layers, Tw, 1, dxt, 0, want_dsurf)
         for li, g in gs:
             cs = e["conv"][li]
-            self._acc_layer(gp, cs, g[:, : 16 * cs.nt], sv["emb_acts"][li][:, : 4 * cs.nq])
+            self._acc_layer(c, cs, g[:, : 16 * cs.nt], sv["emb_acts"][li][:, : 4 * cs.nq])
         if not want_dsurf:
             return None
         # tile-B [inst][slot][half*32 + m] -> (B, Tw, 25): grid point f sits at slot 4*(f>>3) + (f&3), half (f>>2)&1
@@ -359,6 +356,7 @@ class TrainEngine:
             d_out = d_out_fn(out).to(torch.float32).contiguous()
             gp = torch.zeros(c.packed.numel(), dtype=torch.float32, device=self.dev)
             self._enc_bwd(c, gp, which, sv, Tw, d_out)
+            self._wg_flush(c, gp)
         return out, gp
 
     # -- one forward/backward ----------------------------------------------------------
@@ -455,7 +453,7 @@ class TrainEngine:
                 layers.append(ly)
             dh_top = self._dense_bwd(c, layers, horizon, 0, d_pred, Q * 25, True)
             for li, g in gs:
-                self._acc_layer(gp, hd[li], g[:, : 16 * hd[li].nt], sv_d["head_acts"][li][:, : 4 * hd[li].nq])
+                self._acc_layer(c, hd[li], g[:, : 16 * hd[li].nt], sv_d["head_acts"][li][:, : 4 * hd[li].nq])
             # decoder LSTM
             dx = self._e(B, T, 2 * L)
             dg = self._lstm_bwd(c, "d", lay["Hd"], NTd, sv_d, T, Cn, dh_top, 1, 2, dx_rows=dx, dx_f=2 * L)
@@ -476,6 +474,7 @@ class TrainEngine:
                 ds_c = self._enc_bwd(c, gp, 1, c.sv_c, Cn, d_ctx, want_input_grad)
             ds_e = self._enc_bwd(c, gp, 0, c.sv_e, T, d_enc, want_input_grad)
             main.wait_stream(side)
+            self._wg_flush(c, gp)
             if want_input_grad:
                 ds_e[:, :Cn] += ds_c
                 c.outputs["d_surface"] = ds_e.view(B, T, 5, 5)

@@ -1931,7 +1931,8 @@ extern "C" int vsv_dense_backward(const vsv_dense_bwd* d, void* stream) {
 // layout read as a plain array) and X [inst][b][32 rows] are both K-contiguous per output index, so
 // lane (i = lane & 31, kh = lane >> 5) of a 32x32x2 MFMA loads 16 consecutive rows of its a (and of
 // its b) per instance as four float4 and the 32 rows go through 16 MFMAs (k pair j = rows j, 16 + j).
-// One wave per (32 a) x (64 b) tile of one problem; up to VSV_MAX_WGRAD problems (layers) per launch.
+// One workgroup per (32 a) x (64 b) tile of one problem, its four waves splitting the instances;
+// up to VSV_MAX_WGRAD problems (layers) per launch.
 // ---------------------------------------------------------------------------
 struct WgradArgs {
     vsv_wgrad w;
@@ -1941,13 +1942,14 @@ struct WgradArgs {
 __global__ void __launch_bounds__(256) wgrad_kernel(const WgradArgs a) {
     typedef const __attribute__((address_space(4))) WgradArgs* KP;
     const KP kp = (KP)__builtin_amdgcn_kernarg_segment_ptr();
+    __shared__ float red[3][2][16][64];           // partial tiles of waves 1..3
+    __shared__ float redb[3][64];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int tile = blockIdx.x * 4 + wave;
+    const int tile = blockIdx.x;                   // the launcher sizes the grid to the tile count
     const int n = kp->w.n;
-    if (tile >= kp->tile0[n]) return;
     int pi = 0;
-    while (pi + 1 < n && tile >= kp->tile0[pi + 1]) ++pi;                     // wave-uniform
+    while (pi + 1 < n && tile >= kp->tile0[pi + 1]) ++pi;                     // block-uniform
     const float* g = kp->w.p[pi].g;
     const long g_stride = kp->w.p[pi].g_stride;
     const int B0 = kp->w.p[pi].n_b[0], B1 = kp->w.p[pi].n_b[1];
@@ -1966,8 +1968,9 @@ __global__ void __launch_bounds__(256) wgrad_kernel(const WgradArgs a) {
     for (int j = 0; j < 2; ++j) {
         const int b = bg * 64 + j * 32 + i32;
         ok[j] = b < B0 + B1;
-        const int seg = (b >= B0) ? 1 : 0;
-        const int bl = seg ? b - B0 : b;
+        const int bc = ok[j] ? b : 0;                                       // out-of-range columns read column 0, never stored
+        const int seg = (bc >= B0) ? 1 : 0;
+        const int bl = seg ? bc - B0 : bc;
         xb[j] = (seg ? kp->w.p[pi].x[1] : kp->w.p[pi].x[0]) + (size_t)bl * 32 + kh * 16;
         xs[j] = seg ? kp->w.p[pi].x_stride[1] : kp->w.p[pi].x_stride[0];
         sh[j] = seg ? kp->w.p[pi].shift[1] : kp->w.p[pi].shift[0];
@@ -1978,33 +1981,66 @@ __global__ void __launch_bounds__(256) wgrad_kernel(const WgradArgs a) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[j][r] = 0.0f;
     float bsum = 0.0f;
-    const float4 z4 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-    int t = 0;
-    for (int i = 0; i < NI; ++i) {
-        float4 av[4], bv[2][4];
+    // The four waves of the block split the instances (i = wave, wave + 4, ...).  Software pipeline: the
+    // next instance's operands are in flight while this one's go through the MFMAs; loads are
+    // unconditional (a shifted read at t = 0 reads the instance itself) and the zero for t = 0 is applied
+    // as a factor afterwards, so nothing waits on the loads before the MFMAs issue.
+    float4 av[4], bv[2][4], an[4], bn[2][4];
+    float mk[2], mn[2];
+    auto fetch = [&](int i, float4 (&fa)[4], float4 (&fb)[2][4], float (&m)[2]) {
+        const int t = i % Tw;
         const float4* gp4 = (const float4*)(ga + (size_t)i * g_stride);
 #pragma unroll
-        for (int q = 0; q < 4; ++q) av[q] = gp4[q];
+        for (int q = 0; q < 4; ++q) fa[q] = gp4[q];
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
-            // shift: the instance one step earlier in time (h_{t-1}); zeros at t = 0
-            const bool live = ok[j] && !(sh[j] && t == 0);
-            const float4* xp = (const float4*)(xb[j] + (size_t)(i - sh[j]) * xs[j]);
+            const bool dead = sh[j] && t == 0;
+            m[j] = dead ? 0.0f : 1.0f;
+            const float4* xp = (const float4*)(xb[j] + (size_t)(i - (dead ? 0 : sh[j])) * xs[j]);
 #pragma unroll
-            for (int q = 0; q < 4; ++q) bv[j][q] = live ? xp[q] : z4;
+            for (int q = 0; q < 4; ++q) fb[j][q] = xp[q];
         }
+    };
+    if (wave < NI) fetch(wave, av, bv, mk);
+    for (int i = wave; i < NI; i += 4) {
+        if (i + 4 < NI) fetch(i + 4, an, bn, mn);
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const float aq[4] = {av[q].x, av[q].y, av[q].z, av[q].w};
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
-                const float bq[4] = {bv[j][q].x, bv[j][q].y, bv[j][q].z, bv[j][q].w};
+                const float bq[4] = {bv[j][q].x * mk[j], bv[j][q].y * mk[j], bv[j][q].z * mk[j], bv[j][q].w * mk[j]};
 #pragma unroll
                 for (int e = 0; e < 4; ++e) acc[j] = mfma32(aq[e], bq[e], acc[j]);
             }
             bsum += (aq[0] + aq[1]) + (aq[2] + aq[3]);
         }
-        if (++t == Tw) t = 0;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            av[q] = an[q];
+            bv[0][q] = bn[0][q];
+            bv[1][q] = bn[1][q];
+        }
+        mk[0] = mn[0];
+        mk[1] = mn[1];
+    }
+    // fixed-order reduction over the four waves (deterministic)
+    if (wave > 0) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) red[wave - 1][j][r][lane] = acc[j][r];
+        redb[wave - 1][lane] = bsum;
+    }
+    __syncthreads();
+    if (wave > 0) return;
+#pragma unroll
+    for (int w = 0; w < 3; ++w) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[j][r] += red[w][j][r][lane];
+        bsum += redb[w][lane];
     }
     float* gpo = kp->w.gp;
     const long w_off = kp->w.p[pi].w_off;
@@ -2054,7 +2090,7 @@ extern "C" int vsv_weight_grads(const vsv_wgrad* d, void* stream) {
         if (tiles > 0x3fffffffL) { set_error("vsv_weight_grads: too many tiles"); return -2; }
     }
     for (int i = d->n; i <= VSV_MAX_WGRAD; ++i) a.tile0[i] = (int)tiles;
-    hipLaunchKernelGGL(wgrad_kernel, dim3((unsigned)((tiles + 3) / 4)), dim3(256), 0, (hipStream_t)stream, a);
+    hipLaunchKernelGGL(wgrad_kernel, dim3((unsigned)tiles), dim3(256), 0, (hipStream_t)stream, a);
     return launch_check("wgrad_kernel");
 }
 

@@ -523,9 +523,16 @@ class CVAEMemRand(BaseVAE):
         return te
 
     def _loss_cfg(self):
-        w = self.quantile_loss_fn.weights.detach().cpu().tolist()
+        # the quantile levels / weights are buffers on the device: read them back once per version,
+        # not once per step (each read-back is a blocking copy)
+        qf = self.quantile_loss_fn
+        key = (qf.quantiles.data_ptr(), qf.quantiles._version, qf.weights.data_ptr(), qf.weights._version)
+        cached = self.__dict__.get("_vsv_qcache")
+        if cached is None or cached[0] != key:
+            cached = (key, qf.quantiles.detach().cpu().tolist(), qf.weights.detach().cpu().tolist())
+            self.__dict__["_vsv_qcache"] = cached
         X = self.config["ex_feats_dim"]
-        return dict(quantiles=self.quantile_loss_fn.quantiles.detach().cpu().tolist(), quantile_weights=w,
+        return dict(quantiles=list(cached[1]), quantile_weights=list(cached[2]),
                     ex_n=(1 if self.config["ex_loss_on_ret_only"] else max(X, 1)),
                     ex_l2=int(isinstance(self.ex_feats_loss_fn, nn.MSELoss)),
                     ex_weight=float(self.config["re_feat_weight"]), kl_weight=float(self.kl_weight))

@@ -119,8 +119,20 @@ def train_bench(dev, steps: int, cpu_steps: int):
     batches = [{"surface": torch.from_numpy((0.2 + 0.1 * rng.standard_normal((B, int(T), 5, 5))).astype(np.float32)).to(dev),
                 "ex_feats": torch.from_numpy((0.01 * rng.standard_normal((B, int(T), 3))).astype(np.float32)).to(dev)}
                for T in lens]
-    # untimed: one step per sequence length, so every shape's HIP graph (vsv/graphed.py) is captured, as it is
-    # after the first pass over the sampler's length groups in a real run (500+ epochs), then 3 more steps
+    for b in batches[:3]:
+        model.train_step(b, opt)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for b in batches[3:]:
+        model.train_step(b, opt)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    out = {"metric": "train samples/s", "value": B * steps / dt, "unit": "samples/s", "ms_per_step": dt / steps * 1e3,
+           "config": {"workload": "BASELINE configs[1]: CVAEMemRand ex_loss train_step, batch 64, T ~ U[2,21], "
+                                  "horizon 1, AdamW(1e-5), clip 1.0, dropout 0", "steps": steps}}
+    # the same steps with forward+loss+backward replayed as one HIP graph per sequence length (opt-in,
+    # config hip_graphs; vsv/graphed.py).  Untimed first: one step per length, so every graph is captured.
+    model.config["hip_graphs"] = True
     warm = {int(b["surface"].shape[1]): b for b in batches}
     for T in range(2, 22):
         if T not in warm:
@@ -132,24 +144,8 @@ def train_bench(dev, steps: int, cpu_steps: int):
     for b in batches[3:]:
         model.train_step(b, opt)
     torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    out = {"metric": "train samples/s", "value": B * steps / dt, "unit": "samples/s", "ms_per_step": dt / steps * 1e3,
-           "config": {"workload": "BASELINE configs[1]: CVAEMemRand ex_loss train_step, batch 64, T ~ U[2,21], "
-                                  "horizon 1, AdamW(1e-5), clip 1.0, dropout 0; forward+loss+backward replayed as one "
-                                  "HIP graph per sequence length (captured in warm-up), clip + AdamW eager",
-                      "steps": steps}}
-    # the same steps with the launches issued one by one (config hip_graphs False)
+    out["ms_per_step_hip_graph"] = (time.perf_counter() - t0) / steps * 1e3
     model.config["hip_graphs"] = False
-    n_eager = min(20, steps)
-    for b in batches[:3]:
-        model.train_step(b, opt)
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for b in batches[3:3 + n_eager]:
-        model.train_step(b, opt)
-    torch.cuda.synchronize()
-    out["ms_per_step_eager_launches"] = (time.perf_counter() - t0) / n_eager * 1e3
-    model.config["hip_graphs"] = True
     if cpu_steps > 0:
         from oracle.torch_port import TorchPort
         port = TorchPort(cfg, W, torch.float32)
@@ -228,7 +224,7 @@ def main():
     ap.add_argument("--horizon", type=int, default=1)
     ap.add_argument("--latent", type=int, default=12)
     ap.add_argument("--ex-feats", type=int, default=3)
-    ap.add_argument("--chunk-days", type=int, default=500)
+    ap.add_argument("--chunk-days", type=int, default=4000, help="days per decode launch")
     ap.add_argument("--cpu-budget", type=float, default=15.0, help="seconds of CPU baseline work (0 = skip)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL)")
     ap.add_argument("--train-steps", type=int, default=50, help="training steps of the secondary metric (0 = skip)")

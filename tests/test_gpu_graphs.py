@@ -11,6 +11,7 @@ pytestmark = pytest.mark.gpu
 def _model(p=0.0, **kw):
     from vae.cvae_with_mem_randomized import CVAEMemRand
     torch.manual_seed(0)
+    kw.setdefault("hip_graphs", True)
     cfg = vo.make_config(5, 3, device="cuda:0", kl_weight=1e-3, mem_dropout=p, **kw)
     m = CVAEMemRand(cfg)
     m.load_state_dict({k: torch.from_numpy(v) for k, v in vo.init_weights(cfg, 4, 1.5, np.float32).items()}, strict=False)

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define VSV_ABI_VERSION 8
+#define VSV_ABI_VERSION 9
 #define VSV_MAX_CONV 4
 #define VSV_MAX_CHAIN 8
 #define VSV_MAX_INTERACT 3
@@ -272,8 +272,27 @@ typedef struct vsv_lstm_bwd {
     int drop_id;
     int gru;                                /* 1: the saved gates are nn.GRU's (r, z, n, W_hn h + b_hn) */
     const uint64_t* drop_seed_dev;          /* as in vsv_train_save */
+    int sv_nl, sv_l0;                       /* sv_nl > 0: sv_gates / sv_c / dgates hold sv_nl layers per instance and
+                                             * this call handles `layers` of them from sv_l0 (wT_hh[0] is layer sv_l0's):
+                                             * one call per layer, with vsv_tileb_gemm_launch between them */
 } vsv_lstm_bwd;
 int vsv_lstm_backward(const vsv_lstm_bwd *d, int hidden, int layers, void *stream);
+
+/* The parts of BPTT off the recurrence, for all (row tile, t) instances at once:
+ *   out(inst) = W^T . g(inst)      d h_{l-1}(t) = W_ih(l)^T . dgates(l, t)   (x dropout factors of layer l-1)
+ *                                  dx(t)        = W_ih(0)^T . dgates(0, t)
+ * wT: transposed fragments (nqT K-quads, ntT <= 4 output tiles); g: [inst][4*nqT][64] with g_stride floats
+ * per instance; out_tile [inst][64][64] (slot 16*tile + register) and/or out_rows (n_rows, T, out_f).
+ * With two layers vsv_lstm_backward(layer 1) -> this -> vsv_lstm_backward(layer 0, dh_top = out_tile,
+ * t_out0 = 0) -> this computes what one two-layer call does, with half the work on the time loop. */
+typedef struct vsv_tileb_gemm {
+    const float *wT;  int nqT, ntT;
+    const float *g;  long g_stride;
+    long n_rows, n_rowtiles;  int T;
+    float *out_tile, *out_rows;  int out_f;
+    float drop_p;  uint64_t drop_seed;  const uint64_t *drop_seed_dev;  int drop_id, drop_layer;
+} vsv_tileb_gemm;
+int vsv_tileb_gemm_launch(const vsv_tileb_gemm *d, void *stream);
 
 /* Weight gradients of dense / LSTM layers (autograd's dW = dY^T . X for nn.Linear, the conv layers'
  * expanded matrices and nn.LSTM / nn.GRU, reached from loss.backward() at :1127): for each problem,

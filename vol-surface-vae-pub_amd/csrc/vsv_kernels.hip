@@ -1140,6 +1140,8 @@ __global__ void __launch_bounds__(256, 1) lstm_bwd_kernel(const LstmBwdArgs a) {
         for (int r = 0; r < 16; ++r) dc[l][r] = 0.0f;
     const int toff1[1] = {wave * 64};
     const int t_outs = a.T - a.t_out0;
+    // layers of the saved arrays / first of them handled here (one launch per layer: NL = 1, sv_nl = 2)
+    const int SL = a.sv_nl > 0 ? a.sv_nl : NL, L0 = a.sv_nl > 0 ? a.sv_l0 : 0;
     __syncthreads();
 
     for (int t = a.T - 1; t >= 0; --t) {
@@ -1179,9 +1181,9 @@ __global__ void __launch_bounds__(256, 1) lstm_bwd_kernel(const LstmBwdArgs a) {
                 gemm_seg<1>(acc, (const float4*)a.wT_hh[l], lane, toff1, 4 * 64, dg + (size_t)l * GK * 64, 4 * NT);
             // cell backward for the 16 units of this lane
             float dgv[16][4];
-            const float* sg = a.sv_gates + (inst * NL + l) * GK * 64 + lane;
-            const float* sc = a.sv_c + (inst * NL + l) * (4 * NT) * 64 + lane;
-            const float* scp = (t > 0) ? a.sv_c + ((inst - 1) * NL + l) * (4 * NT) * 64 + lane : nullptr;
+            const float* sg = a.sv_gates + (inst * SL + L0 + l) * GK * 64 + lane;
+            const float* sc = a.sv_c + (inst * SL + L0 + l) * (4 * NT) * 64 + lane;
+            const float* scp = (t > 0) ? a.sv_c + ((inst - 1) * SL + L0 + l) * (4 * NT) * 64 + lane : nullptr;
 #pragma unroll
             for (int jq = 0; jq < 4; ++jq) {
                 const int tg = 4 * jq + wave;
@@ -1220,7 +1222,7 @@ __global__ void __launch_bounds__(256, 1) lstm_bwd_kernel(const LstmBwdArgs a) {
             }
             __syncthreads();                                       // every wave has read dgates(l, t+1)
             float* dgl = dg + (size_t)l * GK * 64;
-            float* dgo = a.dgates + (inst * NL + l) * GK * 64 + lane;
+            float* dgo = a.dgates + (inst * SL + L0 + l) * GK * 64 + lane;
 #pragma unroll
             for (int jq = 0; jq < 4; ++jq) {
                 const int tg = 4 * jq + wave;
@@ -1255,6 +1257,57 @@ __global__ void __launch_bounds__(256, 1) lstm_bwd_kernel(const LstmBwdArgs a) {
                     if (f < a.dx_f) o[f] = acc[0][r];
                 }
             }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// tileb_gemm_kernel: Y(inst) = W^T-fragments . G(inst) for every (row tile, t) instance at once -- the
+// parts of BPTT that do not sit on the recurrence (d h_{l-1}(t) = W_in(l)^T . dgates(l, t) and
+// dx(t) = W_in(0)^T . dgates(0, t)), taken out of lstm_bwd_kernel's time loop so that they run on as
+// many CUs as there are instances.  One workgroup per instance, wave w = output tile w.
+// ---------------------------------------------------------------------------
+typedef vsv_tileb_gemm TilebGemmArgs;
+
+__global__ void __launch_bounds__(256) tileb_gemm_kernel(const TilebGemmArgs a) {
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    if (wave >= a.ntT) return;
+    const size_t inst = blockIdx.x;
+    const long rowtile = (long)(inst / (size_t)a.T);
+    const int t = (int)(inst - (size_t)rowtile * a.T);
+    const int hh = lane >> 5, m = lane & 31;
+    const long row_raw = rowtile * 32 + m;
+    const bool row_ok = row_raw < a.n_rows;
+    const int toff1[1] = {wave * 64};
+    f32x16 acc[1];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[0][r] = 0.0f;
+    gemm_seg<1>(acc, (const float4*)a.wT, lane, toff1, a.ntT * 64, a.g + inst * (size_t)a.g_stride + lane, a.nqT);
+    if (a.drop_p > 0.0f) {
+        // the consumer read the dropped copy of these units: same Philox factors as the forward
+        const DropArgs da = resolve_drop(DropArgs{a.drop_p, 1.0f / (1.0f - a.drop_p), (uint32_t)a.drop_seed,
+                                                  (uint32_t)(a.drop_seed >> 32), (uint32_t)a.drop_id,
+                                                  (const uint32_t*)a.drop_seed_dev});
+        const uint32_t rowc = (uint32_t)(row_ok ? row_raw : a.n_rows - 1);
+#pragma unroll
+        for (int jq = 0; jq < 4; ++jq) {
+            float fct[4];
+            dropout_factors(da, rowc, (uint32_t)t, 4 * jq + wave, hh, a.drop_layer, fct);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[0][4 * jq + r] *= fct[r];
+        }
+    }
+    if (a.out_tile) {
+        float* o = a.out_tile + (inst * 64 + 16 * wave) * 64 + lane;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[r * 64] = acc[0][r];
+    }
+    if (a.out_rows && row_ok) {
+        float* o = a.out_rows + ((size_t)row_raw * a.T + t) * a.out_f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int f = feat_of(wave, r, hh);
+            if (f < a.out_f) o[f] = acc[0][r];
         }
     }
 }
@@ -2110,12 +2163,26 @@ extern "C" int vsv_lstm_backward(const vsv_lstm_bwd* d, int hidden, int layers, 
     if (d->nt_x < 0 || d->nt_x > 4 || (d->nt_x > 0 && !d->wT_in[0])) { set_error("vsv_lstm_backward: bad nt_x"); return -1; }
     if (layers == 2 && (!d->wT_hh[1] || !d->wT_in[1])) { set_error("vsv_lstm_backward: layer 1 weights missing"); return -1; }
     if (d->drop_p < 0.0f || d->drop_p >= 1.0f) { set_error("vsv_lstm_backward: dropout probability must be in [0,1)"); return -1; }
+    if (d->sv_nl < 0 || (d->sv_nl > 0 && (d->sv_l0 < 0 || d->sv_l0 + layers > d->sv_nl))) { set_error("vsv_lstm_backward: bad sv_nl / sv_l0"); return -1; }
     const int NT = (hidden + 7) / 8;
     hipStream_t st = (hipStream_t)stream;
     if (NT == 13) return layers == 2 ? launch_lstm_bwd<13, 2>(*d, st) : launch_lstm_bwd<13, 1>(*d, st);
     if (NT == 16) return layers == 2 ? launch_lstm_bwd<16, 2>(*d, st) : launch_lstm_bwd<16, 1>(*d, st);
     set_error("vsv_lstm_backward: unsupported hidden size %d", hidden);
     return -4;
+}
+
+extern "C" int vsv_tileb_gemm_launch(const vsv_tileb_gemm* d, void* stream) {
+    if (!d || !d->wT || !d->g || (!d->out_tile && !d->out_rows)) { set_error("vsv_tileb_gemm_launch: null pointer"); return -1; }
+    if (d->nqT < 1 || d->ntT < 1 || d->ntT > 4 || d->T < 1 || d->n_rows < 1 || d->n_rowtiles != (d->n_rows + 31) / 32 ||
+        d->g_stride < (long)d->nqT * 4 * 64 || (d->out_rows && d->out_f < 1)) {
+        set_error("vsv_tileb_gemm_launch: bad sizes"); return -1;
+    }
+    if (d->drop_p < 0.0f || d->drop_p >= 1.0f) { set_error("vsv_tileb_gemm_launch: dropout probability must be in [0,1)"); return -1; }
+    const long insts = d->n_rowtiles * d->T;
+    if (insts > 0x7fffffffL) { set_error("vsv_tileb_gemm_launch: too many instances"); return -2; }
+    hipLaunchKernelGGL(tileb_gemm_kernel, dim3((unsigned)insts), dim3(256), 0, (hipStream_t)stream, *d);
+    return launch_check("tileb_gemm_kernel");
 }
 
 extern "C" int vsv_loss_grad(const vsv_loss* d, void* stream) {

@@ -91,7 +91,16 @@ class VsvLstmBwd(C.Structure):
                 ("sv_gates", C.c_void_p), ("sv_c", C.c_void_p), ("dh_top", C.c_void_p),
                 ("dgates", C.c_void_p), ("dx_tile", C.c_void_p), ("dx_rows", C.c_void_p), ("dx_f", C.c_int),
                 ("drop_p", C.c_float), ("drop_seed", C.c_uint64), ("drop_id", C.c_int), ("gru", C.c_int),
-                ("drop_seed_dev", C.c_void_p)]
+                ("drop_seed_dev", C.c_void_p), ("sv_nl", C.c_int), ("sv_l0", C.c_int)]
+
+
+class VsvTilebGemm(C.Structure):
+    _fields_ = [("wT", C.c_void_p), ("nqT", C.c_int), ("ntT", C.c_int),
+                ("g", C.c_void_p), ("g_stride", C.c_long),
+                ("n_rows", C.c_long), ("n_rowtiles", C.c_long), ("T", C.c_int),
+                ("out_tile", C.c_void_p), ("out_rows", C.c_void_p), ("out_f", C.c_int),
+                ("drop_p", C.c_float), ("drop_seed", C.c_uint64), ("drop_seed_dev", C.c_void_p),
+                ("drop_id", C.c_int), ("drop_layer", C.c_int)]
 
 
 VSV_MAX_WGRAD = 16
@@ -150,6 +159,7 @@ SIGNATURES = {
     "vsv_dense_backward": (C.c_int, [C.POINTER(VsvDenseBwd), C.c_void_p]),
     "vsv_lstm_backward": (C.c_int, [C.POINTER(VsvLstmBwd), C.c_int, C.c_int, C.c_void_p]),
     "vsv_loss_grad": (C.c_int, [C.POINTER(VsvLoss), C.c_void_p]),
+    "vsv_tileb_gemm_launch": (C.c_int, [C.POINTER(VsvTilebGemm), C.c_void_p]),
     "vsv_weight_grads": (C.c_int, [C.POINTER(VsvWgrad), C.c_void_p]),
     "vsv_debug_layout": (C.c_int, [C.POINTER(VsvDims), C.POINTER(C.c_longlong), C.c_int]),
     "vsv_philox_normal": (C.c_int, [C.c_uint64, C.c_long, C.c_long, C.c_long, C.c_int, C.c_int,
@@ -178,7 +188,7 @@ def load() -> C.CDLL:
             fn = getattr(lib, name)
             fn.restype = res
             fn.argtypes = args
-        if lib.vsv_abi_version() != 8:
+        if lib.vsv_abi_version() != 9:
             raise RuntimeError("libvsv_hip.so ABI version mismatch")
         _lib = lib
     return _lib

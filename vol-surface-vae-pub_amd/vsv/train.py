@@ -15,6 +15,7 @@ gates and summed biases all come out as gradients of the original parameters.
 from __future__ import annotations
 
 import ctypes as C
+import os
 from typing import Dict, List, Optional
 
 import numpy as np
@@ -283,20 +284,53 @@ class TrainEngine:
         return dx
 
     def _lstm_bwd(self, c, prefix, hidden, NT, sv, Tw, t_out0, dh_top, nt_x, drop_id, dx_tile=None, dx_rows=None, dx_f=0):
+        """BPTT of one memory stack -> dgates (NI, NL, 16*NT, 64).  Two layers run as four launches: the
+        recurrence of layer 1, d h_0 = W_ih(1)^T . dgates(1) for every step at once, the recurrence of
+        layer 0, dx = W_ih(0)^T . dgates(0) for every step at once -- only the W_hh^T products stay on the
+        time loop (VSV_BWD_FUSED=1: the single two-layer launch)."""
         NL = self.NL
         blobT = self._blobT(c)
-        a = _lib.VsvLstmBwd()
-        a.drop_p, a.drop_seed, a.drop_id = c.drop_p, c.drop_seed, drop_id
-        a.drop_seed_dev = _ptr(c.drop_seed_dev)
-        a.gru = self.dims.mem_type
-        for l in range(NL):
-            a.wT_hh[l] = self._wT(blobT, f"{prefix}.hh{l}")[0]
-            a.wT_in[l] = self._wT(blobT, f"{prefix}.in{l}")[0]
-        a.nt_x, a.n_rows, a.n_rowtiles, a.T, a.t_out0 = nt_x, c.B, c.rt, Tw, t_out0
-        a.sv_gates, a.sv_c, a.dh_top = sv["gates"].data_ptr(), sv["c"].data_ptr(), dh_top.data_ptr()
         dg = self._e(c.rt * Tw, NL, 16 * NT, 64)
-        a.dgates, a.dx_tile, a.dx_rows, a.dx_f = dg.data_ptr(), _ptr(dx_tile), _ptr(dx_rows), dx_f
-        _lib.check(self.lib.vsv_lstm_backward(C.byref(a), hidden, NL, self._stream()), "vsv_lstm_backward")
+        st = self._stream()
+
+        def rec(l0, layers, dh, t0, ntx):
+            a = _lib.VsvLstmBwd()
+            a.drop_p, a.drop_seed, a.drop_id = c.drop_p, c.drop_seed, drop_id
+            a.drop_seed_dev = _ptr(c.drop_seed_dev)
+            a.gru = self.dims.mem_type
+            for l in range(layers):
+                a.wT_hh[l] = self._wT(blobT, f"{prefix}.hh{l0 + l}")[0]
+                a.wT_in[l] = self._wT(blobT, f"{prefix}.in{l0 + l}")[0]
+            a.nt_x, a.n_rows, a.n_rowtiles, a.T, a.t_out0 = ntx, c.B, c.rt, Tw, t0
+            a.sv_gates, a.sv_c, a.dh_top = sv["gates"].data_ptr(), sv["c"].data_ptr(), _ptr(dh)
+            a.dgates = dg.data_ptr()
+            if ntx > 0:
+                a.dx_tile, a.dx_rows, a.dx_f = _ptr(dx_tile), _ptr(dx_rows), dx_f
+            if layers != NL:
+                a.sv_nl, a.sv_l0 = NL, l0
+            _lib.check(self.lib.vsv_lstm_backward(C.byref(a), hidden, layers, st), "vsv_lstm_backward")
+
+        def off_loop(name, l, out_tile, out_rows, out_f, drop_layer):
+            w, nq, nt = self._wT(blobT, name)
+            g = _lib.VsvTilebGemm()
+            g.wT, g.nqT, g.ntT = w, nq, nt
+            g.g, g.g_stride = dg.data_ptr() + 4 * l * 16 * NT * 64, NL * 16 * NT * 64
+            g.n_rows, g.n_rowtiles, g.T = c.B, c.rt, Tw
+            g.out_tile, g.out_rows, g.out_f = _ptr(out_tile), _ptr(out_rows), out_f
+            if drop_layer is not None and c.drop_p > 0:
+                g.drop_p, g.drop_seed, g.drop_seed_dev = c.drop_p, c.drop_seed, _ptr(c.drop_seed_dev)
+                g.drop_id, g.drop_layer = drop_id, drop_layer
+            _lib.check(self.lib.vsv_tileb_gemm_launch(C.byref(g), st), "vsv_tileb_gemm_launch")
+
+        if NL == 1 or os.environ.get("VSV_BWD_FUSED", "0") == "1":
+            rec(0, NL, dh_top, t_out0, nt_x)
+            return dg
+        rec(1, 1, dh_top, t_out0, 0)
+        dh0 = self._e(c.rt * Tw, 64, 64)
+        off_loop(f"{prefix}.in1", 1, dh0, None, 0, 0)
+        rec(0, 1, dh0, 0, 0)
+        if nt_x > 0:
+            off_loop(f"{prefix}.in0", 0, dx_tile, dx_rows, dx_f, None)
         return dg
 
     def _lstm_wgrads(self, c, gp, secs, sv, dg, Tw, NT, x_tile):

@@ -507,6 +507,11 @@ struct LstmSeqArgs {
     DropArgs drop;
     float* sv_hd;
     int gru;                // memory cell: 0 nn.LSTM, 1 nn.GRU
+    // training, one launch per layer (NL = 1): the saved arrays hold sv_nl layers per instance and this
+    // launch is layer sv_l0 (w[0] / b[0] are that layer's); rec: the gate accumulators start from the
+    // pre-activations b + W_ih . x that lstm_pre_kernel left in sv_gates for every step, and only the
+    // recurrent product stays on the time loop
+    int rec, sv_nl, sv_l0;
 };
 
 // per-thread constants of the decoder input assembly
@@ -712,7 +717,10 @@ lstm_kernel(const LstmSeqArgs a) {
     float* const ha0 = hb0 + (size_t)NL * HPK * 64;               // head activations (HEAD only)
     float* const xs = xs0 + lane;                                 // prologue / epilogue views
     float* const hb = hb0 + lane;
-    const bool dropping = SAVE && NL > 1 && a.drop.p > 0.0f;      // wave-uniform; the dropped h lives at ha0
+    const int SL = (SAVE && a.sv_nl > 0) ? a.sv_nl : NL;          // layers per instance in the saved arrays
+    const int L0 = (SAVE && a.sv_nl > 0) ? a.sv_l0 : 0;           // the model's layer that is l = 0 here
+    const bool rec = SAVE && a.rec != 0;                          // wave-uniform
+    const bool dropping = SAVE && SL > 1 && a.drop.p > 0.0f;      // wave-uniform; the dropped h lives at ha0
     const DropArgs drop = (SAVE && dropping) ? resolve_drop(a.drop) : a.drop;
 
     // gate tiles of this wave; out-of-range ones are computed on a clamped tile and never stored
@@ -755,7 +763,15 @@ lstm_kernel(const LstmSeqArgs a) {
     // after the previous layer's cell has consumed the accumulators -- so the barriers hide them.
     f32x16 acc[OWN];
     float4 a0[OWN];                                               // quad 0 of the next gate GEMM (OWN == 4)
-    auto acc_init = [&](int l, bool shared, int lv) {
+    auto acc_init = [&](int l, bool shared, int lv, int t) {
+        if (SAVE && rec) {
+            const float* p = a.sv_gates + ((size_t)(rowtile * a.T + t) * SL + L0 + l) * (16 * NT) * 64 + lv;
+#pragma unroll
+            for (int i = 0; i < OWN; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][r] = p[((toff[i] >> 2) + r) * 64];
+            return;
+        }
         const int hh = lv >> 5;
         const float* p0 = shared ? gate_in + (size_t)l * NT * 32 : a.b[l];
 #pragma unroll
@@ -770,7 +786,7 @@ lstm_kernel(const LstmSeqArgs a) {
     };
     const bool shared0 = (XMODE == 1) && a.din.gate_in != nullptr;      // wave-uniform
     VSV_STAMP(16);
-    acc_init(0, shared0, lane);
+    acc_init(0, shared0, lane, 0);
     if (OWN == 4) wload<OWN>(a0, (const float4*)a.w[0], wo, 0u);
 
     // state: (h | c) per layer, each HP floats in lane order (position 8*tile + 4*hh + jj holds unit
@@ -889,7 +905,7 @@ lstm_kernel(const LstmSeqArgs a) {
                 const float* bin;
                 if (l == 0) bin = (XMODE == 0) ? a.x_tileb + ((size_t)(rowtile * a.T + t) * kx) * 64 + lv : xs;
                 else bin = (SAVE && dropping) ? ha0 + lv : hb + (size_t)(l - 1) * HPK * 64;
-                gemm_seg<OWN>(acc, w, lv, toff, NT * 64, bin, nq_in);
+                if (!(SAVE && rec)) gemm_seg<OWN>(acc, w, lv, toff, NT * 64, bin, nq_in);
                 if (!shared) gemm_seg<OWN>(acc, w + (size_t)nq_in * NT * 64, lv, toff, NT * 64, hl, NT);
             }
             if constexpr (HEAD) {
@@ -899,7 +915,7 @@ lstm_kernel(const LstmSeqArgs a) {
             lstm_cell<SAVE, OWN>(acc, c[l], hn, a.gru != 0);
             VSV_STAMP(3 + 3 * l);
             if (SAVE) {
-                const size_t il = (size_t)(rowtile * a.T + t) * NL + l;
+                const size_t il = (size_t)(rowtile * a.T + t) * SL + L0 + l;
                 float* sg = a.sv_gates + il * (16 * NT) * 64 + lane;
                 float* sc = a.sv_c + il * HPK * 64 + lane;
                 float* sh = a.sv_h + il * HPK * 64 + lane;
@@ -917,11 +933,11 @@ lstm_kernel(const LstmSeqArgs a) {
                 }
             }
             float hd[OWN][4];
-            if (SAVE && l + 1 < NL && dropping) {
+            if (SAVE && L0 + l + 1 < SL && dropping) {
 #pragma unroll
                 for (int i = 0; i < OWN; ++i) {
                     float fct[4];
-                    dropout_factors(drop, row32, (uint32_t)t, toff[i] >> 6, hh, l, fct);
+                    dropout_factors(drop, row32, (uint32_t)t, toff[i] >> 6, hh, L0 + l, fct);
 #pragma unroll
                     for (int jj = 0; jj < 4; ++jj) hd[i][jj] = hn[i][jj] * fct[jj];
                     if (tval[i]) {
@@ -932,8 +948,8 @@ lstm_kernel(const LstmSeqArgs a) {
                 }
             }
             // the accumulators are free: start the next stage's initial values
-            if (l + 1 < NL) acc_init(l + 1, shared, opaque<OWN == 4>(lane));
-            else if (!head_now && t + 1 < a.T) acc_init(0, false, opaque<OWN == 4>(lane));
+            if (l + 1 < NL) acc_init(l + 1, shared, opaque<OWN == 4>(lane), t);
+            else if (!head_now && t + 1 < a.T) acc_init(0, false, opaque<OWN == 4>(lane), t + 1);
             // h of this layer is overwritten only after every wave has read the old one (a shared first
             // step has no recurrent product, so nobody reads it)
             if (!shared) __syncthreads();
@@ -978,7 +994,7 @@ lstm_kernel(const LstmSeqArgs a) {
                 fused_head<NT>(a, wq, bq, hb0 + (size_t)(NL - 1) * HPK * 64, ha0, lane, wave, rowtile, t - a.t_out0);
                 if (t + 1 < a.T) {
                     const int ln = opaque<OWN == 4>(lane);
-                    acc_init(0, false, ln);
+                    acc_init(0, false, ln, t + 1);
                     if (OWN == 4) {
                         unsigned wn[OWN];
 #pragma unroll
@@ -1597,6 +1613,41 @@ static int launch_lstm(const LstmSeqArgs& a, int NT, int NL, bool head, hipStrea
     }
 }
 
+// Gate pre-activations b + W_ih . x of one layer for every (row tile, t) instance at once (training):
+// the half of the gate products that does not depend on the recurrence, taken off the time loop and
+// spread over as many CUs as there are instances.  One workgroup per instance, one wave per gate tile;
+// the result lands in the layer's slots of sv_gates, where the recurrent launch (rec) picks it up and
+// later overwrites it with the activated gates.
+template <int NT>
+__global__ void __launch_bounds__(64 * NT) lstm_pre_kernel(const float* w, const float* b, int nq_in, const float* x,
+                                                           long x_stride, float* gates, long g_stride) {
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const size_t inst = blockIdx.x;
+    const int toff1[1] = {wave * 64};
+    f32x16 acc[1];
+    load_bias<1>(acc, b, toff1, lane >> 5);
+    gemm_seg<1>(acc, (const float4*)w, lane, toff1, NT * 64, x + inst * (size_t)x_stride + lane, nq_in);
+    float* o = gates + inst * (size_t)g_stride + (size_t)(16 * wave) * 64 + lane;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) o[r * 64] = acc[0][r];
+}
+
+static int launch_lstm_pre(int NT, const float* w, const float* b, int nq_in, const float* x, long x_stride,
+                           float* gates, long g_stride, long insts, hipStream_t st) {
+    if (insts > 0x7fffffffL) { set_error("lstm_pre_kernel: too many instances"); return -2; }
+    if (NT == 13) hipLaunchKernelGGL(lstm_pre_kernel<13>, dim3((unsigned)insts), dim3(64 * 13), 0, st, w, b, nq_in, x, x_stride, gates, g_stride);
+    else if (NT == 16) hipLaunchKernelGGL(lstm_pre_kernel<16>, dim3((unsigned)insts), dim3(64 * 16), 0, st, w, b, nq_in, x, x_stride, gates, g_stride);
+    else { set_error("unsupported LSTM hidden size: %d tiles of 8 units", NT); return -4; }
+    return launch_check("lstm_pre_kernel");
+}
+
+// two-layer training forward as one launch per layer (few row tiles: the one-wave-per-gate-tile schedule);
+// VSV_FWD_FUSED=1 keeps the single two-layer launch
+static bool per_layer_forward(int NL, long rowtiles) {
+    static const bool fused = [] { const char* e = getenv("VSV_FWD_FUSED"); return e && e[0] == '1'; }();
+    return NL == 2 && rowtiles <= kWideMaxRowtiles && !fused;
+}
+
 static thread_local hipEvent_t g_prof_ev[2] = {nullptr, nullptr};
 
 static int fill_dropout(LstmSeqArgs& l, const vsv_train_save* sv, int NL, const char* who) {
@@ -1904,7 +1955,24 @@ extern "C" int vsv_train_encode(const vsv_dims* dims, const float* packed, int w
     l.hout = sv->hout; l.t_out0 = 0;
     l.sv_gates = sv->gates; l.sv_c = sv->c; l.sv_h = sv->h;
     if (int rcd = fill_dropout(l, sv, lay.NL, "vsv_train_encode")) return rcd;
-    rc = launch_lstm<0>(l, lay.NTm, lay.NL, false, st);
+    if (per_layer_forward(lay.NL, rt)) {
+        const int NT = lay.NTm;
+        const long gs = (long)lay.NL * 16 * NT * 64, hs = (long)lay.NL * 4 * NT * 64;
+        for (int L = 0; L < 2 && !rc; ++L) {
+            const float* x = (L == 0) ? sv->xe : (l.sv_hd ? l.sv_hd : sv->h);
+            const long xs = (L == 0) ? (long)e.kx * 64 : (l.sv_hd ? (long)4 * NT * 64 : hs);
+            const int nq_in = (L == 0) ? e.kx >> 2 : NT;
+            rc = launch_lstm_pre(NT, l.w[L], l.b[L], nq_in, x, xs, sv->gates + (size_t)L * 16 * NT * 64, gs, rt * T, st);
+            if (rc) return rc;
+            LstmSeqArgs r = l;
+            r.w[0] = l.w[L]; r.b[0] = l.b[L]; r.kx = 4 * nq_in;
+            r.rec = 1; r.sv_nl = 2; r.sv_l0 = L;
+            r.hout = (L == 1) ? sv->hout : nullptr;
+            rc = launch_lstm<0>(r, NT, 1, false, st);
+        }
+    } else {
+        rc = launch_lstm<0>(l, lay.NTm, lay.NL, false, st);
+    }
     if (rc) return rc;
 
     DenseChainArgs h = {};
@@ -1945,7 +2013,27 @@ extern "C" int vsv_train_decode(const vsv_dims* dims, const float* packed, const
     l.hout = sv->hout; l.t_out0 = t_out0;
     l.sv_gates = sv->gates; l.sv_c = sv->c; l.sv_h = sv->h; l.sv_x = sv->xe;
     if (int rcd = fill_dropout(l, sv, lay.NL, "vsv_train_decode")) return rcd;
-    int rc = launch_lstm<1>(l, lay.NTd, lay.NL, false, st);
+    int rc;
+    if (per_layer_forward(lay.NL, rt)) {
+        // layer 0 keeps its (narrow) input product: the latent draw is assembled inside the kernel
+        const int NT = lay.NTd;
+        LstmSeqArgs r0 = l;
+        r0.sv_nl = 2; r0.sv_l0 = 0; r0.hout = nullptr;
+        rc = launch_lstm<1>(r0, NT, 1, false, st);
+        if (rc) return rc;
+        const float* x = l.sv_hd ? l.sv_hd : sv->h;
+        const long xs = l.sv_hd ? (long)4 * NT * 64 : (long)lay.NL * 4 * NT * 64;
+        rc = launch_lstm_pre(NT, l.w[1], l.b[1], NT, x, xs, sv->gates + (size_t)16 * NT * 64, (long)lay.NL * 16 * NT * 64,
+                             rt * T, st);
+        if (rc) return rc;
+        LstmSeqArgs r1 = l;
+        r1.w[0] = l.w[1]; r1.b[0] = l.b[1]; r1.kx = 4 * NT;
+        r1.rec = 1; r1.sv_nl = 2; r1.sv_l0 = 1;
+        r1.z_out = nullptr; r1.sv_x = nullptr;
+        rc = launch_lstm<0>(r1, NT, 1, false, st);
+    } else {
+        rc = launch_lstm<1>(l, lay.NTd, lay.NL, false, st);
+    }
     if (rc) return rc;
 
     DenseChainArgs a = {};

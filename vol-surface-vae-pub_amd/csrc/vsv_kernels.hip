@@ -1095,6 +1095,7 @@ __global__ void __launch_bounds__(256, 2) dense_bwd_kernel(const DenseBwdArgs a)
         }
     } else {
         const float* src = a.in + (size_t)inst * kDenseSlots * 64 + lane;
+#pragma unroll 16
         for (int s = 0; s < kDenseSlots; ++s) col[s * 64] = row_ok ? src[s * 64] : 0.0f;
     }
 #pragma unroll 1
@@ -1103,13 +1104,23 @@ __global__ void __launch_bounds__(256, 2) dense_bwd_kernel(const DenseBwdArgs a)
         const float* act = ly.act_out ? ly.act_out + (size_t)inst * kDenseSlots * 64 + lane : nullptr;
         const float* add = (ly.add && row_ok) ? ly.add + ((size_t)row * a.T + t) * ly.add_n - ly.add_f0 : nullptr;
         float* go = ly.g_out ? ly.g_out + (size_t)inst * kDenseSlots * 64 + lane : nullptr;
-        for (int s = 0; s < kDenseSlots; ++s) {
-            const int f = feat_of(s >> 4, s & 15, hh);
-            float g = col[s * 64];
-            if (add && f >= ly.add_f0 && f < ly.add_f0 + ly.add_n) g += add[f];
-            if (act && f < ly.n_relu && !(act[s * 64] > 0.0f)) g = 0.0f;
-            col[s * 64] = g;
-            if (go) go[s * 64] = g;
+        // 16 slots at a time with the global loads of the group issued together: one at a time, each
+        // iteration waited a full memory latency (25 us per layer at two instances)
+#pragma unroll 1
+        for (int s0 = 0; s0 < kDenseSlots; s0 += 16) {
+            float av[16];
+#pragma unroll
+            for (int k = 0; k < 16; ++k) av[k] = act ? act[(s0 + k) * 64] : 1.0f;
+#pragma unroll
+            for (int k = 0; k < 16; ++k) {
+                const int s = s0 + k;
+                const int f = feat_of(s >> 4, s & 15, hh);
+                float g = col[s * 64];
+                if (add && f >= ly.add_f0 && f < ly.add_f0 + ly.add_n) g += add[f];
+                if (act && f < ly.n_relu && !(av[k] > 0.0f)) g = 0.0f;
+                col[s * 64] = g;
+                if (go) go[s * 64] = g;
+            }
         }
         switch (ly.ntT) {
             case 0: break;
@@ -1121,6 +1132,7 @@ __global__ void __launch_bounds__(256, 2) dense_bwd_kernel(const DenseBwdArgs a)
     }
     if (a.dx_out) {
         float* o = a.dx_out + (size_t)inst * kDenseSlots * 64 + lane;
+#pragma unroll 16
         for (int s = 0; s < kDenseSlots; ++s) o[s * 64] = col[s * 64];
     }
 }
@@ -1165,6 +1177,27 @@ __global__ void __launch_bounds__(256, 1) lstm_bwd_kernel(const LstmBwdArgs a) {
 #pragma unroll
         for (int l = NL - 1; l >= 0; --l) {
             f32x16 acc[1];
+            // saved gates and cell states of this step: issued before the matrix products so that they
+            // land while those run (nothing here depends on the products)
+            float gsv[16][4], cnv[16], cpv[16];
+            {
+                const float* sg = a.sv_gates + (inst * SL + L0 + l) * GK * 64 + lane;
+                const float* sc = a.sv_c + (inst * SL + L0 + l) * (4 * NT) * 64 + lane;
+                const float* scp = (t > 0) ? a.sv_c + ((inst - 1) * SL + L0 + l) * (4 * NT) * 64 + lane : nullptr;
+#pragma unroll
+                for (int jq = 0; jq < 4; ++jq) {
+                    const int tg = 4 * jq + wave;
+                    const int tc = tg < NT ? tg : NT - 1;              // clamped: out-of-range tiles are never used
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int reg = 4 * jq + r, gs = 16 * tc + 4 * r, cs = 4 * tc + r;
+#pragma unroll
+                        for (int g = 0; g < 4; ++g) gsv[reg][g] = sg[(gs + g) * 64];
+                        cnv[reg] = sc[cs * 64];
+                        cpv[reg] = scp ? scp[cs * 64] : 0.0f;
+                    }
+                }
+            }
             if (l == NL - 1) {
                 if (t >= a.t_out0 && a.dh_top) {
                     const float* p = a.dh_top + ((size_t)(rowtile * t_outs + (t - a.t_out0)) * 64 + 16 * wave) * 64 + lane;
@@ -1197,9 +1230,6 @@ __global__ void __launch_bounds__(256, 1) lstm_bwd_kernel(const LstmBwdArgs a) {
                 gemm_seg<1>(acc, (const float4*)a.wT_hh[l], lane, toff1, 4 * 64, dg + (size_t)l * GK * 64, 4 * NT);
             // cell backward for the 16 units of this lane
             float dgv[16][4];
-            const float* sg = a.sv_gates + (inst * SL + L0 + l) * GK * 64 + lane;
-            const float* sc = a.sv_c + (inst * SL + L0 + l) * (4 * NT) * 64 + lane;
-            const float* scp = (t > 0) ? a.sv_c + ((inst - 1) * SL + L0 + l) * (4 * NT) * 64 + lane : nullptr;
 #pragma unroll
             for (int jq = 0; jq < 4; ++jq) {
                 const int tg = 4 * jq + wave;
@@ -1209,9 +1239,8 @@ __global__ void __launch_bounds__(256, 1) lstm_bwd_kernel(const LstmBwdArgs a) {
                     float di = 0.0f, df = 0.0f, dgg = 0.0f, dog = 0.0f;
                     if (tg < NT && a.gru) {
                         // nn.GRU: saved slots (r, z, n, n_h); sv_c holds h.  dc carries dh' * z, the direct path
-                        const int gs = 16 * tg + 4 * r, cs = 4 * tg + r;
-                        const float rg = sg[(gs + 0) * 64], zg = sg[(gs + 1) * 64], ng = sg[(gs + 2) * 64], nh = sg[(gs + 3) * 64];
-                        const float hp = scp ? scp[cs * 64] : 0.0f;
+                        const float rg = gsv[reg][0], zg = gsv[reg][1], ng = gsv[reg][2], nh = gsv[reg][3];
+                        const float hp = cpv[reg];
                         const float dh = acc[0][reg] + dc[l][reg];
                         const float dnp = dh * (1.0f - zg) * (1.0f - ng * ng);
                         di = dnp * nh * rg * (1.0f - rg);                       // d r_pre
@@ -1220,10 +1249,9 @@ __global__ void __launch_bounds__(256, 1) lstm_bwd_kernel(const LstmBwdArgs a) {
                         dog = dnp * rg;                                         // d n_h
                         dc[l][reg] = dh * zg;
                     } else if (tg < NT) {
-                        const int gs = 16 * tg + 4 * r, cs = 4 * tg + r;
-                        const float ig = sg[(gs + 0) * 64], fg = sg[(gs + 1) * 64], gg = sg[(gs + 2) * 64], og = sg[(gs + 3) * 64];
-                        const float cn = sc[cs * 64];
-                        const float cp = scp ? scp[cs * 64] : 0.0f;
+                        const float ig = gsv[reg][0], fg = gsv[reg][1], gg = gsv[reg][2], og = gsv[reg][3];
+                        const float cn = cnv[reg];
+                        const float cp = cpv[reg];
                         const float th = fast_tanh(cn);
                         const float dh = acc[0][reg];
                         const float dct = dc[l][reg] + dh * og * (1.0f - th * th);

@@ -274,7 +274,19 @@ class CVAEMemRand(BaseVAE):
         return self.encoder.z_mean_layer.weight.dtype
 
     def _hip_named_params(self):
-        return [(n, p) for n, p in self.named_parameters()]
+        # walking the module tree costs ~0.1 ms and a train step asks three times: keep the list (module
+        # conversions go through _apply, which drops it; Parameter objects are otherwise never replaced)
+        cached = self.__dict__.get("_vsv_named_params")
+        if cached is None:
+            cached = [(n, p) for n, p in self.named_parameters()]
+            self.__dict__["_vsv_named_params"] = cached
+        return cached
+
+    def _apply(self, fn, recurse=True):
+        self.__dict__.pop("_vsv_named_params", None)
+        out = super()._apply(fn, recurse)
+        self.__dict__.pop("_vsv_named_params", None)
+        return out
 
     def _engine(self, pack: bool = True):
         """The kernel engine with weights packed from the CURRENT parameters

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define VSV_ABI_VERSION 9
+#define VSV_ABI_VERSION 10
 #define VSV_MAX_CONV 4
 #define VSV_MAX_CHAIN 8
 #define VSV_MAX_INTERACT 3
@@ -111,6 +111,16 @@ int vsv_encode(const vsv_dims *dims, const float *packed, int which,
                const float *ex, long ex_row_stride, long ex_t_stride,
                long n_rows, int T, float *out,
                void *ws, size_t ws_bytes, void *stream);
+
+/* The same encoders over OVERLAPPING windows of one calendar series -- the date-range backfill loops of
+ * generate_surfaces.py:60-102 / eval_scripts/eval_utils.py:42-70, where window r is days [r, r+T) of
+ * vol (n_windows + T - 1, 25) [, ex (n_windows + T - 1, X)], both contiguous.  Results equal
+ * vsv_encode(surf = vol, row stride 25, t stride 25, ...); the conv embedding and the first memory
+ * layer's input product depend only on the calendar day and are computed once per day instead of once
+ * per (window, step).  At most 8192 windows per call (-5 beyond: use vsv_encode). */
+size_t vsv_encode_windows_ws_bytes(const vsv_dims *dims, long n_windows, int T);
+int vsv_encode_windows(const vsv_dims *dims, const float *packed, int which, const float *vol, const float *ex,
+                       long n_windows, int T, float *out, void *ws, size_t ws_bytes, void *stream);
 
 /* ---- decoder ---------------------------------------------------------------
  * CVAEMemRandDecoder.forward (cvae_with_mem_randomized.py:482-514) over T steps

@@ -522,3 +522,21 @@ def test_model_class_training_api():
     m2 = CVAEMemRand(vo.make_config(5, 0, device="cuda:0"))
     l2 = m2.train_step({"surface": x["surface"]}, torch.optim.AdamW(m2.parameters(), lr=1e-4))
     assert l2["re_ex_feats"].shape == (1,) and len(m2.forward({"surface": x["surface"]})) == 4
+
+
+@pytest.mark.parametrize("L,X,N,C,mem", [(12, 3, 70, 9, "lstm"), (5, 0, 33, 4, "lstm"), (5, 3, 101, 20, "gru")])
+def test_windows_encoder_equals_strided_encoder(L, X, N, C, mem):
+    """vsv_encode_windows (embedding and first-layer input product once per calendar day) against
+    vsv_encode reading the same overlapping windows in place: the same products in the same order."""
+    cfg = vo.make_config(L, X, mem_type=mem)
+    eng, _ = _engine(cfg, 31, 2.0)
+    rng = np.random.default_rng(12)
+    vol = _t((0.2 + 0.1 * rng.standard_normal((N + C - 1, 5, 5))).astype(np.float32))
+    ex = _t((0.01 * rng.standard_normal((N + C - 1, X))).astype(np.float32)) if X else None
+    for which in (0, 1):
+        a = eng.encode_windows(which, vol, ex, N, C)
+        b = eng.encode_strided(which, vol, 25, 25, ex, X, X, N, C)
+        assert a.shape == b.shape and float((a - b).abs().max()) <= 1e-6
+    e2, c2 = eng.encode_both_windows(vol, ex, N - 3, C, C - 2)
+    assert e2.shape == (N - 3, C, 2 * L) and c2.shape == (N - 3, C - 2, L)
+    assert float((c2 - eng.encode_strided(1, vol, 25, 25, ex, X, X, N - 3, C - 2)).abs().max()) <= 1e-6

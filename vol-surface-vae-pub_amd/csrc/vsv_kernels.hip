@@ -512,6 +512,12 @@ struct LstmSeqArgs {
     // pre-activations b + W_ih . x that lstm_pre_kernel left in sv_gates for every step, and only the
     // recurrent product stays on the time loop
     int rec, sv_nl, sv_l0;
+    // XMODE 0, inference over overlapping windows (row r, step t <-> calendar day r + t): layer 0's gate
+    // pre-activations b + W_ih . x per CALENDAR DAY, transposed ([32*NT gate values][pre_stride days], gate
+    // value j = 2*(16*tile + register) + lane half), computed once per day instead of once per
+    // (window, step); layer 0 starts from them and skips its input product
+    const float* pre_t;
+    long pre_stride;
 };
 
 // per-thread constants of the decoder input assembly
@@ -764,6 +770,14 @@ lstm_kernel(const LstmSeqArgs a) {
     f32x16 acc[OWN];
     float4 a0[OWN];                                               // quad 0 of the next gate GEMM (OWN == 4)
     auto acc_init = [&](int l, bool shared, int lv, int t) {
+        if (XMODE == 0 && !SAVE && l == 0 && a.pre_t) {
+            const float* p = a.pre_t + (size_t)(lv >> 5) * a.pre_stride + row32 + t;
+#pragma unroll
+            for (int i = 0; i < OWN; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][r] = p[(size_t)(2 * ((toff[i] >> 2) + r)) * a.pre_stride];
+            return;
+        }
         if (SAVE && rec) {
             const float* p = a.sv_gates + ((size_t)(rowtile * a.T + t) * SL + L0 + l) * (16 * NT) * 64 + lv;
 #pragma unroll
@@ -905,7 +919,8 @@ lstm_kernel(const LstmSeqArgs a) {
                 const float* bin;
                 if (l == 0) bin = (XMODE == 0) ? a.x_tileb + ((size_t)(rowtile * a.T + t) * kx) * 64 + lv : xs;
                 else bin = (SAVE && dropping) ? ha0 + lv : hb + (size_t)(l - 1) * HPK * 64;
-                if (!(SAVE && rec)) gemm_seg<OWN>(acc, w, lv, toff, NT * 64, bin, nq_in);
+                if (!(SAVE && rec) && !(XMODE == 0 && !SAVE && l == 0 && a.pre_t))
+                    gemm_seg<OWN>(acc, w, lv, toff, NT * 64, bin, nq_in);
                 if (!shared) gemm_seg<OWN>(acc, w + (size_t)nq_in * NT * 64, lv, toff, NT * 64, hl, NT);
             }
             if constexpr (HEAD) {
@@ -1669,6 +1684,22 @@ static int launch_lstm_pre(int NT, const float* w, const float* b, int nq_in, co
     return launch_check("lstm_pre_kernel");
 }
 
+// Layer-0 gate pre-activations per calendar day, transposed for the windows encoder (LstmSeqArgs::pre_t):
+// one workgroup per tile of 32 days, one wave per gate tile.
+template <int NT>
+__global__ void __launch_bounds__(64 * NT) lstm_pre_t_kernel(const float* w, const float* b, int nq_in, const float* x,
+                                                             float* pre_t, long pre_stride) {
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const size_t ct = blockIdx.x;
+    const int toff1[1] = {wave * 64};
+    f32x16 acc[1];
+    load_bias<1>(acc, b, toff1, lane >> 5);
+    gemm_seg<1>(acc, (const float4*)w, lane, toff1, NT * 64, x + ct * (size_t)(4 * nq_in) * 64 + lane, nq_in);
+    float* o = pre_t + (size_t)(lane >> 5) * pre_stride + ct * 32 + (lane & 31);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) o[(size_t)(2 * (16 * wave + r)) * pre_stride] = acc[0][r];
+}
+
 // two-layer training forward as one launch per layer (few row tiles: the one-wave-per-gate-tile schedule);
 // VSV_FWD_FUSED=1 keeps the single two-layer launch
 static bool per_layer_forward(int NL, long rowtiles) {
@@ -1719,6 +1750,80 @@ extern "C" size_t vsv_encode_ws_bytes(const vsv_dims* dims, long n_rows, int T) 
     const long rt = (n_rows + 31) / 32;
     const int kx = lay.enc[0].kx > lay.enc[1].kx ? lay.enc[0].kx : lay.enc[1].kx;
     return align256((size_t)rt * T * kx * 64 * sizeof(float)) + align256((size_t)rt * T * 4 * lay.NTm * 64 * sizeof(float)) + 256;
+}
+
+// ---- overlapping windows: everything that depends only on the calendar day is computed once per day ----
+extern "C" size_t vsv_encode_windows_ws_bytes(const vsv_dims* dims, long n_windows, int T) {
+    Layout lay;
+    const char* msg = nullptr;
+    if (!dims || make_layout(*dims, lay, &msg) != 0 || n_windows < 0 || T < 0) return 0;
+    const long rt = (n_windows + 31) / 32, ct = (n_windows + T - 1 + 31) / 32;
+    const int kx = lay.enc[0].kx > lay.enc[1].kx ? lay.enc[0].kx : lay.enc[1].kx;
+    return align256((size_t)ct * kx * 64 * sizeof(float)) + align256((size_t)32 * lay.NTm * ct * 32 * sizeof(float)) +
+           align256((size_t)rt * T * 4 * lay.NTm * 64 * sizeof(float)) + 256;
+}
+
+extern "C" int vsv_encode_windows(const vsv_dims* dims, const float* packed, int which, const float* vol, const float* ex,
+                                  long n_windows, int T, float* out, void* ws, size_t ws_bytes, void* stream) {
+    VSV_LAYOUT_OR_FAIL("vsv_encode_windows")
+    if (!packed || !vol || !out || !ws) { set_error("vsv_encode_windows: null pointer"); return -1; }
+    if (which < 0 || which > 1) { set_error("vsv_encode_windows: which must be 0 or 1"); return -1; }
+    if (n_windows < 0 || T < 0) { set_error("vsv_encode_windows: negative size"); return -1; }
+    if (lay.X > 0 && !ex) { set_error("vsv_encode_windows: ex_feats_dim > 0 but ex is null"); return -1; }
+    if (n_windows == 0 || T == 0) return 0;
+    const long rt = (n_windows + 31) / 32;
+    if (rt > kWideMaxRowtiles) { set_error("vsv_encode_windows: at most %ld windows per call (use vsv_encode beyond)", kWideMaxRowtiles * 32); return -5; }
+    if (ws_bytes < vsv_encode_windows_ws_bytes(dims, n_windows, T)) { set_error("vsv_encode_windows: workspace too small"); return -1; }
+    hipStream_t st = (hipStream_t)stream;
+    const EncLayout& e = lay.enc[which];
+    const int NT = lay.NTm;
+    const long n_cal = n_windows + T - 1, ct = (n_cal + 31) / 32;
+    float* xe = (float*)(((uintptr_t)ws + 255) & ~(uintptr_t)255);
+    float* pre = (float*)((char*)xe + align256((size_t)ct * e.kx * 64 * sizeof(float)));
+    float* hbuf = (float*)((char*)pre + align256((size_t)32 * NT * ct * 32 * sizeof(float)));
+
+    // 1. conv embedding of every calendar day (T = 1 "sequences")
+    DenseChainArgs a = {};
+    a.n_layers = e.n_chain;
+    for (int i = 0; i < e.n_chain; ++i) fill_dense(a, i, packed, e.conv[i]);
+    a.inj_layer = e.n_conv - 1;
+    a.n_rows = n_cal; a.n_rowtiles = ct; a.T = 1;
+    a.in_mode = 0; a.in = vol; a.in_rs = 25; a.in_ts = 0; a.in_f = 25;
+    a.in_ks = 4 * e.conv[0].nq;
+    if (lay.X > 0) { a.inj = ex; a.inj_rs = lay.X; a.inj_ts = 0; a.inj_f0 = e.ex_f0; a.inj_n = lay.X; }
+    a.out_mode = 0; a.out = xe; a.out_f = e.E; a.S = 1;
+    a.aux_layer = -1;
+    int rc = launch_dense_chain(a, st);
+    if (rc) return rc;
+
+    // 2. layer 0's b + W_ih . x of every calendar day, transposed
+    const float* w0 = packed + e.lstm[0].w_off;
+    const float* b0 = packed + e.lstm[0].b_off;
+    if (NT == 13) hipLaunchKernelGGL(lstm_pre_t_kernel<13>, dim3((unsigned)ct), dim3(64 * 13), 0, st, w0, b0, e.kx >> 2, xe, pre, ct * 32);
+    else if (NT == 16) hipLaunchKernelGGL(lstm_pre_t_kernel<16>, dim3((unsigned)ct), dim3(64 * 16), 0, st, w0, b0, e.kx >> 2, xe, pre, ct * 32);
+    else { set_error("unsupported LSTM hidden size: %d tiles of 8 units", NT); return -4; }
+    rc = launch_check("lstm_pre_t_kernel");
+    if (rc) return rc;
+
+    // 3. LSTM over the windows (row r, step t reads day r + t), top-layer h of every step -> hbuf
+    LstmSeqArgs l = {};
+    l.gru = lay.gru;
+    for (int i = 0; i < lay.NL; ++i) { l.w[i] = packed + e.lstm[i].w_off; l.b[i] = packed + e.lstm[i].b_off; }
+    l.kx = e.kx; l.n_rows = n_windows; l.n_rowtiles = rt; l.T = T;
+    l.pre_t = pre; l.pre_stride = ct * 32; l.L = lay.L;
+    l.hout = hbuf; l.t_out0 = 0;
+    rc = launch_lstm<0>(l, NT, lay.NL, false, st);
+    if (rc) return rc;
+
+    // 4. linear head on every step
+    DenseChainArgs h = {};
+    h.n_layers = 1;
+    fill_dense(h, 0, packed, e.head);
+    h.n_rows = n_windows; h.n_rowtiles = rt; h.T = T;
+    h.in_mode = 1; h.in = hbuf; h.in_ks = 4 * NT;
+    h.out_mode = 1; h.out = out; h.out_f = e.nh; h.S = 1;
+    h.aux_layer = -1;
+    return launch_dense_chain(h, st);
 }
 
 extern "C" int vsv_encode(const vsv_dims* dims, const float* packed, int which,

@@ -215,6 +215,38 @@ class Engine:
         ctx.record_stream(main)
         return enc, ctx
 
+    MAX_WINDOWS = 8192          # vsv_encode_windows: one-wave-per-gate-tile schedule only
+
+    def encode_windows(self, which, vol, ex, n_windows, T) -> torch.Tensor:
+        """Encoder `which` over the overlapping windows vol[r : r + T] (r < n_windows) of a contiguous
+        calendar series vol (>= n_windows + T - 1, 5, 5) [, ex (.., X)]: vsv_encode_windows."""
+        nh = self.L if which else 2 * self.L
+        out = torch.empty((n_windows, T, nh), dtype=torch.float32, device=self.device)
+        ws = self._ws(self.lib.vsv_encode_windows_ws_bytes(C.byref(self.dims), n_windows, T))
+        with torch.cuda.device(self.device):
+            rc = self.lib.vsv_encode_windows(C.byref(self.dims), _ptr(self.packed), which, _ptr(vol), _ptr(ex),
+                                             n_windows, T, _ptr(out), _ptr(ws), ws.numel(), self._stream())
+        _lib.check(rc, "vsv_encode_windows")
+        return out
+
+    def encode_both_windows(self, vol, ex, n_windows, T, T_ctx=None):
+        """Both encoders over overlapping windows (posterior encoder T steps, context encoder T_ctx), on two
+        HIP streams (see encode_both_strided); falls back to the strided entry point beyond MAX_WINDOWS."""
+        T_ctx = T if T_ctx is None else T_ctx
+        if n_windows > self.MAX_WINDOWS:
+            return self.encode_both_strided(vol, 25, 25, ex, self.X, self.X, n_windows, T, T_ctx)
+        main = torch.cuda.current_stream(self.device)
+        if self._side is None:
+            self._side = torch.cuda.Stream(self.device)
+        side = self._side
+        side.wait_stream(main)
+        with torch.cuda.stream(side):
+            ctx = self.encode_windows(1, vol, ex, n_windows, T_ctx)
+        enc = self.encode_windows(0, vol, ex, n_windows, T)
+        main.wait_stream(side)
+        ctx.record_stream(main)
+        return enc, ctx
+
     # -- decoder -----------------------------------------------------------
     def decode(self, n_rows: int, T: int, t_out0: int, *,
                ctx: Optional[torch.Tensor] = None, ctx_div: int = 1,

@@ -88,7 +88,7 @@ def prior_mc_windows(eng: Engine, vol: torch.Tensor, ex: Optional[torch.Tensor],
     w0 = first_day - ctx_len                               # first calendar row of the first window
     sv = vol[w0:]
     se = ex[w0:] if eng.X > 0 else None
-    enc, ctx = eng.encode_both_strided(sv, 25, 25, se, eng.X, eng.X, n_days, ctx_len)
+    enc, ctx = eng.encode_both_windows(sv, se, n_days, ctx_len)
     zm = enc[..., :L].contiguous()
     pre = eng.decode(n_days, ctx_len, ctx_len, ctx=ctx, zb=zm, want_state=True, want_gates=True)
     state, gates = pre["state"], pre["gates"]
@@ -129,7 +129,7 @@ def prior_windows(eng: Engine, vol: torch.Tensor, ex: Optional[torch.Tensor], fi
         day_index0 = first_day
     L, Q, X, S = eng.L, eng.Q, eng.X, n_samples
     w0 = first_day - ctx_len
-    enc, ctx = eng.encode_both_strided(vol[w0:], 25, 25, ex[w0:] if X > 0 else None, X, X, n_days, ctx_len)
+    enc, ctx = eng.encode_both_windows(vol[w0:], ex[w0:] if X > 0 else None, n_days, ctx_len)
     zm = enc[..., :L].contiguous()
     pre = eng.decode(n_days, ctx_len, ctx_len, ctx=ctx, zb=zm, want_state=True, want_gates=S > 1)
     out_s = torch.empty((n_days, S, horizon, Q, 5, 5), dtype=torch.float32, device=eng.device)
@@ -161,7 +161,7 @@ def oracle_windows(eng: Engine, vol: torch.Tensor, ex: Optional[torch.Tensor], f
         day_index0 = first_day
     L, Q, X, S = eng.L, eng.Q, eng.X, n_samples
     w0 = first_day - ctx_len
-    enc, ctx = eng.encode_both_strided(vol[w0:], 25, 25, ex[w0:] if X > 0 else None, X, X, n_days, T, ctx_len)
+    enc, ctx = eng.encode_both_windows(vol[w0:], ex[w0:] if X > 0 else None, n_days, T, ctx_len)
     zm, zl = enc[..., :L].contiguous(), enc[..., L:].contiguous()
     out_s = torch.empty((n_days, S, horizon, Q, 5, 5), dtype=torch.float32, device=eng.device)
     out_e = torch.empty((n_days, S, horizon, X), dtype=torch.float32, device=eng.device) if X > 0 else None
@@ -322,7 +322,7 @@ def oracle_mc_windows(eng: Engine, vol: torch.Tensor, ex: Optional[torch.Tensor]
     w0 = first_day - ctx_len
     sv = vol[w0:]
     se = ex[w0:] if X > 0 else None
-    enc, ctx = eng.encode_both_strided(sv, 25, 25, se, X, X, n_days, T, ctx_len)   # posterior on context + target
+    enc, ctx = eng.encode_both_windows(sv, se, n_days, T, ctx_len)   # posterior on context + target
     zm, zl = enc[..., :L].contiguous(), enc[..., L:].contiguous()
     outs = []
     for d0 in range(0, n_days, chunk_days):

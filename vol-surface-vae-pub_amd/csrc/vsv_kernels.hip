@@ -66,27 +66,32 @@ __device__ __forceinline__ void quad_mfma(f32x16 (&acc)[NC], const float4 (&a)[N
     for (int i = 0; i < NC; ++i) acc[i] = mfma32(a[i].w, b3, acc[i]);
 }
 
-// NC = 1: a quad is only 4 MFMAs (256 cycles), so the weights run four quads ahead.
+// NC = 1: a quad is only 4 MFMAs (256 cycles = 0.1 us), so the weights run VSV_SEG1_DEPTH quads ahead
+// (an L2 hit is 0.5-0.8 us away: four quads ahead left the one-tile-per-wave kernels waiting on it).
+#ifndef VSV_SEG1_DEPTH
+#define VSV_SEG1_DEPTH 8
+#endif
 __device__ __forceinline__ void gemm_seg(f32x16 (&acc)[1], const float4* __restrict__ w, unsigned lane,
                                          const int (&toff)[1], int qstride, const float* b, int nq) {
+    constexpr int D = VSV_SEG1_DEPTH;
     // w is wave-uniform: indexing it with 32-bit offsets keeps the address in SGPRs + one VGPR
     const unsigned o = lane + (unsigned)toff[0];
-    float4 a[4];
+    float4 a[D];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) a[u] = w[o + (unsigned)(((u < nq) ? u : nq - 1) * qstride)];
+    for (int u = 0; u < D; ++u) a[u] = w[o + (unsigned)(((u < nq) ? u : nq - 1) * qstride)];
     int q = 0;
 #pragma unroll 1
-    for (; q + 4 <= nq; q += 4) {
+    for (; q + D <= nq; q += D) {
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
+        for (int u = 0; u < D; ++u) {
             const float4 cur[1] = {a[u]};
-            const int qn = (q + 4 + u < nq) ? q + 4 + u : nq - 1;
+            const int qn = (q + D + u < nq) ? q + D + u : nq - 1;
             a[u] = w[o + (unsigned)(qn * qstride)];
             quad_mfma<1>(acc, cur, b, q + u);
         }
     }
 #pragma unroll
-    for (int u = 0; u < 3; ++u) {
+    for (int u = 0; u < D - 1; ++u) {
         if (q + u < nq) {
             const float4 cur[1] = {a[u]};
             quad_mfma<1>(acc, cur, b, q + u);
@@ -117,6 +122,40 @@ __device__ __forceinline__ void gemm_seg(f32x16 (&acc)[NC], const float4* __rest
         quad_mfma<NC>(acc, a1, b, q + 1);
     }
     if (q < nq) quad_mfma<NC>(acc, a0, b, q);
+}
+
+// gemm_seg with the A fragments requested four quads ahead: for weights that are not cache-warm (the
+// transposed blob of a training step is gathered anew every step) one quad of MFMAs (0.4 us) does not
+// cover a fetch, four do.
+template <int NC>
+__device__ __forceinline__ void gemm_seg_deep(f32x16 (&acc)[NC], const float4* __restrict__ w, unsigned lane,
+                                              const int (&toff)[NC], int qstride, const float* b, int nq) {
+    float4 a[4][NC];
+    unsigned o[NC];
+#pragma unroll
+    for (int i = 0; i < NC; ++i) o[i] = lane + (unsigned)toff[i];
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int i = 0; i < NC; ++i) a[u][i] = w[o[i] + (unsigned)(((u < nq) ? u : nq - 1) * qstride)];
+    int q = 0;
+#pragma unroll 1
+    for (; q + 4 <= nq; q += 4) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            float4 cur[NC];
+#pragma unroll
+            for (int i = 0; i < NC; ++i) cur[i] = a[u][i];
+            const int qn = (q + 4 + u < nq) ? q + 4 + u : nq - 1;
+#pragma unroll
+            for (int i = 0; i < NC; ++i) a[u][i] = w[o[i] + (unsigned)(qn * qstride)];
+            quad_mfma<NC>(acc, cur, b, q + u);
+        }
+    }
+#pragma unroll
+    for (int u = 0; u < 3; ++u) {
+        if (q + u < nq) quad_mfma<NC>(acc, a[u], b, q + u);
+    }
 }
 
 // Pinned software pipeline for the 4-tiles-per-wave schedule: the A fragments (global, L2-resident) and the
@@ -1082,7 +1121,7 @@ __device__ __forceinline__ void dense_bwd_layer(const DenseBwdLayer& ly, float* 
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[i][r] = 0.0f;
     }
-    gemm_seg<NT>(acc, (const float4*)ly.wT, lane, toff, NT * 64, col, ly.nqT);
+    gemm_seg_deep<NT>(acc, (const float4*)ly.wT, lane, toff, NT * 64, col, ly.nqT);
 #pragma unroll
     for (int tt = 0; tt < NT; ++tt)
 #pragma unroll

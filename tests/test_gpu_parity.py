@@ -540,3 +540,25 @@ def test_windows_encoder_equals_strided_encoder(L, X, N, C, mem):
     e2, c2 = eng.encode_both_windows(vol, ex, N - 3, C, C - 2)
     assert e2.shape == (N - 3, C, 2 * L) and c2.shape == (N - 3, C - 2, L)
     assert float((c2 - eng.encode_strided(1, vol, 25, 25, ex, X, X, N - 3, C - 2)).abs().max()) <= 1e-6
+
+
+def test_windows_encoder_edges():
+    """One-step windows, a window count that is not a multiple of the 32-row tile, zero windows, and the
+    fall-back to the strided entry point beyond Engine.MAX_WINDOWS."""
+    import ctypes as C
+    cfg = vo.make_config(5, 3)
+    eng, _ = _engine(cfg, 32, 2.0)
+    rng = np.random.default_rng(13)
+    n_big = eng.MAX_WINDOWS + 5
+    vol = _t((0.2 + 0.1 * rng.standard_normal((n_big + 2, 5, 5))).astype(np.float32))
+    ex = _t((0.01 * rng.standard_normal((n_big + 2, 3))).astype(np.float32))
+    a = eng.encode_windows(0, vol, ex, 45, 1)
+    assert float((a - eng.encode_strided(0, vol, 25, 25, ex, 3, 3, 45, 1)).abs().max()) <= 1e-6
+    assert eng.encode_windows(1, vol, ex, 0, 4).shape == (0, 4, 5)
+    ws = eng._ws(1 << 20)
+    rc = eng.lib.vsv_encode_windows(C.byref(eng.dims), eng.packed.data_ptr(), 0, vol.data_ptr(), ex.data_ptr(),
+                                    n_big, 2, ws.data_ptr(), ws.data_ptr(), ws.numel(), None)
+    assert rc == -5 and b"8192" in eng.lib.vsv_last_error()
+    e1, c1 = eng.encode_both_windows(vol, ex, n_big, 3, 2)               # > MAX_WINDOWS: strided path
+    e2, c2 = eng.encode_both_windows(vol, ex, 64, 3, 2)
+    assert torch.allclose(e1[:64], e2, atol=1e-6) and torch.allclose(c1[:64], c2, atol=1e-6)

@@ -1805,11 +1805,11 @@ extern "C" size_t vsv_encode_windows_ws_bytes(const vsv_dims* dims, long n_windo
 extern "C" int vsv_encode_windows(const vsv_dims* dims, const float* packed, int which, const float* vol, const float* ex,
                                   long n_windows, int T, float* out, void* ws, size_t ws_bytes, void* stream) {
     VSV_LAYOUT_OR_FAIL("vsv_encode_windows")
-    if (!packed || !vol || !out || !ws) { set_error("vsv_encode_windows: null pointer"); return -1; }
     if (which < 0 || which > 1) { set_error("vsv_encode_windows: which must be 0 or 1"); return -1; }
     if (n_windows < 0 || T < 0) { set_error("vsv_encode_windows: negative size"); return -1; }
+    if (n_windows == 0 || T == 0) return 0;                       // nothing to do (empty outputs have no address)
+    if (!packed || !vol || !out || !ws) { set_error("vsv_encode_windows: null pointer"); return -1; }
     if (lay.X > 0 && !ex) { set_error("vsv_encode_windows: ex_feats_dim > 0 but ex is null"); return -1; }
-    if (n_windows == 0 || T == 0) return 0;
     const long rt = (n_windows + 31) / 32;
     if (rt > kWideMaxRowtiles) { set_error("vsv_encode_windows: at most %ld windows per call (use vsv_encode beyond)", kWideMaxRowtiles * 32); return -5; }
     if (ws_bytes < vsv_encode_windows_ws_bytes(dims, n_windows, T)) { set_error("vsv_encode_windows: workspace too small"); return -1; }
@@ -1870,11 +1870,11 @@ extern "C" int vsv_encode(const vsv_dims* dims, const float* packed, int which,
                           const float* ex, long ex_row_stride, long ex_t_stride,
                           long n_rows, int T, float* out, void* ws, size_t ws_bytes, void* stream) {
     VSV_LAYOUT_OR_FAIL("vsv_encode")
-    if (!packed || !surf || !out || !ws) { set_error("vsv_encode: null pointer"); return -1; }
     if (which < 0 || which > 1) { set_error("vsv_encode: which must be 0 or 1"); return -1; }
     if (n_rows < 0 || T < 0) { set_error("vsv_encode: negative size"); return -1; }
+    if (n_rows == 0 || T == 0) return 0;                          // nothing to do (empty outputs have no address)
+    if (!packed || !surf || !out || !ws) { set_error("vsv_encode: null pointer"); return -1; }
     if (lay.X > 0 && !ex) { set_error("vsv_encode: ex_feats_dim > 0 but ex is null"); return -1; }
-    if (n_rows == 0 || T == 0) return 0;
     if (ws_bytes < vsv_encode_ws_bytes(dims, n_rows, T)) { set_error("vsv_encode: workspace too small"); return -1; }
     hipStream_t st = (hipStream_t)stream;
     const EncLayout& e = lay.enc[which];

@@ -596,14 +596,24 @@ class CVAEMemRand(BaseVAE):
         if weight != 1.0:
             grads = torch._foreach_mul(list(grads), weight)
             graphed = False                                  # fresh tensors
+        views = weight == 1.0 and (alias or not graphed)        # every .grad set below is a view of te.last_flat
         for p, g in zip(params, grads):
             g = g.to(p.dtype)
+            views = views and p.grad is None and g.dtype == torch.float32
             if p.grad is None:
                 # eager-path gradients and scaled copies are fresh tensors; graph outputs are copied out
                 # unless aliasing was allowed
                 p.grad = g.clone() if (graphed and not alias and g.dtype == torch.float32) else g
             else:
                 p.grad = p.grad + g
+        return te.last_flat if views else None
+
+    @staticmethod
+    def _clip_flat_(flat: torch.Tensor, max_norm: float) -> None:
+        """clip_grad_norm_ (reference :1129) on gradients that are all views of one flat buffer: the same
+        total 2-norm and coefficient, three launches instead of a foreach pass over 56 tensors."""
+        total = torch.linalg.vector_norm(flat)
+        flat.mul_(torch.clamp(max_norm / (total + 1e-6), max=1.0))
 
     def test_step(self, x):
         """Reference :1265-1308: forward + losses, returns a dict of tensors."""
@@ -616,8 +626,11 @@ class CVAEMemRand(BaseVAE):
         Returns a dict of tensors."""
         optimizer.zero_grad()
         losses, gp = self._loss_terms(x, self.horizon, True)
-        self._accumulate_grads(gp, alias=True)
-        torch.nn.utils.clip_grad_norm_(self.parameters(), max_norm=1.0)
+        flat = self._accumulate_grads(gp, alias=True)
+        if flat is not None:
+            self._clip_flat_(flat, 1.0)
+        else:
+            torch.nn.utils.clip_grad_norm_(self.parameters(), max_norm=1.0)
         optimizer.step()
         return losses
 

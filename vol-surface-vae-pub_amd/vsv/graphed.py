@@ -1,7 +1,7 @@
 """HIP-graph replay of the training step's device work.
 
-One train_step issues ~250 launches (the vsv_* kernels plus the small torch ops that assemble the
-weight gradients); at batch 64 they are short, so issued one by one the step is bound by the host.
+One train_step issues ~80 launches (the vsv_* kernels plus the small torch ops around them; ~250 before the
+weight-gradient kernel); at batch 64 they are short, so issued one by one the step can be bound by the host.
 GraphedLossGrads captures, once per input shape, everything between "parameters + batch" and
 "loss terms + parameter gradients" into one HIP graph (torch.cuda.CUDAGraph: the vsv_* launches go to
 torch's capturing stream like any other kernel, the side stream forks and joins inside the capture)
@@ -46,6 +46,7 @@ class GraphedLossGrads:
         self.graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.graph, capture_error_mode="thread_local"):
             self.loss_vec, self.grads, self.packed = self._body()
+        self.flat = te.last_flat                 # the gradients are views of this static buffer
 
     def _body(self):
         te, eng = self.te, self.eng
@@ -73,6 +74,7 @@ class GraphedLossGrads:
         self.eng.packed = self.packed            # what the blob now holds: the parameters as of this replay
         v = self.loss_vec.clone()
         losses = {"loss": v[0], "re_surface": v[1], "re_ex_feats": v[2], "reconstruction_loss": v[3], "kl_loss": v[4]}
+        self.te.last_flat = self.flat
         return losses, self.grads
 
 

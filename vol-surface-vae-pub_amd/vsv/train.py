@@ -580,6 +580,7 @@ class TrainEngine:
         flat = torch.zeros(n + 1 + self._DUMP, dtype=torch.float32, device=self.dev)
         flat.index_add_(0, self._idx_a, gp)
         flat.index_add_(0, self._idx_b, gp[self._idx_b_pos])
+        self.last_flat = flat[1:1 + n]                           # the returned gradients are views of this
         out, o = [], 1
         for sz, sh in zip(self._sizes, self._shapes):
             out.append(flat[o:o + sz].view(sh))

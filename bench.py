@@ -150,6 +150,25 @@ def train_bench(dev, steps: int, cpu_steps: int):
         out["ms_per_step_hip_graph"] = None
         out["hip_graph_error"] = repr(exc)[:200]
     model.config["hip_graphs"] = False
+    # BASELINE configs[2]: multi-horizon [1, 7, 14, 30] quantile training, context 20 (sequence 50), batch 64:
+    # four forward/backward passes and one optimizer step per call (train_step_multihorizon)
+    try:
+        mh_batch = {"surface": torch.from_numpy((0.2 + 0.1 * rng.standard_normal((B, 50, 5, 5))).astype(np.float32)).to(dev),
+                    "ex_feats": torch.from_numpy((0.01 * rng.standard_normal((B, 50, 3))).astype(np.float32)).to(dev)}
+        for _ in range(2):
+            model.train_step_multihorizon(mh_batch, opt, horizons=[1, 7, 14, 30])
+        torch.cuda.synchronize()
+        n_mh = 10
+        t0 = time.perf_counter()
+        for _ in range(n_mh):
+            model.train_step_multihorizon(mh_batch, opt, horizons=[1, 7, 14, 30])
+        torch.cuda.synchronize()
+        mh_dt = (time.perf_counter() - t0) / n_mh
+        out["multihorizon"] = {"workload": "BASELINE configs[2]: train_step_multihorizon, horizons [1,7,14,30], batch 64, "
+                                           "sequence 50 (context 20 + 30)", "ms_per_step": mh_dt * 1e3,
+                               "samples_per_s": B / mh_dt}
+    except Exception as exc:
+        out["multihorizon"] = {"error": repr(exc)[:200]}
     if cpu_steps > 0:
         from oracle.torch_port import TorchPort
         port = TorchPort(cfg, W, torch.float32)

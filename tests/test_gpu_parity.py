@@ -562,3 +562,20 @@ def test_windows_encoder_edges():
     e1, c1 = eng.encode_both_windows(vol, ex, n_big, 3, 2)               # > MAX_WINDOWS: strided path
     e2, c2 = eng.encode_both_windows(vol, ex, 64, 3, 2)
     assert torch.allclose(e1[:64], e2, atol=1e-6) and torch.allclose(c1[:64], c2, atol=1e-6)
+
+
+def test_fused_two_layer_training_launches_still_match_reference():
+    """Two-layer stacks train through one launch per layer by default; the single two-layer launches
+    (kept for > 8192 rows and behind VSV_FWD_FUSED / VSV_BWD_FUSED) must give the same gradients.  The
+    switches are read once per process, so the golden-gradient tests are re-run in a child process."""
+    import os
+    import subprocess
+    import sys
+    env = dict(os.environ, VSV_FWD_FUSED="1", VSV_BWD_FUSED="1")
+    here = os.path.dirname(os.path.abspath(__file__))
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(here, "test_gpu_parity.py"), "-q", "-x", "-m", "gpu",
+                        "-k", "test_train_losses_and_gradients_vs_reference or test_train_with_lstm_dropout",
+                        "-p", "no:cacheprovider"],
+                       env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-1000:]
+    assert " passed" in r.stdout

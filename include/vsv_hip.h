@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define VSV_ABI_VERSION 10
+#define VSV_ABI_VERSION 11
 #define VSV_MAX_CONV 4
 #define VSV_MAX_CHAIN 8
 #define VSV_MAX_INTERACT 3
@@ -111,6 +111,19 @@ int vsv_encode(const vsv_dims *dims, const float *packed, int which,
                const float *ex, long ex_row_stride, long ex_t_stride,
                long n_rows, int T, float *out,
                void *ws, size_t ws_bytes, void *stream);
+
+/* vsv_encode continuing from / leaving a memory state: state_in (n_rows / state_div states, each
+ * vsv_enc_state_floats floats = layers x (h | c) of mem_hidden padded to a multiple of 8, layout as the
+ * decoder's in vsv_decode_in) or null for the zero state; row r starts from state r / state_div; state_out
+ * (n_rows states) or null.  Used by the autoregressive rollouts (generate_autoregressive_sequence,
+ * :717-807): the leading part of a row's window that is still the day's original context is encoded once
+ * per day and all samples of the day continue from that state. */
+size_t vsv_enc_state_floats(const vsv_dims *dims);
+int vsv_encode_state(const vsv_dims *dims, const float *packed, int which,
+                     const float *surf, long surf_row_stride, long surf_t_stride,
+                     const float *ex, long ex_row_stride, long ex_t_stride,
+                     long n_rows, int T, const float *state_in, long state_div, float *state_out,
+                     float *out, void *ws, size_t ws_bytes, void *stream);
 
 /* The same encoders over OVERLAPPING windows of one calendar series -- the date-range backfill loops of
  * generate_surfaces.py:60-102 / eval_scripts/eval_utils.py:42-70, where window r is days [r, r+T) of

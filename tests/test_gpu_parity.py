@@ -220,6 +220,28 @@ def test_autoregressive_sequence_vs_reference(name):
     assert err(_n(s), g["surf_out"]) <= TOL
     if ex is not None:
         assert err(_n(e), g["ex_out"]) <= TOL
+    # the shared-prefix schedule (encoders / decoder continue from the state after the days that are
+    # still original context) runs the same products in the same order
+    s2, e2 = paths.ar_generate(eng, surf, ex, int(g["horizon"]), 1, eps=eps, share_prefix=True)
+    assert float((s2 - s).abs().max()) <= 1e-6
+    if ex is not None:
+        assert float((e2 - e).abs().max()) <= 1e-6
+
+
+def test_autoregressive_shared_prefix_equals_literal_rollout():
+    """S > 1 (Philox noise): every row re-encoding its whole window against the per-day shared prefix."""
+    from vsv import paths
+    for mem, L, X, D, S, C, H in (("lstm", 12, 3, 3, 40, 6, 9), ("gru", 5, 0, 2, 33, 4, 3)):
+        cfg = vo.make_config(L, X, mem_type=mem)
+        eng, _ = _engine(cfg, 41, 2.0)
+        rng = np.random.default_rng(19)
+        surf = _t((0.2 + 0.1 * rng.standard_normal((D, C, 5, 5))).astype(np.float32))
+        ex = _t((0.01 * rng.standard_normal((D, C, X))).astype(np.float32)) if X else None
+        a_s, a_e = paths.ar_generate(eng, surf, ex, H, S, seed=77, day0=5, share_prefix=False)
+        b_s, b_e = paths.ar_generate(eng, surf, ex, H, S, seed=77, day0=5, share_prefix=True)
+        assert float((a_s - b_s).abs().max()) <= 1e-6
+        if X:
+            assert float((a_e - b_e).abs().max()) <= 1e-6
 
 
 @pytest.mark.parametrize("name", golden_names("g7_"))

@@ -801,6 +801,10 @@ lstm_kernel(const LstmSeqArgs a) {
         di.day = (uint32_t)d.day0 + day_rel;
         state_row = (d.state_div == d.S) ? day_rel : row32 / div32(d.state_div);
         if (d.gate_in) gate_in = d.gate_in + (size_t)state_row * NL * NT * 32;
+    } else if (a.din.state_in) {
+        // encoders continuing from a shared state (autoregressive rollouts: the part of a row's window
+        // that is still the day's original context was run once per day)
+        state_row = a.din.state_div == 1 ? row32 : row32 / div32(a.din.state_div);
     }
 
     // Gate accumulators start from the bias, or (first step from a shared state) from bias + W_hh . h_prev,
@@ -846,7 +850,7 @@ lstm_kernel(const LstmSeqArgs a) {
     // 8*tile + 2*jj + hh), so a lane's four units of a tile are one float4
     float c[NL][OWN][4];
     {
-        const bool has_state = (XMODE == 1) && a.din.state_in != nullptr;  // wave-uniform
+        const bool has_state = a.din.state_in != nullptr;                  // wave-uniform
         const float* st = has_state ? a.din.state_in + (size_t)state_row * NL * 2 * HP : nullptr;
         float4 hv[NL][OWN], cv[NL][OWN];
 #pragma unroll
@@ -1865,10 +1869,35 @@ extern "C" int vsv_encode_windows(const vsv_dims* dims, const float* packed, int
     return launch_dense_chain(h, st);
 }
 
+static int encode_impl(const vsv_dims* dims, const float* packed, int which,
+                       const float* surf, long surf_row_stride, long surf_t_stride,
+                       const float* ex, long ex_row_stride, long ex_t_stride,
+                       long n_rows, int T, const float* state_in, long state_div, float* state_out,
+                       float* out, void* ws, size_t ws_bytes, void* stream);
+
 extern "C" int vsv_encode(const vsv_dims* dims, const float* packed, int which,
                           const float* surf, long surf_row_stride, long surf_t_stride,
                           const float* ex, long ex_row_stride, long ex_t_stride,
                           long n_rows, int T, float* out, void* ws, size_t ws_bytes, void* stream) {
+    return encode_impl(dims, packed, which, surf, surf_row_stride, surf_t_stride, ex, ex_row_stride, ex_t_stride,
+                       n_rows, T, nullptr, 1, nullptr, out, ws, ws_bytes, stream);
+}
+
+extern "C" int vsv_encode_state(const vsv_dims* dims, const float* packed, int which,
+                                const float* surf, long surf_row_stride, long surf_t_stride,
+                                const float* ex, long ex_row_stride, long ex_t_stride,
+                                long n_rows, int T, const float* state_in, long state_div, float* state_out,
+                                float* out, void* ws, size_t ws_bytes, void* stream) {
+    if (state_in && state_div < 1) { set_error("vsv_encode_state: state_div must be >= 1"); return -1; }
+    return encode_impl(dims, packed, which, surf, surf_row_stride, surf_t_stride, ex, ex_row_stride, ex_t_stride,
+                       n_rows, T, state_in, state_div, state_out, out, ws, ws_bytes, stream);
+}
+
+static int encode_impl(const vsv_dims* dims, const float* packed, int which,
+                       const float* surf, long surf_row_stride, long surf_t_stride,
+                       const float* ex, long ex_row_stride, long ex_t_stride,
+                       long n_rows, int T, const float* state_in, long state_div, float* state_out,
+                       float* out, void* ws, size_t ws_bytes, void* stream) {
     VSV_LAYOUT_OR_FAIL("vsv_encode")
     if (which < 0 || which > 1) { set_error("vsv_encode: which must be 0 or 1"); return -1; }
     if (n_rows < 0 || T < 0) { set_error("vsv_encode: negative size"); return -1; }
@@ -1903,6 +1932,8 @@ extern "C" int vsv_encode(const vsv_dims* dims, const float* packed, int which,
     l.kx = e.kx; l.n_rows = n_rows; l.n_rowtiles = rt; l.T = T;
     l.x_tileb = xe; l.L = lay.L;
     l.hout = hbuf; l.t_out0 = 0;
+    l.din.state_in = state_in; l.din.state_div = state_in ? state_div : 1;
+    l.state_out = state_out;
     rc = launch_lstm<0>(l, lay.NTm, lay.NL, false, st);
     if (rc) return rc;
 

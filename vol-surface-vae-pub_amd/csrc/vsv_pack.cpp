@@ -283,6 +283,16 @@ extern "C" size_t vsv_state_floats(const vsv_dims* dims) {
     return (size_t)lay.NL * 2 * 8 * lay.NTd;
 }
 
+extern "C" size_t vsv_enc_state_floats(const vsv_dims* dims) {
+    Layout lay;
+    const char* msg = nullptr;
+    if (!dims || make_layout(*dims, lay, &msg) != 0) {
+        set_error("vsv_enc_state_floats: %s", msg ? msg : "null dims");
+        return 0;
+    }
+    return (size_t)lay.NL * 2 * 8 * lay.NTm;
+}
+
 extern "C" size_t vsv_gate_floats(const vsv_dims* dims) {
     Layout lay;
     const char* msg = nullptr;

@@ -198,6 +198,25 @@ class Engine:
         _lib.check(rc, "vsv_encode")
         return out
 
+    def encode_state(self, which, surf, surf_rs, surf_ts, ex, ex_rs, ex_ts, n_rows, T, state_in=None, state_div=1,
+                     want_state=False):
+        """vsv_encode_state: encoder `which` over T steps starting from state_in[row // state_div] (or the
+        zero state) -> (out (n_rows, T, nh), state (n_rows, enc_state_floats) or None)."""
+        nh = self.L if which else 2 * self.L
+        out = torch.empty((n_rows, T, nh), dtype=torch.float32, device=self.device)
+        st_out = None
+        if want_state:
+            st_out = torch.empty((n_rows, int(self.lib.vsv_enc_state_floats(C.byref(self.dims)))),
+                                 dtype=torch.float32, device=self.device)
+        ws = self._ws(self.lib.vsv_encode_ws_bytes(C.byref(self.dims), n_rows, T))
+        with torch.cuda.device(self.device):
+            rc = self.lib.vsv_encode_state(C.byref(self.dims), _ptr(self.packed), which,
+                                           _ptr(surf), surf_rs, surf_ts, _ptr(ex), ex_rs, ex_ts, n_rows, T,
+                                           _ptr(state_in), state_div, _ptr(st_out),
+                                           _ptr(out), _ptr(ws), ws.numel(), self._stream())
+        _lib.check(rc, "vsv_encode_state")
+        return out, st_out
+
     def encode_both_strided(self, surf, surf_rs, surf_ts, ex, ex_rs, ex_ts, n_rows, T, T_ctx=None):
         """Posterior encoder (which=0, T steps) and context encoder (which=1, T_ctx steps) of the
         same windows on two HIP streams: they are independent and, for a date-range prefix,

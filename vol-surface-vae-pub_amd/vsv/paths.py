@@ -202,38 +202,65 @@ def ar_offset_windows(eng: Engine, vol: torch.Tensor, ex: Optional[torch.Tensor]
 
 
 def ar_generate(eng: Engine, surf_ctx: torch.Tensor, ex_ctx: Optional[torch.Tensor], horizon: int,
-                n_samples: int = 1, eps: Optional[torch.Tensor] = None, seed: int = 0, day0: int = 0):
+                n_samples: int = 1, eps: Optional[torch.Tensor] = None, seed: int = 0, day0: int = 0,
+                share_prefix: Optional[bool] = None):
     """generate_autoregressive_sequence (cvae_with_mem_randomized.py:717-807) for D
     context windows x S samples: every row rolls its OWN window -- each step is a
     one-day prior generation (:776), whose p50 channel (:786/:794) and predicted
     ex-features (:788) slide into the row's context (_update_context, :925-967).
     The windows live in one (rows, C+horizon, 25) ring so a step reads its context
     in place (time stride = one day) and the kernels write the feedback day behind it.
+    share_prefix (default: S > 1): at step k < C the first C-k days of every row's window are still
+    the day's ORIGINAL context, identical for its S samples, so both encoders and the decoder run
+    them once per day and the rows continue from those states over their own k generated days
+    (the same products in the same order: results do not change).
     eps: (D*S, horizon, L) injected future latents, or None -> Philox keyed by
     (seed; sample, day0 + day, step).  Returns (D*S, horizon, Q, 5, 5)[, (D*S, horizon, X)]."""
     D, C = surf_ctx.shape[:2]
     S, R, L, X, Q = n_samples, D * n_samples, eng.L, eng.X, eng.Q
     dev = eng.device
     TT = C + horizon
+    share = (S > 1) if share_prefix is None else bool(share_prefix)
+    ctx0 = surf_ctx.to(dev, torch.float32).reshape(D, C, 25).contiguous()
+    ex0 = ex_ctx.to(dev, torch.float32).reshape(D, C, X).contiguous() if X > 0 else None
     buf = torch.empty((R, TT, 25), dtype=torch.float32, device=dev)
-    buf[:, :C] = surf_ctx.to(dev, torch.float32).reshape(D, 1, C, 25).expand(D, S, C, 25).reshape(R, C, 25)
+    buf[:, :C] = ctx0.reshape(D, 1, C, 25).expand(D, S, C, 25).reshape(R, C, 25)
     exb = None
     if X > 0:
         exb = torch.empty((R, TT, X), dtype=torch.float32, device=dev)
-        exb[:, :C] = ex_ctx.to(dev, torch.float32).reshape(D, 1, C, X).expand(D, S, C, X).reshape(R, C, X)
+        exb[:, :C] = ex0.reshape(D, 1, C, X).expand(D, S, C, X).reshape(R, C, X)
     out_s = torch.empty((R, horizon, Q, 5, 5), dtype=torch.float32, device=dev)
     out_e = torch.empty((R, horizon, X), dtype=torch.float32, device=dev) if X > 0 else None
     if eps is not None:
         eps = eps.to(dev, torch.float32).contiguous()
         assert eps.shape == (R, horizon, L)
     for k in range(horizon):
-        win = buf[:, k:]
-        wex = exb[:, k:] if X > 0 else None
-        enc, ctx = eng.encode_both_strided(win, TT * 25, 25, wex, TT * X, X, R, C)
-        zm = enc[..., :L].contiguous()
-        r = eng.decode(R, C + 1, C, ctx=ctx, zb=zm,
-                       eps=None if eps is None else eps[:, k:k + 1].contiguous(), eps_t0=C,
-                       seed=seed, S=S, day0=day0, step0=k)
+        ek = None if eps is None else eps[:, k:k + 1].contiguous()
+        if share and k < C:
+            ns = C - k                                         # days of the original context still in the window
+            enc_s, st_e = eng.encode_state(0, ctx0[:, k:], C * 25, 25, ex0[:, k:] if X > 0 else None, C * X, X,
+                                           D, ns, want_state=k > 0)
+            ctx_s, st_c = eng.encode_state(1, ctx0[:, k:], C * 25, 25, ex0[:, k:] if X > 0 else None, C * X, X,
+                                           D, ns, want_state=k > 0)
+            pre = eng.decode(D, ns, ns, ctx=ctx_s, zb=enc_s[..., :L].contiguous(), want_state=True, want_gates=k == 0)
+            if k == 0:
+                r = eng.decode(R, 1, 0, state_in=pre["state"], state_div=S, gate_in=pre["gates"],
+                               eps=ek, eps_t0=0, seed=seed, S=S, day0=day0, step0=0)
+            else:
+                gen = buf[:, C:]                               # the rows' own generated days 0..k-1
+                gex = exb[:, C:] if X > 0 else None
+                enc_r, _ = eng.encode_state(0, gen, TT * 25, 25, gex, TT * X, X, R, k, state_in=st_e, state_div=S)
+                ctx_r, _ = eng.encode_state(1, gen, TT * 25, 25, gex, TT * X, X, R, k, state_in=st_c, state_div=S)
+                r = eng.decode(R, k + 1, k, ctx=ctx_r, zb=enc_r[..., :L].contiguous(),
+                               state_in=pre["state"], state_div=S,
+                               eps=ek, eps_t0=k, seed=seed, S=S, day0=day0, step0=k)
+        else:
+            win = buf[:, k:]
+            wex = exb[:, k:] if X > 0 else None
+            enc, ctx = eng.encode_both_strided(win, TT * 25, 25, wex, TT * X, X, R, C)
+            zm = enc[..., :L].contiguous()
+            r = eng.decode(R, C + 1, C, ctx=ctx, zb=zm, eps=ek, eps_t0=C,
+                           seed=seed, S=S, day0=day0, step0=k)
         out_s[:, k] = r["surf"][:, 0]
         buf[:, C + k] = r["surf"][:, 0, 1].reshape(R, 25)
         if X > 0:

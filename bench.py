@@ -231,7 +231,7 @@ def other_workloads(eng, dev, L, X, C, S):
     ea = torch.from_numpy(ea).to(dev) if X else None
     dt = timed(lambda: paths.ar_mc_windows(eng, va, ea, Ca, n, Ca, H, Sa, seed=1, chunk_days=4))
     res.append({"workload": f"c4-shaped autoregressive MC, context {Ca}, latent {L}, ex_feats {X}, {n} days x {Sa} "
-                            f"rollouts x {H} steps (each step re-encodes its own {Ca}-day window)",
+                            f"rollouts x {H} steps (each step re-encodes its {Ca}-day window; the days a day's rollouts still share once per day)",
                 "value": n * Sa * H / dt, "unit": "surfaces/s", "ms": dt * 1e3})
     return res
 

@@ -590,7 +590,9 @@ __device__ __forceinline__ float decoder_input(const LstmSeqArgs& a, const DecIn
         if (d.eps_in)
             eps = di.eps[(size_t)te * L + f];
         else
-            eps = philox_normal_elem((uint32_t)d.seed, (uint32_t)(d.seed >> 32), di.sample, di.day,
+            // (opaque: otherwise the first Philox round's products of the sample index are hoisted out of
+            // the time loop and live in scratch)
+            eps = philox_normal_elem((uint32_t)d.seed, (uint32_t)(d.seed >> 32), (uint32_t)opaque((int)di.sample), di.day,
                                      (uint32_t)(d.step0 + te), f);
         v = base + scale * eps;
     }
@@ -1035,10 +1037,11 @@ lstm_kernel(const LstmSeqArgs a) {
             __syncthreads();
             VSV_STAMP(4 + 3 * l);
         }
-        const float* htop = hb0 + lane + (size_t)(NL - 1) * HPK * 64;
         // ---- outputs
         if (a.hout && t >= a.t_out0) {
-            float* ho = a.hout + ((size_t)(rowtile * t_outs + (t - a.t_out0)) * HPK) * 64 + lane;
+            const int lo = opaque<OWN == 4>(lane);
+            const float* htop = hb0 + lo + (size_t)(NL - 1) * HPK * 64;
+            float* ho = a.hout + ((size_t)(rowtile * t_outs + (t - a.t_out0)) * HPK) * 64 + lo;
 #pragma unroll
             for (int i = 0; i < OWN; ++i) {
                 if (tval[i]) {
@@ -1064,17 +1067,25 @@ lstm_kernel(const LstmSeqArgs a) {
         }
     }
     VSV_STAMP(13);
-    if (a.state_out && row_ok) {
+    // epilogue: per-lane values re-derived from an opaque copy of the lane index (kept alive across the
+    // time loop they sat in scratch: the row, its validity, the LDS view)
+    const int le = opaque<OWN == 4>(lane);
+    const int hhe = le >> 5;
+    const long rowe_raw = rowtile * 32 + (le & 31);
+    const bool rowe_ok = rowe_raw < a.n_rows;
+    const long rowe = rowe_ok ? rowe_raw : a.n_rows - 1;
+    float* const hbe = hb0 + le;
+    if (a.state_out && rowe_ok) {
 #pragma unroll
         for (int l = 0; l < NL; ++l) {
-            float* st = a.state_out + ((size_t)row * NL + l) * 2 * HP;
+            float* st = a.state_out + ((size_t)rowe * NL + l) * 2 * HP;
 #pragma unroll
             for (int i = 0; i < OWN; ++i) {
                 if (tval[i]) {
                     const int s0 = l * HPK + (toff[i] >> 4);
-                    *(float4*)(st + (toff[i] >> 3) + 4 * hh) =
-                        make_float4(hb[(s0 + 0) * 64], hb[(s0 + 1) * 64], hb[(s0 + 2) * 64], hb[(s0 + 3) * 64]);
-                    *(float4*)(st + HP + (toff[i] >> 3) + 4 * hh) = make_float4(c[l][i][0], c[l][i][1], c[l][i][2], c[l][i][3]);
+                    *(float4*)(st + (toff[i] >> 3) + 4 * hhe) =
+                        make_float4(hbe[(s0 + 0) * 64], hbe[(s0 + 1) * 64], hbe[(s0 + 2) * 64], hbe[(s0 + 3) * 64]);
+                    *(float4*)(st + HP + (toff[i] >> 3) + 4 * hhe) = make_float4(c[l][i][0], c[l][i][1], c[l][i][2], c[l][i][3]);
                 }
             }
         }
@@ -1086,14 +1097,14 @@ lstm_kernel(const LstmSeqArgs a) {
         for (int l = 0; l < NL; ++l) {
             f32x16 acc[OWN];
             const int nq_in = (l == 0) ? (kx >> 2) : NT;
-            load_bias<OWN>(acc, a.b[l], toff, hh);
-            gemm_seg<OWN>(acc, (const float4*)a.w[l] + (size_t)nq_in * NT * 64, lane, toff, NT * 64,
-                           hb + (size_t)l * HPK * 64, NT);
-            if (row_ok) {
+            load_bias<OWN>(acc, a.b[l], toff, hhe);
+            gemm_seg<OWN>(acc, (const float4*)a.w[l] + (size_t)nq_in * NT * 64, le, toff, NT * 64,
+                           hbe + (size_t)l * HPK * 64, NT);
+            if (rowe_ok) {
 #pragma unroll
                 for (int i = 0; i < OWN; ++i) {
                     if (tval[i]) {
-                        float4* p = (float4*)(a.din.gate_out + (((size_t)row * NL + l) * NT + (toff[i] >> 6)) * 32 + hh * 16);
+                        float4* p = (float4*)(a.din.gate_out + (((size_t)rowe * NL + l) * NT + (toff[i] >> 6)) * 32 + hhe * 16);
 #pragma unroll
                         for (int v = 0; v < 4; ++v)
                             p[v] = make_float4(acc[i][4 * v + 0], acc[i][4 * v + 1], acc[i][4 * v + 2], acc[i][4 * v + 3]);

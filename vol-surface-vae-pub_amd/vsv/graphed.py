@@ -17,7 +17,7 @@ Clipping and the optimizer stay outside (they belong to the caller's optimizer o
 from __future__ import annotations
 
 from collections import OrderedDict
-from typing import Dict, List, Optional
+from typing import Dict, Optional
 
 import torch
 

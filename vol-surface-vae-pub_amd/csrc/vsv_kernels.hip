@@ -846,7 +846,15 @@ lstm_kernel(const LstmSeqArgs a) {
     const bool shared0 = (XMODE == 1) && a.din.gate_in != nullptr;      // wave-uniform
     VSV_STAMP(16);
     acc_init(0, shared0, lane, 0);
-    if (OWN == 4) wload<OWN>(a0, (const float4*)a.w[0], wo, 0u);
+    // Monte-Carlo first step from a shared state (a prior draw): the context half of [ctx | z] is the zero
+    // padding and what follows z is alignment padding, so of layer 0's input quads only those that hold z
+    // are multiplied (L = 12: quads 1-2 of 4)
+    int qx0 = 0, qxn = kx >> 2;
+    if (XMODE == 1 && !SAVE && OWN == 4 && shared0 && a.din.ctx_T <= 0 && a.din.z_T <= 0 && !a.din.eps_in && !a.z_out) {
+        qx0 = a.L >> 3;
+        qxn = ((2 * a.L + 7) >> 3) - qx0;
+    }
+    if (OWN == 4) wload<OWN>(a0, (const float4*)a.w[0] + (size_t)qx0 * NT * 64, wo, 0u);
 
     // state: (h | c) per layer, each HP floats in lane order (position 8*tile + 4*hh + jj holds unit
     // 8*tile + 2*jj + hh), so a lane's four units of a tile are one float4
@@ -951,9 +959,13 @@ lstm_kernel(const LstmSeqArgs a) {
                     }
                 }
                 if (XMODE == 1 || l > 0) {
-                    const float* bin = (l == 0) ? xs : ((SAVE && dropping) ? ha0 + lv : hb + (size_t)(l - 1) * HPK * 64);
-                    gemm_stream<OWN>(acc, a0, w, wo, NT * 64, nq, [&](int q, float (&bv)[4]) {
-                        const float* bp = (q < nq_in) ? bin + (size_t)(4 * q) * 64 : hl + (size_t)(4 * (q - nq_in)) * 64;
+                    // (a shared Monte-Carlo first step streams only layer 0's input quads that hold z)
+                    const bool zq = XMODE == 1 && l == 0 && shared;
+                    const int q0 = zq ? qx0 : 0, nqs = zq ? qxn : nq, nqi = nq_in - q0;
+                    const float* bin = ((l == 0) ? xs : ((SAVE && dropping) ? ha0 + lv : hb + (size_t)(l - 1) * HPK * 64)) +
+                                       (size_t)(4 * q0) * 64;
+                    gemm_stream<OWN>(acc, a0, w + (size_t)q0 * NT * 64, wo, NT * 64, nqs, [&](int q, float (&bv)[4]) {
+                        const float* bp = (q < nqi) ? bin + (size_t)(4 * q) * 64 : hl + (size_t)(4 * (q - nqi)) * 64;
 #pragma unroll
                         for (int j = 0; j < 4; ++j) bv[j] = bp[j * 64];
                     });

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define VSV_ABI_VERSION 11
+#define VSV_ABI_VERSION 12
 #define VSV_MAX_CONV 4
 #define VSV_MAX_CHAIN 8
 #define VSV_MAX_INTERACT 3
@@ -134,6 +134,12 @@ int vsv_encode_state(const vsv_dims *dims, const float *packed, int which,
 size_t vsv_encode_windows_ws_bytes(const vsv_dims *dims, long n_windows, int T);
 int vsv_encode_windows(const vsv_dims *dims, const float *packed, int which, const float *vol, const float *ex,
                        long n_windows, int T, float *out, void *ws, size_t ws_bytes, void *stream);
+/* ... continuing from / leaving one memory state per window (vsv_enc_state_floats each; null = zero state /
+ * not wanted): a window's T steps can be run in segments (segment starting at step t0: vol + 25*t0,
+ * ex + X*t0), so that the decoder's context prefix of one segment overlaps the encoders' next segment. */
+int vsv_encode_windows_state(const vsv_dims *dims, const float *packed, int which, const float *vol, const float *ex,
+                             long n_windows, int T, const float *state_in, float *state_out,
+                             float *out, void *ws, size_t ws_bytes, void *stream);
 
 /* ---- decoder ---------------------------------------------------------------
  * CVAEMemRandDecoder.forward (cvae_with_mem_randomized.py:482-514) over T steps

@@ -601,3 +601,20 @@ def test_fused_two_layer_training_launches_still_match_reference():
                        env=env, capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-1000:]
     assert " passed" in r.stdout
+
+
+def test_segmented_context_prefix_equals_single_launches():
+    """The date-range prefix cut into time segments (encoders' segment i+1 beside the decoder's segment i,
+    memory states handed on) against one launch per stack: the same steps in the same order."""
+    from vsv import paths
+    for mem, L, X, N, C in (("lstm", 12, 3, 70, 13), ("gru", 5, 0, 40, 9)):
+        cfg = vo.make_config(L, X, mem_type=mem)
+        eng, _ = _engine(cfg, 52, 2.0)
+        rng = np.random.default_rng(23)
+        vol = _t((0.2 + 0.1 * rng.standard_normal((N + C - 1, 5, 5))).astype(np.float32))
+        ex = _t((0.01 * rng.standard_normal((N + C - 1, X))).astype(np.float32)) if X else None
+        s1, g1 = paths._context_prefix(eng, vol, ex, N, C, n_seg=1)
+        for n_seg in (2, 3):
+            s2, g2 = paths._context_prefix(eng, vol, ex, N, C, n_seg=n_seg)
+            torch.cuda.synchronize()
+            assert float((s1 - s2).abs().max()) <= 1e-6 and float((g1 - g2).abs().max()) <= 1e-6, (mem, n_seg)

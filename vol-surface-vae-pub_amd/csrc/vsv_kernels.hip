@@ -1829,8 +1829,24 @@ extern "C" size_t vsv_encode_windows_ws_bytes(const vsv_dims* dims, long n_windo
            align256((size_t)rt * T * 4 * lay.NTm * 64 * sizeof(float)) + 256;
 }
 
+static int encode_windows_impl(const vsv_dims* dims, const float* packed, int which, const float* vol, const float* ex,
+                               long n_windows, int T, const float* state_in, float* state_out, float* out, void* ws,
+                               size_t ws_bytes, void* stream);
+
 extern "C" int vsv_encode_windows(const vsv_dims* dims, const float* packed, int which, const float* vol, const float* ex,
                                   long n_windows, int T, float* out, void* ws, size_t ws_bytes, void* stream) {
+    return encode_windows_impl(dims, packed, which, vol, ex, n_windows, T, nullptr, nullptr, out, ws, ws_bytes, stream);
+}
+
+extern "C" int vsv_encode_windows_state(const vsv_dims* dims, const float* packed, int which, const float* vol,
+                                        const float* ex, long n_windows, int T, const float* state_in, float* state_out,
+                                        float* out, void* ws, size_t ws_bytes, void* stream) {
+    return encode_windows_impl(dims, packed, which, vol, ex, n_windows, T, state_in, state_out, out, ws, ws_bytes, stream);
+}
+
+static int encode_windows_impl(const vsv_dims* dims, const float* packed, int which, const float* vol, const float* ex,
+                               long n_windows, int T, const float* state_in, float* state_out, float* out, void* ws,
+                               size_t ws_bytes, void* stream) {
     VSV_LAYOUT_OR_FAIL("vsv_encode_windows")
     if (which < 0 || which > 1) { set_error("vsv_encode_windows: which must be 0 or 1"); return -1; }
     if (n_windows < 0 || T < 0) { set_error("vsv_encode_windows: negative size"); return -1; }
@@ -1878,6 +1894,8 @@ extern "C" int vsv_encode_windows(const vsv_dims* dims, const float* packed, int
     l.kx = e.kx; l.n_rows = n_windows; l.n_rowtiles = rt; l.T = T;
     l.pre_t = pre; l.pre_stride = ct * 32; l.L = lay.L;
     l.hout = hbuf; l.t_out0 = 0;
+    l.din.state_in = state_in; l.din.state_div = 1;
+    l.state_out = state_out;
     rc = launch_lstm<0>(l, NT, lay.NL, false, st);
     if (rc) return rc;
 

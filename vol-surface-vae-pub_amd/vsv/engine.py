@@ -236,17 +236,23 @@ class Engine:
 
     MAX_WINDOWS = 8192          # vsv_encode_windows: one-wave-per-gate-tile schedule only
 
-    def encode_windows(self, which, vol, ex, n_windows, T) -> torch.Tensor:
+    def encode_windows(self, which, vol, ex, n_windows, T, state_in=None, want_state=False):
         """Encoder `which` over the overlapping windows vol[r : r + T] (r < n_windows) of a contiguous
-        calendar series vol (>= n_windows + T - 1, 5, 5) [, ex (.., X)]: vsv_encode_windows."""
+        calendar series vol (>= n_windows + T - 1, 5, 5) [, ex (.., X)]: vsv_encode_windows(_state).
+        state_in (n_windows, enc_state_floats): continue from it; want_state: -> (out, state)."""
         nh = self.L if which else 2 * self.L
         out = torch.empty((n_windows, T, nh), dtype=torch.float32, device=self.device)
         ws = self._ws(self.lib.vsv_encode_windows_ws_bytes(C.byref(self.dims), n_windows, T))
+        st_out = None
+        if want_state:
+            st_out = torch.empty((n_windows, int(self.lib.vsv_enc_state_floats(C.byref(self.dims)))),
+                                 dtype=torch.float32, device=self.device)
         with torch.cuda.device(self.device):
-            rc = self.lib.vsv_encode_windows(C.byref(self.dims), _ptr(self.packed), which, _ptr(vol), _ptr(ex),
-                                             n_windows, T, _ptr(out), _ptr(ws), ws.numel(), self._stream())
+            rc = self.lib.vsv_encode_windows_state(C.byref(self.dims), _ptr(self.packed), which, _ptr(vol), _ptr(ex),
+                                                   n_windows, T, _ptr(state_in), _ptr(st_out),
+                                                   _ptr(out), _ptr(ws), ws.numel(), self._stream())
         _lib.check(rc, "vsv_encode_windows")
-        return out
+        return (out, st_out) if want_state else out
 
     def encode_both_windows(self, vol, ex, n_windows, T, T_ctx=None):
         """Both encoders over overlapping windows (posterior encoder T steps, context encoder T_ctx), on two

@@ -147,6 +147,9 @@ SIGNATURES = {
                                    C.c_void_p, C.c_long, C.c_long, C.c_void_p, C.c_long, C.c_long,
                                    C.c_long, C.c_int, C.c_void_p, C.c_long, C.c_void_p,
                                    C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "vsv_encode_windows_state": (C.c_int, [C.POINTER(VsvDims), C.c_void_p, C.c_int, C.c_void_p, C.c_void_p,
+                                           C.c_long, C.c_int, C.c_void_p, C.c_void_p,
+                                           C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     "vsv_state_floats": (C.c_size_t, [C.POINTER(VsvDims)]),
     "vsv_gate_floats": (C.c_size_t, [C.POINTER(VsvDims)]),
     "vsv_decode_ws_bytes": (C.c_size_t, [C.POINTER(VsvDims), C.c_long, C.c_int, C.c_int]),
@@ -196,7 +199,7 @@ def load() -> C.CDLL:
             fn = getattr(lib, name)
             fn.restype = res
             fn.argtypes = args
-        if lib.vsv_abi_version() != 11:
+        if lib.vsv_abi_version() != 12:
             raise RuntimeError("libvsv_hip.so ABI version mismatch")
         _lib = lib
     return _lib

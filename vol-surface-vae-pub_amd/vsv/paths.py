@@ -4,6 +4,7 @@ launch plumbing on device tensors; no arithmetic happens on the host.
 """
 from __future__ import annotations
 
+import os
 from typing import Optional, Sequence
 
 import torch
@@ -55,6 +56,60 @@ def prior_generate(eng: Engine, surf_ctx: torch.Tensor, ex_ctx: Optional[torch.T
     return r["surf"], r["ex"], zm
 
 
+def _context_prefix(eng: Engine, sv: torch.Tensor, se: Optional[torch.Tensor], n_days: int, ctx_len: int,
+                    n_seg: Optional[int] = None):
+    """Decoder state after the C context steps of the windows sv[d : d + C] (d < n_days), and the first
+    future step's shared gates: posterior mean and context embedding from the two encoders, then the
+    decoder over (ctx_t, z_mean_t).  The three launches are each bound by one CU per 32-day tile stepping
+    through time, and the decoder's step t needs the encoders' step t only -- so the C steps are cut into
+    n_seg segments and the decoder's segment i runs (third stream) beside the encoders' segment i+1, the
+    memory states handed from segment to segment (VSV_PREFIX_SEGMENTS overrides; 1 = one launch each)."""
+    L = eng.L
+    if n_seg is None:
+        n_seg = int(os.environ.get("VSV_PREFIX_SEGMENTS", "3"))
+    if n_seg <= 1 or n_days > eng.MAX_WINDOWS or ctx_len < 4 * n_seg:
+        enc, ctx = eng.encode_both_windows(sv, se, n_days, ctx_len)
+        zm = enc[..., :L].contiguous()
+        pre = eng.decode(n_days, ctx_len, ctx_len, ctx=ctx, zb=zm, want_state=True, want_gates=True)
+        return pre["state"], pre["gates"]
+    dev = eng.device
+    main = torch.cuda.current_stream(dev)
+    if eng._side is None:
+        eng._side = torch.cuda.Stream(dev)
+    if getattr(eng, "_third", None) is None:
+        eng._third = torch.cuda.Stream(dev)
+    side, third = eng._side, eng._third
+    side.wait_stream(main)
+    third.wait_stream(main)
+    st_e = st_c = st_d = None
+    pre = None
+    for i in range(n_seg):
+        t0, t1 = (i * ctx_len) // n_seg, ((i + 1) * ctx_len) // n_seg
+        last = i == n_seg - 1
+        v, e = sv[t0:], (se[t0:] if se is not None else None)
+        with torch.cuda.stream(side):
+            r = eng.encode_windows(1, v, e, n_days, t1 - t0, state_in=st_c, want_state=not last)
+            ctx_i, st_c = r if not last else (r, None)
+            ev_side = side.record_event()
+        r = eng.encode_windows(0, v, e, n_days, t1 - t0, state_in=st_e, want_state=not last)
+        enc_i, st_e = r if not last else (r, None)
+        zm_i = enc_i[..., :L].contiguous()
+        ev_main = main.record_event()
+        third.wait_event(ev_side)
+        third.wait_event(ev_main)
+        with torch.cuda.stream(third):
+            pre = eng.decode(n_days, t1 - t0, t1 - t0, ctx=ctx_i, zb=zm_i, state_in=st_d, state_div=1,
+                             want_state=True, want_gates=last)
+            st_d = pre["state"]
+        ctx_i.record_stream(third)
+        zm_i.record_stream(third)
+    main.wait_stream(third)
+    main.wait_stream(side)
+    pre["state"].record_stream(main)
+    pre["gates"].record_stream(main)
+    return pre["state"], pre["gates"]
+
+
 def prior_mc_windows(eng: Engine, vol: torch.Tensor, ex: Optional[torch.Tensor], first_day: int, n_days: int,
                      ctx_len: int, horizon: int, n_samples: int, seed: int = 0,
                      qs: Sequence[float] = (5, 50, 95), channel: Optional[int] = 1,
@@ -88,10 +143,7 @@ def prior_mc_windows(eng: Engine, vol: torch.Tensor, ex: Optional[torch.Tensor],
     w0 = first_day - ctx_len                               # first calendar row of the first window
     sv = vol[w0:]
     se = ex[w0:] if eng.X > 0 else None
-    enc, ctx = eng.encode_both_windows(sv, se, n_days, ctx_len)
-    zm = enc[..., :L].contiguous()
-    pre = eng.decode(n_days, ctx_len, ctx_len, ctx=ctx, zb=zm, want_state=True, want_gates=True)
-    state, gates = pre["state"], pre["gates"]
+    state, gates = _context_prefix(eng, sv, se, n_days, ctx_len)
     outs = []
     for d0 in range(0, n_days, chunk_days):
         nd = min(chunk_days, n_days - d0)

@@ -113,7 +113,26 @@ def test_gather_maps_reproduce_host_packing(L, X):
     spec = vo.state_dict_spec(cfg)
     ia, ib = build_gather_maps(dims, spec)
     flat = np.concatenate([[0.0]] + [W[n].ravel() for n, _ in spec]).astype(np.float32)
-    assert np.array_equal(flat[ia] + flat[ib], pack_state_dict(dims, W))
+    got, want = flat[ia] + flat[ib], pack_state_dict(dims, W)
+    # everything but the folded Linear . ConvT section of the decoder head is a gather of parameters ...
+    from vsv.engine import build_fold_maps
+    fm = build_fold_maps(dims)
+    mask = np.ones(want.size, bool)
+    for lo, hi in (fm["fold_w"], fm["fold_b"]):
+        mask[lo:hi] = False
+        assert not got[lo:hi].any()
+    assert np.array_equal(got[mask], want[mask])
+    # ... and that section is the product of two gathered matrices (what set_weights_from_params does on
+    # the device), equal to the host packer's float64 fold up to float32 rounding
+    A, Bm = got[fm["a_w"]].astype(np.float64), got[fm["b_w"]].astype(np.float64)
+    F = A @ Bm
+    bF = A @ got[fm["b_b"]].astype(np.float64) + got[fm["a_b"]]
+    assert np.allclose(F, want[fm["f_w"]], rtol=1e-5, atol=1e-6) and np.allclose(bF, want[fm["f_b"]], rtol=1e-5, atol=1e-6)
+    touched = np.zeros(want.size, bool)
+    touched[fm["f_w"].ravel()] = True
+    touched[fm["f_b"]] = True
+    rest = ~mask & ~touched
+    assert not want[rest].any()                       # what the fold maps do not write is zero padding
 
 
 def test_dataset_and_sampler_match_reference():

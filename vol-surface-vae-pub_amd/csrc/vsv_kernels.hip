@@ -2043,14 +2043,18 @@ extern "C" int vsv_decode(const vsv_dims* dims, const float* packed, const vsv_d
 
     // the decoder head: Linear -> ConvT+ReLU x n -> Conv [, ex Linear x2 riding in spare features]
     DenseChainArgs& a = l.head;
-    a.n_layers = dc.n_head;
-    for (int i = 0; i < dc.n_head; ++i) fill_dense(a, i, packed, dc.head[i]);
+    // (generation runs Linear . first ConvT, which have no activation between them, as the folded layer)
+    a.n_layers = dc.n_head - 1;
+    for (int i = 0; i < a.n_layers; ++i)
+        fill_dense(a, i, packed, i < dc.fold_at ? dc.head[i] : (i == dc.fold_at ? dc.head_fold : dc.head[i + 1]));
     a.n_rows = n_rows; a.n_rowtiles = rt; a.T = touts;
     a.out_mode = out_mode == 0 ? 1 : 2; a.out = surf_out; a.out_f = dc.n_surf; a.S = l.din.S;
-    a.aux_layer = (lay.X > 0 && ex_out) ? dc.ex_layer : -1;
+    a.aux_layer = (lay.X > 0 && ex_out) ? dc.ex_layer - 1 : -1;
     a.aux = ex_out; a.aux_f0 = dc.ex_f0; a.aux_n = lay.X;
 
-    if (a.n_layers < 2 || dc.head[0].nq != lay.NTd) { set_error("vsv_decode: unexpected head layout"); return -4; }
+    if (a.n_layers < 2 || a.layer[0].nq != lay.NTd || dc.ex_layer != (lay.X > 0 ? dc.fold_at + 1 : -1)) {
+        set_error("vsv_decode: unexpected head layout"); return -4;
+    }
     hipEvent_t ev0 = g_prof_ev[0], ev1 = g_prof_ev[1];
     g_prof_ev[0] = g_prof_ev[1] = nullptr;
     if (ev0) (void)hipEventRecord(ev0, st);

@@ -52,6 +52,10 @@ struct DecLayout {
     int kx = 0;                    // k-steps of [ctx | z] in natural order: ceil(2L/2) rounded up to 4
     int n_head = 0;
     Sec head[kMaxDenseLayers];     // [interaction Linears,] Linear, ConvT x n_conv, Conv
+    // inference only: head[fold_at] (Linear) and head[fold_at + 1] (first ConvT [+ ex Linear]) have no
+    // activation between them (reference :495-503), so generation runs their product as ONE layer
+    Sec head_fold;
+    int fold_at = -1;
     int ex_layer = -1;             // head layer whose features [ex_f0, ex_f0+X) are the ex output
     int ex_f0 = 0;
     int n_surf = 0;                // Q*25

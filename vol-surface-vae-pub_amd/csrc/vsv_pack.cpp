@@ -137,6 +137,10 @@ int make_layout(const vsv_dims& d, Layout& lay, const char** msg) {
     dc.head[nh++] = alloc_sec(cur, 4 * kHeadTiles, cdiv(lay.Q * 25, 32), lay.Q * 25, 0);
     dc.n_head = nh;
     dc.n_surf = lay.Q * 25;
+    // the folded Linear . ConvT layer (appended, so every other offset stays where it was)
+    dc.fold_at = lay.NI;
+    dc.head_fold = alloc_sec(cur, dc.head[dc.fold_at].nq, kHeadTiles, dc.head[dc.fold_at + 1].n_out,
+                             dc.head[dc.fold_at + 1].n_relu);
     lay.total = cur;
     return 0;
 }
@@ -372,13 +376,16 @@ extern "C" int vsv_pack_weights(const vsv_dims* dims, const vsv_raw_weights* raw
         BFn B = [=](int r) { return b[r]; };
         pack_sec(out, dc.head[hi++], out_nat32(Hd), j == 0 ? in_nat(Hd) : in_perm(Hd), W, B);
     }
+    WFn W_lin;
+    BFn B_lin;
+    const int n_lin = c_last * 25 + X;
     {   // Linear: rows [surface_decoder_input ; ex_feats_decoder_input]
         const int ns = c_last * 25;
         const float *ws = raw->dec_in_w, *bs = raw->dec_in_b, *we = raw->ex_in_w, *be = raw->ex_in_b;
         if (X > 0 && (!we || !be)) { set_error("vsv_pack_weights: missing ex_feats_decoder_input"); return -1; }
-        WFn W = [=](int r, int c) { return r < ns ? ws[(size_t)r * Hd + c] : we[(size_t)(r - ns) * Hd + c]; };
-        BFn B = [=](int r) { return r < ns ? bs[r] : be[r - ns]; };
-        pack_sec(out, dc.head[hi++], out_nat32(ns + X), lay.NI > 0 ? in_perm(Hd) : in_nat(Hd), W, B);
+        W_lin = [=](int r, int c) { return r < ns ? ws[(size_t)r * Hd + c] : we[(size_t)(r - ns) * Hd + c]; };
+        B_lin = [=](int r) { return r < ns ? bs[r] : be[r - ns]; };
+        pack_sec(out, dc.head[hi++], out_nat32(ns + X), lay.NI > 0 ? in_perm(Hd) : in_nat(Hd), W_lin, B_lin);
     }
     int cin = c_last;
     for (int i = 0; i < d.n_conv; ++i) {
@@ -398,6 +405,26 @@ extern "C" int vsv_pack_weights(const vsv_dims* dims, const vsv_raw_weights* raw
         BFn B = [=](int r) { return r < n_out ? bias[r / 25] : b2[r - n_out]; };
         const int n_in_tot = n_in + ((i == 0) ? X : 0);
         pack_sec(out, dc.head[hi++], out_nat32(n_out + (carries_ex ? X : 0)), in_perm(n_in_tot), W, B);
+        if (i == 0) {
+            // inference: this layer applied to the Linear above, as one matrix (float64 accumulation)
+            const int n_f = n_out + (carries_ex ? X : 0);
+            std::vector<float> F((size_t)n_f * Hd), bF(n_f);
+            for (int r = 0; r < n_f; ++r) {
+                double bacc = B(r);
+                std::vector<double> row(Hd, 0.0);
+                for (int k = 0; k < n_lin; ++k) {
+                    const double a = W(r, k);
+                    if (a == 0.0) continue;
+                    bacc += a * B_lin(k);
+                    for (int c = 0; c < Hd; ++c) row[c] += a * W_lin(k, c);
+                }
+                bF[r] = (float)bacc;
+                for (int c = 0; c < Hd; ++c) F[(size_t)r * Hd + c] = (float)row[c];
+            }
+            WFn Wf = [&](int r, int c) { return F[(size_t)r * Hd + c]; };
+            BFn Bf = [&](int r) { return bF[r]; };
+            pack_sec(out, dc.head_fold, out_nat32(n_f), lay.NI > 0 ? in_perm(Hd) : in_nat(Hd), Wf, Bf);
+        }
         cin = cout;
     }
     {
@@ -437,6 +464,8 @@ extern "C" int vsv_debug_layout(const vsv_dims* dims, long long* out, int cap) {
                             lay.enc[0].ex_f0, lay.dec.kx, lay.dec.n_head, lay.dec.ex_layer, lay.dec.ex_f0,
                             lay.NTm, lay.NTd, lay.Hd, lay.enc[0].n_chain, lay.enc[1].n_chain, lay.NI};
     for (long long x : sc) v.push_back(x);
+    put(lay.dec.head_fold);
+    v.push_back(lay.dec.fold_at);
     if (out) {
         if (cap < (int)v.size()) { set_error("vsv_debug_layout: buffer too small"); return -1; }
         for (size_t i = 0; i < v.size(); ++i) out[i] = v[i];

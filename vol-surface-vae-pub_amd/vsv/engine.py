@@ -95,6 +95,60 @@ def pack_state_dict(dims: _lib.VsvDims, sd: Dict[str, np.ndarray]) -> np.ndarray
     return out
 
 
+def _fold_geometry(dims: _lib.VsvDims):
+    """(w_off, b_off, nq, nt) of the decoder head's Linear, first ConvT and folded section, and whether the
+    Linear reads its input in slot order (after interaction layers) -- from vsv_debug_layout."""
+    L = _lib.load()
+    n = L.vsv_debug_layout(C.byref(dims), None, 0)
+    buf = (C.c_longlong * n)()
+    assert L.vsv_debug_layout(C.byref(dims), buf, n) == n
+    v = [int(x) for x in buf]
+    MC = 8
+    nrec = 2 * (MC + 3) + 2 + MC
+    fold = v[6 * nrec + 16: 6 * nrec + 22]
+    fold_at = v[6 * nrec + 22]
+    d0 = 2 * (MC + 3) + 2                                        # first decoder head record
+    lin = v[6 * (d0 + fold_at): 6 * (d0 + fold_at) + 6]
+    conv = v[6 * (d0 + fold_at + 1): 6 * (d0 + fold_at + 1) + 6]
+    return dict(lin=lin[:4], conv=conv[:4], fold=fold[:4], perm_in=fold_at > 0)
+
+
+def _wpos(w_off, nt, n, k):
+    """Blob position of W[n][k] of a packed section (vsv_layout.h): n = 32*tile + row, k = 2*kstep + half."""
+    return w_off + (((k >> 3) * nt + (n >> 5)) * 64 + ((k & 1) * 32 + (n & 31))) * 4 + ((k >> 1) & 3)
+
+
+def _bpos(b_off, n):
+    t, i = n >> 5, n & 31
+    return b_off + (t * 2 + ((i >> 2) & 1)) * 16 + 4 * (i >> 3) + (i & 3)
+
+
+def _k_of_feature(f, perm):
+    """k index (2*kstep + half) at which a section reads input feature f: natural order, or the slot order
+    the previous layer's accumulators leave (feature 32t + 8a + 4h + b sits at slot 16t + 4a + b, half h)."""
+    if not perm:
+        return f
+    t, i = f >> 5, f & 31
+    return 2 * (16 * t + 4 * (i >> 3) + (i & 3)) + ((i >> 2) & 1)
+
+
+def build_fold_maps(dims: _lib.VsvDims):
+    """Index maps for folding the decoder head's Linear into its first ConvT on the device:
+    dense(A) = blob[a_w] (128 x 128), dense(B) = blob[b_w] (128 x K), F = A @ B -> blob[f_w], and the biases."""
+    g = _fold_geometry(dims)
+    n = np.arange(128)
+    K = 8 * g["lin"][2]
+    kin = _k_of_feature(np.arange(K), g["perm_in"])
+    kmid = _k_of_feature(np.arange(128), True)                   # the ConvT reads the Linear's slot order
+    a_w = _wpos(g["conv"][0], g["conv"][3], n[:, None], kmid[None, :])
+    b_w = _wpos(g["lin"][0], g["lin"][3], n[:, None], kin[None, :])
+    f_w = _wpos(g["fold"][0], g["fold"][3], n[:, None], kin[None, :])
+    sec_floats = g["fold"][2] * g["fold"][3] * 256
+    return dict(a_w=a_w, b_w=b_w, f_w=f_w, a_b=_bpos(g["conv"][1], n), b_b=_bpos(g["lin"][1], n),
+                f_b=_bpos(g["fold"][1], n), fold_w=(g["fold"][0], g["fold"][0] + sec_floats),
+                fold_b=(g["fold"][1], g["fold"][1] + g["fold"][3] * 32))
+
+
 def build_gather_maps(dims: _lib.VsvDims, spec):
     """Index maps that express the packing as two gathers: with
     flat = cat([0, p.flatten() for p in params in `spec` order]),
@@ -112,9 +166,15 @@ def build_gather_maps(dims: _lib.VsvDims, spec):
         fake_b[name] = ids if is_bhh else np.zeros(shape, np.float32)
         off += n
     assert off < 2 ** 24, "parameter count exceeds float32-exact index range"
-    idx_a = pack_state_dict(dims, fake_a).astype(np.int64)
-    idx_b = pack_state_dict(dims, fake_b).astype(np.int64)
-    return idx_a, idx_b
+    idx_a = pack_state_dict(dims, fake_a)
+    idx_b = pack_state_dict(dims, fake_b)
+    # the folded Linear . ConvT section is a PRODUCT of parameters, not a gather: nothing maps there
+    # (set_weights_from_params computes it on the device, build_fold_maps)
+    fm = build_fold_maps(dims)
+    for lo, hi in (fm["fold_w"], fm["fold_b"]):
+        idx_a[lo:hi] = 0
+        idx_b[lo:hi] = 0
+    return idx_a.astype(np.int64), idx_b.astype(np.int64)
 
 
 def _ptr(t: Optional[torch.Tensor]):
@@ -143,6 +203,7 @@ class Engine:
         self.gate_floats = int(self.lib.vsv_gate_floats(C.byref(self.dims)))
         self.packed = None
         self._maps = None
+        self._fold = None
         self._side = None
         if state_dict is not None:
             self.set_weights(state_dict)
@@ -164,6 +225,17 @@ class Engine:
         flat = torch.cat([torch.zeros(1, dtype=torch.float32, device=self.device)] +
                          [p.reshape(-1).to(device=self.device, dtype=torch.float32) for _, p in named_params])
         packed = flat[self._maps[0]] + flat[self._maps[1]]
+        # generation's folded head layer: (first ConvT) . (Linear), two small matmuls on the gathered blob
+        if self._fold is None:
+            fm = build_fold_maps(self.dims)
+            self._fold = {k: torch.from_numpy(np.ascontiguousarray(v).astype(np.int64)).to(self.device)
+                          for k, v in fm.items() if k not in ("fold_w", "fold_b")}
+        f = self._fold
+        with torch.no_grad():
+            A, Bm = packed[f["a_w"]], packed[f["b_w"]]
+            packed = packed.clone()
+            packed.index_copy_(0, f["f_w"].reshape(-1), (A @ Bm).reshape(-1))
+            packed.index_copy_(0, f["f_b"], A @ packed[f["b_b"]] + packed[f["a_b"]])
         self.packed = packed.detach()
         return packed
 

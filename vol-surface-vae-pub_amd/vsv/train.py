@@ -47,7 +47,7 @@ def read_layout(dims) -> dict:
                                lstm=[_Sec(recs[base + MC]), _Sec(recs[base + MC + 1])], head=_Sec(recs[base + MC + 2])))
     d0 = 2 * (MC + 3)
     lay["dec"] = dict(lstm=[_Sec(recs[d0]), _Sec(recs[d0 + 1])], head=[_Sec(recs[d0 + 2 + i]) for i in range(MC)])
-    sc = [int(x) for x in v[6 * nrec:]]
+    sc = [int(x) for x in v[6 * nrec: 6 * nrec + 16]]          # (the folded head section follows: engine.py)
     (lay["enc"][0]["kx"], lay["enc"][1]["kx"], lay["enc"][0]["nh"], lay["enc"][1]["nh"], lay["E"], lay["ex_f0"],
      lay["dec"]["kx"], lay["dec"]["n_head"], lay["dec"]["ex_layer"], lay["dec"]["ex_f0"],
      lay["NTm"], lay["NTd"], lay["Hd"], lay["enc"][0]["n_chain"], lay["enc"][1]["n_chain"], lay["NI"]) = sc

@@ -104,10 +104,11 @@ def test_library_exports_every_declared_symbol():
     assert b"latent_dim" in L.vsv_last_error()
 
 
-@pytest.mark.parametrize("L,X", [(5, 0), (12, 3)])
-def test_gather_maps_reproduce_host_packing(L, X):
+@pytest.mark.parametrize("L,X,extra", [(5, 0, {}), (12, 3, {}), (12, 3, {"interaction_layers": 2}),
+                                       (5, 3, {"mem_type": "gru", "mem_layers": 1})])
+def test_gather_maps_reproduce_host_packing(L, X, extra):
     from vsv.engine import build_gather_maps, dims_from_config, pack_state_dict
-    cfg = vo.make_config(L, X)
+    cfg = vo.make_config(L, X, **extra)
     W = vo.init_weights(cfg, 9, 2.0)
     dims = dims_from_config(cfg)
     spec = vo.state_dict_spec(cfg)

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define VSV_ABI_VERSION 12
+#define VSV_ABI_VERSION 13
 #define VSV_MAX_CONV 4
 #define VSV_MAX_CHAIN 8
 #define VSV_MAX_INTERACT 3
@@ -124,6 +124,22 @@ int vsv_encode_state(const vsv_dims *dims, const float *packed, int which,
                      const float *ex, long ex_row_stride, long ex_t_stride,
                      long n_rows, int T, const float *state_in, long state_div, float *state_out,
                      float *out, void *ws, size_t ws_bytes, void *stream);
+
+/* Autoregressive rollouts (generate_autoregressive_sequence, :717-807): a generated day's conv embedding and
+ * first-layer input product do not depend on its position in the window, so they are computed once, when the
+ * day is generated -- vsv_encode_pre: rows surf (n_rows x 25, row stride given) [, ex] -> pre
+ * [32 * NTm gate values][pre_stride >= rows padded to 32] -- and the encoders of later steps run from the
+ * tables of their T days -- vsv_encode_from_pre: day t's table at pre + t * pre_tstride; state arguments as in
+ * vsv_encode_state.  Results equal vsv_encode_state on the same surfaces. */
+size_t vsv_encode_pre_ws_bytes(const vsv_dims *dims, long n_rows);
+int vsv_encode_pre(const vsv_dims *dims, const float *packed, int which,
+                   const float *surf, long surf_row_stride, const float *ex, long ex_row_stride,
+                   long n_rows, float *pre, long pre_stride, void *ws, size_t ws_bytes, void *stream);
+size_t vsv_encode_from_pre_ws_bytes(const vsv_dims *dims, long n_rows, int T);
+int vsv_encode_from_pre(const vsv_dims *dims, const float *packed, int which,
+                        const float *pre, long pre_stride, long pre_tstride, long n_rows, int T,
+                        const float *state_in, long state_div, float *state_out,
+                        float *out, void *ws, size_t ws_bytes, void *stream);
 
 /* The same encoders over OVERLAPPING windows of one calendar series -- the date-range backfill loops of
  * generate_surfaces.py:60-102 / eval_scripts/eval_utils.py:42-70, where window r is days [r, r+T) of

@@ -555,8 +555,10 @@ struct LstmSeqArgs {
     // pre-activations b + W_ih . x per CALENDAR DAY, transposed ([32*NT gate values][pre_stride days], gate
     // value j = 2*(16*tile + register) + lane half), computed once per day instead of once per
     // (window, step); layer 0 starts from them and skips its input product
+    // Step t of row r reads column r + t * pre_tstride: 1 for calendar windows; for autoregressive
+    // rollouts the table is [generated day][gate value][row] and pre_tstride = one day's table.
     const float* pre_t;
-    long pre_stride;
+    long pre_stride, pre_tstride;
 };
 
 // per-thread constants of the decoder input assembly
@@ -816,7 +818,7 @@ lstm_kernel(const LstmSeqArgs a) {
     float4 a0[OWN];                                               // quad 0 of the next gate GEMM (OWN == 4)
     auto acc_init = [&](int l, bool shared, int lv, int t) {
         if (XMODE == 0 && !SAVE && l == 0 && a.pre_t) {
-            const float* p = a.pre_t + (size_t)(lv >> 5) * a.pre_stride + row32 + t;
+            const float* p = a.pre_t + (size_t)(lv >> 5) * a.pre_stride + row32 + (size_t)t * a.pre_tstride;
 #pragma unroll
             for (int i = 0; i < OWN; ++i)
 #pragma unroll
@@ -854,7 +856,9 @@ lstm_kernel(const LstmSeqArgs a) {
         qx0 = a.L >> 3;
         qxn = ((2 * a.L + 7) >> 3) - qx0;
     }
-    if (OWN == 4) wload<OWN>(a0, (const float4*)a.w[0] + (size_t)qx0 * NT * 64, wo, 0u);
+    // (with a pre-activation table layer 0 streams its recurrent quads only)
+    const size_t w0_skip = (XMODE == 0 && !SAVE && a.pre_t) ? (size_t)(kx >> 2) * NT * 64 : 0;
+    if (OWN == 4) wload<OWN>(a0, (const float4*)a.w[0] + w0_skip + (size_t)qx0 * NT * 64, wo, 0u);
 
     // state: (h | c) per layer, each HP floats in lane order (position 8*tile + 4*hh + jj holds unit
     // 8*tile + 2*jj + hh), so a lane's four units of a tile are one float4
@@ -947,13 +951,15 @@ lstm_kernel(const LstmSeqArgs a) {
                 if constexpr (XMODE == 0) {
                     if (l == 0) {
                         const float* xg = a.x_tileb + ((size_t)(rowtile * a.T + t) * kx) * 64 + lv;
-                        gemm_stream<OWN>(acc, a0, w, wo, NT * 64, nq, [&](int q, float (&bv)[4]) {
-                            if (q < nq_in) {
+                        const int qp = w0_skip ? nq_in : 0;          // input quads already in the accumulators
+                        gemm_stream<OWN>(acc, a0, w + w0_skip, wo, NT * 64, nq - qp, [&](int q, float (&bv)[4]) {
+                            const int qq = q + qp;
+                            if (qq < nq_in) {
 #pragma unroll
-                                for (int j = 0; j < 4; ++j) bv[j] = xg[(4 * q + j) * 64];
+                                for (int j = 0; j < 4; ++j) bv[j] = xg[(4 * qq + j) * 64];
                             } else {
 #pragma unroll
-                                for (int j = 0; j < 4; ++j) bv[j] = hl[(4 * (q - nq_in) + j) * 64];
+                                for (int j = 0; j < 4; ++j) bv[j] = hl[(4 * (qq - nq_in) + j) * 64];
                             }
                         });
                     }
@@ -971,7 +977,7 @@ lstm_kernel(const LstmSeqArgs a) {
                     });
                 }
                 if (l + 1 < NL) wload<OWN>(a0, (const float4*)a.w[l + 1], wo, 0u);
-                else if (!head_now && t + 1 < a.T) wload<OWN>(a0, (const float4*)a.w[0], wo, 0u);
+                else if (!head_now && t + 1 < a.T) wload<OWN>(a0, (const float4*)a.w[0] + w0_skip, wo, 0u);
             } else {
                 const float* bin;
                 if (l == 0) bin = (XMODE == 0) ? a.x_tileb + ((size_t)(rowtile * a.T + t) * kx) * 64 + lv : xs;
@@ -1072,7 +1078,7 @@ lstm_kernel(const LstmSeqArgs a) {
                         unsigned wn[OWN];
 #pragma unroll
                         for (int i = 0; i < OWN; ++i) wn[i] = (unsigned)ln + (unsigned)toff[i];
-                        wload<OWN>(a0, (const float4*)a.w[0], wn, 0u);
+                        wload<OWN>(a0, (const float4*)a.w[0] + w0_skip, wn, 0u);
                     }
                 }
             }
@@ -1892,7 +1898,7 @@ static int encode_windows_impl(const vsv_dims* dims, const float* packed, int wh
     l.gru = lay.gru;
     for (int i = 0; i < lay.NL; ++i) { l.w[i] = packed + e.lstm[i].w_off; l.b[i] = packed + e.lstm[i].b_off; }
     l.kx = e.kx; l.n_rows = n_windows; l.n_rowtiles = rt; l.T = T;
-    l.pre_t = pre; l.pre_stride = ct * 32; l.L = lay.L;
+    l.pre_t = pre; l.pre_stride = ct * 32; l.pre_tstride = 1; l.L = lay.L;
     l.hout = hbuf; l.t_out0 = 0;
     l.din.state_in = state_in; l.din.state_div = 1;
     l.state_out = state_out;
@@ -1915,6 +1921,99 @@ static int encode_impl(const vsv_dims* dims, const float* packed, int which,
                        const float* ex, long ex_row_stride, long ex_t_stride,
                        long n_rows, int T, const float* state_in, long state_div, float* state_out,
                        float* out, void* ws, size_t ws_bytes, void* stream);
+
+// ---- autoregressive rollouts: a generated day's embedding and first-layer input product are the same at
+// every later step of the rollout (they do not depend on the day's position in the window), so they are
+// computed once when the day is generated (vsv_encode_pre) and the later steps start from the table ----
+extern "C" size_t vsv_encode_pre_ws_bytes(const vsv_dims* dims, long n_rows) {
+    Layout lay;
+    const char* msg = nullptr;
+    if (!dims || make_layout(*dims, lay, &msg) != 0 || n_rows < 0) return 0;
+    const long rt = (n_rows + 31) / 32;
+    const int kx = lay.enc[0].kx > lay.enc[1].kx ? lay.enc[0].kx : lay.enc[1].kx;
+    return align256((size_t)rt * kx * 64 * sizeof(float)) + 256;
+}
+
+extern "C" int vsv_encode_pre(const vsv_dims* dims, const float* packed, int which,
+                              const float* surf, long surf_row_stride, const float* ex, long ex_row_stride,
+                              long n_rows, float* pre, long pre_stride, void* ws, size_t ws_bytes, void* stream) {
+    VSV_LAYOUT_OR_FAIL("vsv_encode_pre")
+    if (which < 0 || which > 1) { set_error("vsv_encode_pre: which must be 0 or 1"); return -1; }
+    if (n_rows < 0) { set_error("vsv_encode_pre: negative size"); return -1; }
+    if (n_rows == 0) return 0;
+    if (!packed || !surf || !pre || !ws) { set_error("vsv_encode_pre: null pointer"); return -1; }
+    if (lay.X > 0 && !ex) { set_error("vsv_encode_pre: ex_feats_dim > 0 but ex is null"); return -1; }
+    const long rt = (n_rows + 31) / 32;
+    if (pre_stride < rt * 32) { set_error("vsv_encode_pre: pre_stride must cover the rows padded to 32"); return -1; }
+    if (ws_bytes < vsv_encode_pre_ws_bytes(dims, n_rows)) { set_error("vsv_encode_pre: workspace too small"); return -1; }
+    hipStream_t st = (hipStream_t)stream;
+    const EncLayout& e = lay.enc[which];
+    const int NT = lay.NTm;
+    float* xe = (float*)(((uintptr_t)ws + 255) & ~(uintptr_t)255);
+    DenseChainArgs a = {};
+    a.n_layers = e.n_chain;
+    for (int i = 0; i < e.n_chain; ++i) fill_dense(a, i, packed, e.conv[i]);
+    a.inj_layer = e.n_conv - 1;
+    a.n_rows = n_rows; a.n_rowtiles = rt; a.T = 1;
+    a.in_mode = 0; a.in = surf; a.in_rs = surf_row_stride; a.in_ts = 0; a.in_f = 25;
+    a.in_ks = 4 * e.conv[0].nq;
+    if (lay.X > 0) { a.inj = ex; a.inj_rs = ex_row_stride; a.inj_ts = 0; a.inj_f0 = e.ex_f0; a.inj_n = lay.X; }
+    a.out_mode = 0; a.out = xe; a.out_f = e.E; a.S = 1;
+    a.aux_layer = -1;
+    int rc = launch_dense_chain(a, st);
+    if (rc) return rc;
+    const float* w0 = packed + e.lstm[0].w_off;
+    const float* b0 = packed + e.lstm[0].b_off;
+    if (rt > 0x7fffffffL) { set_error("vsv_encode_pre: too many rows"); return -2; }
+    if (NT == 13) hipLaunchKernelGGL(lstm_pre_t_kernel<13>, dim3((unsigned)rt), dim3(64 * 13), 0, st, w0, b0, e.kx >> 2, xe, pre, pre_stride);
+    else if (NT == 16) hipLaunchKernelGGL(lstm_pre_t_kernel<16>, dim3((unsigned)rt), dim3(64 * 16), 0, st, w0, b0, e.kx >> 2, xe, pre, pre_stride);
+    else { set_error("unsupported LSTM hidden size: %d tiles of 8 units", NT); return -4; }
+    return launch_check("lstm_pre_t_kernel");
+}
+
+extern "C" size_t vsv_encode_from_pre_ws_bytes(const vsv_dims* dims, long n_rows, int T) {
+    Layout lay;
+    const char* msg = nullptr;
+    if (!dims || make_layout(*dims, lay, &msg) != 0 || n_rows < 0 || T < 0) return 0;
+    const long rt = (n_rows + 31) / 32;
+    return align256((size_t)rt * T * 4 * lay.NTm * 64 * sizeof(float)) + 256;
+}
+
+extern "C" int vsv_encode_from_pre(const vsv_dims* dims, const float* packed, int which,
+                                   const float* pre, long pre_stride, long pre_tstride, long n_rows, int T,
+                                   const float* state_in, long state_div, float* state_out,
+                                   float* out, void* ws, size_t ws_bytes, void* stream) {
+    VSV_LAYOUT_OR_FAIL("vsv_encode_from_pre")
+    if (which < 0 || which > 1) { set_error("vsv_encode_from_pre: which must be 0 or 1"); return -1; }
+    if (n_rows < 0 || T < 0) { set_error("vsv_encode_from_pre: negative size"); return -1; }
+    if (n_rows == 0 || T == 0) return 0;
+    if (!packed || !pre || !out || !ws) { set_error("vsv_encode_from_pre: null pointer"); return -1; }
+    if (state_in && state_div < 1) { set_error("vsv_encode_from_pre: state_div must be >= 1"); return -1; }
+    const long rt = (n_rows + 31) / 32;
+    if (pre_stride < rt * 32 || pre_tstride < 1) { set_error("vsv_encode_from_pre: bad table strides"); return -1; }
+    if (ws_bytes < vsv_encode_from_pre_ws_bytes(dims, n_rows, T)) { set_error("vsv_encode_from_pre: workspace too small"); return -1; }
+    hipStream_t st = (hipStream_t)stream;
+    const EncLayout& e = lay.enc[which];
+    float* hbuf = (float*)(((uintptr_t)ws + 255) & ~(uintptr_t)255);
+    LstmSeqArgs l = {};
+    l.gru = lay.gru;
+    for (int i = 0; i < lay.NL; ++i) { l.w[i] = packed + e.lstm[i].w_off; l.b[i] = packed + e.lstm[i].b_off; }
+    l.kx = e.kx; l.n_rows = n_rows; l.n_rowtiles = rt; l.T = T;
+    l.pre_t = pre; l.pre_stride = pre_stride; l.pre_tstride = pre_tstride; l.L = lay.L;
+    l.hout = hbuf; l.t_out0 = 0;
+    l.din.state_in = state_in; l.din.state_div = state_in ? state_div : 1;
+    l.state_out = state_out;
+    int rc = launch_lstm<0>(l, lay.NTm, lay.NL, false, st);
+    if (rc) return rc;
+    DenseChainArgs h = {};
+    h.n_layers = 1;
+    fill_dense(h, 0, packed, e.head);
+    h.n_rows = n_rows; h.n_rowtiles = rt; h.T = T;
+    h.in_mode = 1; h.in = hbuf; h.in_ks = 4 * lay.NTm;
+    h.out_mode = 1; h.out = out; h.out_f = e.nh; h.S = 1;
+    h.aux_layer = -1;
+    return launch_dense_chain(h, st);
+}
 
 extern "C" int vsv_encode(const vsv_dims* dims, const float* packed, int which,
                           const float* surf, long surf_row_stride, long surf_t_stride,

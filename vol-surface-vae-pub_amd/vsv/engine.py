@@ -289,6 +289,35 @@ class Engine:
         _lib.check(rc, "vsv_encode_state")
         return out, st_out
 
+    def pre_table_floats(self, n_rows: int) -> int:
+        """floats of one day's pre-activation table for n_rows rows: [32 * NTm gate values][rows padded to 32]."""
+        return 32 * ((self.dims.mem_hidden + 7) // 8) * (((n_rows + 31) // 32) * 32)
+
+    def encode_pre(self, which, surf, surf_rs, ex, ex_rs, n_rows, pre_out: torch.Tensor):
+        """vsv_encode_pre: the position-independent part of encoder `which` (embedding + first-layer input
+        product) of one day per row -> pre_out (a view of pre_table_floats(n_rows) floats)."""
+        assert pre_out.is_contiguous() and pre_out.numel() == self.pre_table_floats(n_rows)
+        ws = self._ws(self.lib.vsv_encode_pre_ws_bytes(C.byref(self.dims), n_rows))
+        with torch.cuda.device(self.device):
+            rc = self.lib.vsv_encode_pre(C.byref(self.dims), _ptr(self.packed), which, _ptr(surf), surf_rs,
+                                         _ptr(ex), ex_rs, n_rows, _ptr(pre_out), ((n_rows + 31) // 32) * 32,
+                                         _ptr(ws), ws.numel(), self._stream())
+        _lib.check(rc, "vsv_encode_pre")
+
+    def encode_from_pre(self, which, pre: torch.Tensor, n_rows, T, state_in=None, state_div=1):
+        """vsv_encode_from_pre: encoder `which` over the T days whose tables are pre[0:T] (T, table floats)."""
+        assert pre.is_contiguous() and pre.shape[0] >= T and pre[0].numel() == self.pre_table_floats(n_rows)
+        nh = self.L if which else 2 * self.L
+        out = torch.empty((n_rows, T, nh), dtype=torch.float32, device=self.device)
+        ws = self._ws(self.lib.vsv_encode_from_pre_ws_bytes(C.byref(self.dims), n_rows, T))
+        with torch.cuda.device(self.device):
+            rc = self.lib.vsv_encode_from_pre(C.byref(self.dims), _ptr(self.packed), which, _ptr(pre),
+                                              ((n_rows + 31) // 32) * 32, pre[0].numel(), n_rows, T,
+                                              _ptr(state_in), state_div, None,
+                                              _ptr(out), _ptr(ws), ws.numel(), self._stream())
+        _lib.check(rc, "vsv_encode_from_pre")
+        return out
+
     def encode_both_strided(self, surf, surf_rs, surf_ts, ex, ex_rs, ex_ts, n_rows, T, T_ctx=None):
         """Posterior encoder (which=0, T steps) and context encoder (which=1, T_ctx steps) of the
         same windows on two HIP streams: they are independent and, for a date-range prefix,

@@ -150,6 +150,13 @@ SIGNATURES = {
     "vsv_encode_windows_state": (C.c_int, [C.POINTER(VsvDims), C.c_void_p, C.c_int, C.c_void_p, C.c_void_p,
                                            C.c_long, C.c_int, C.c_void_p, C.c_void_p,
                                            C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "vsv_encode_pre_ws_bytes": (C.c_size_t, [C.POINTER(VsvDims), C.c_long]),
+    "vsv_encode_pre": (C.c_int, [C.POINTER(VsvDims), C.c_void_p, C.c_int, C.c_void_p, C.c_long, C.c_void_p, C.c_long,
+                                 C.c_long, C.c_void_p, C.c_long, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "vsv_encode_from_pre_ws_bytes": (C.c_size_t, [C.POINTER(VsvDims), C.c_long, C.c_int]),
+    "vsv_encode_from_pre": (C.c_int, [C.POINTER(VsvDims), C.c_void_p, C.c_int, C.c_void_p, C.c_long, C.c_long,
+                                      C.c_long, C.c_int, C.c_void_p, C.c_long, C.c_void_p,
+                                      C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     "vsv_state_floats": (C.c_size_t, [C.POINTER(VsvDims)]),
     "vsv_gate_floats": (C.c_size_t, [C.POINTER(VsvDims)]),
     "vsv_decode_ws_bytes": (C.c_size_t, [C.POINTER(VsvDims), C.c_long, C.c_int, C.c_int]),
@@ -199,7 +206,7 @@ def load() -> C.CDLL:
             fn = getattr(lib, name)
             fn.restype = res
             fn.argtypes = args
-        if lib.vsv_abi_version() != 12:
+        if lib.vsv_abi_version() != 13:
             raise RuntimeError("libvsv_hip.so ABI version mismatch")
         _lib = lib
     return _lib

@@ -286,9 +286,20 @@ def ar_generate(eng: Engine, surf_ctx: torch.Tensor, ex_ctx: Optional[torch.Tens
     if eps is not None:
         eps = eps.to(dev, torch.float32).contiguous()
         assert eps.shape == (R, horizon, L)
+    # per generated day and encoder: the position-independent part (embedding + first-layer input product),
+    # computed once when the day is generated and read by every later step of the rollout
+    ptab = None
+    if share and horizon > 1:
+        ptab = [torch.empty((horizon - 1, eng.pre_table_floats(R)), dtype=torch.float32, device=dev) for _ in range(2)]
     for k in range(horizon):
         ek = None if eps is None else eps[:, k:k + 1].contiguous()
-        if share and k < C:
+        if share and k >= C:
+            # the window is all generated days k-C .. k-1
+            enc = eng.encode_from_pre(0, ptab[0][k - C:], R, C)
+            ctx = eng.encode_from_pre(1, ptab[1][k - C:], R, C)
+            r = eng.decode(R, C + 1, C, ctx=ctx, zb=enc[..., :L].contiguous(), eps=ek, eps_t0=C,
+                           seed=seed, S=S, day0=day0, step0=k)
+        elif share and k < C:
             ns = C - k                                         # days of the original context still in the window
             enc_s, st_e = eng.encode_state(0, ctx0[:, k:], C * 25, 25, ex0[:, k:] if X > 0 else None, C * X, X,
                                            D, ns, want_state=k > 0)
@@ -299,10 +310,9 @@ def ar_generate(eng: Engine, surf_ctx: torch.Tensor, ex_ctx: Optional[torch.Tens
                 r = eng.decode(R, 1, 0, state_in=pre["state"], state_div=S, gate_in=pre["gates"],
                                eps=ek, eps_t0=0, seed=seed, S=S, day0=day0, step0=0)
             else:
-                gen = buf[:, C:]                               # the rows' own generated days 0..k-1
-                gex = exb[:, C:] if X > 0 else None
-                enc_r, _ = eng.encode_state(0, gen, TT * 25, 25, gex, TT * X, X, R, k, state_in=st_e, state_div=S)
-                ctx_r, _ = eng.encode_state(1, gen, TT * 25, 25, gex, TT * X, X, R, k, state_in=st_c, state_div=S)
+                # the rows' own generated days 0..k-1, from their tables
+                enc_r = eng.encode_from_pre(0, ptab[0], R, k, state_in=st_e, state_div=S)
+                ctx_r = eng.encode_from_pre(1, ptab[1], R, k, state_in=st_c, state_div=S)
                 r = eng.decode(R, k + 1, k, ctx=ctx_r, zb=enc_r[..., :L].contiguous(),
                                state_in=pre["state"], state_div=S,
                                eps=ek, eps_t0=k, seed=seed, S=S, day0=day0, step0=k)
@@ -318,6 +328,9 @@ def ar_generate(eng: Engine, surf_ctx: torch.Tensor, ex_ctx: Optional[torch.Tens
         if X > 0:
             out_e[:, k] = r["ex"][:, 0]
             exb[:, C + k] = r["ex"][:, 0]
+        if ptab is not None and k < horizon - 1:
+            for which in (0, 1):
+                eng.encode_pre(which, buf[:, C + k], TT * 25, exb[:, C + k] if X > 0 else None, TT * X, R, ptab[which][k])
     return out_s, out_e
 
 

@@ -33,6 +33,9 @@ struct Sec {                       // one packed layer
     int nt = 0;                    // output tiles (32 output rows each)
     int n_relu = 0;                // output features < n_relu get ReLU (dense layers)
     int n_out = 0;                 // real output features
+    // K quads [qlo, qhi) that can be non-zero for output tile t (conv layers of the decoder head in
+    // pixel-major feature order: a tile's outputs read a band of input pixels); [0, nq) otherwise
+    int qlo[4] = {0, 0, 0, 0}, qhi[4] = {0, 0, 0, 0};
 };
 
 struct EncLayout {

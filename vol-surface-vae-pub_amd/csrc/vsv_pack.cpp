@@ -31,7 +31,36 @@ static Sec alloc_sec(size_t& cur, int nq, int nt, int n_out, int n_relu) {
     cur += (size_t)nq * nt * 256;
     s.b_off = cur;
     cur += (size_t)nt * 32;
+    for (int t = 0; t < 4; ++t) { s.qlo[t] = 0; s.qhi[t] = nq; }
     return s;
+}
+
+// Hidden features of the decoder head's conv layers are stored PIXEL-major (packed index p = pixel * C +
+// channel <-> reference feature channel * 25 + pixel; the ex-feature riders behind them keep their place):
+// a 3x3 conv / conv-transpose output pixel reads its 3x3 neighbourhood, so in this order an output tile's
+// non-zero weights form a contiguous band of input features.
+static inline int px2orig(int p, int C) { return p < 25 * C ? (p % C) * 25 + p / C : p; }
+
+// band of K quads (8 input features each) read by the 32 outputs of tile t of a cin -> cout conv layer
+static void conv_band(Sec& s, int cin, int cout) {
+    for (int t = 0; t < s.nt && t < 4; ++t) {
+        int lo = 1 << 30, hi = -1;
+        for (int p = 32 * t; p < 32 * t + 32 && p < 25 * cout; ++p) {
+            const int y = (p / cout) / 5, x = (p / cout) % 5;
+            for (int dy = -1; dy <= 1; ++dy)
+                for (int dx = -1; dx <= 1; ++dx) {
+                    const int yy = y + dy, xx = x + dx;
+                    if (yy < 0 || yy >= 5 || xx < 0 || xx >= 5) continue;
+                    const int f0 = (yy * 5 + xx) * cin;
+                    lo = f0 < lo ? f0 : lo;
+                    hi = f0 + cin - 1 > hi ? f0 + cin - 1 : hi;
+                }
+        }
+        if (hi < 0) { s.qlo[t] = 0; s.qhi[t] = 1; continue; }
+        s.qlo[t] = lo / 8;
+        s.qhi[t] = hi / 8 + 1;
+        if (s.qhi[t] > s.nq) s.qhi[t] = s.nq;
+    }
 }
 
 int make_layout(const vsv_dims& d, Layout& lay, const char** msg) {
@@ -132,6 +161,7 @@ int make_layout(const vsv_dims& d, Layout& lay, const char** msg) {
             dc.ex_f0 = cout * 25;
         }
         dc.head[nh++] = alloc_sec(cur, 4 * kHeadTiles, kHeadTiles, n_out, cout * 25);
+        if (i > 0) conv_band(dc.head[nh - 1], cin, cout);      // (layer 0 carries the ex riders and is folded)
         cin = cout;
     }
     dc.head[nh++] = alloc_sec(cur, 4 * kHeadTiles, cdiv(lay.Q * 25, 32), lay.Q * 25, 0);
@@ -178,6 +208,16 @@ static OutMap out_gate(int H) {
 }
 static InMap in_nat(int n_in) {
     return [=](int s, int hh) { const int f = 2 * s + hh; return f < n_in ? f : -1; };
+}
+static OutMap out_px(int n_out, int C) {
+    return [=](int t, int i) { const int f = 32 * t + i; return f < n_out ? px2orig(f, C) : -1; };
+}
+static InMap in_perm(int n_in);
+static InMap in_perm_px(int n_in, int C) {
+    return [=](int s, int hh) {
+        const int f = 32 * (s >> 4) + 8 * ((s >> 2) & 3) + 4 * hh + (s & 3);
+        return f < n_in ? px2orig(f, C) : -1;
+    };
 }
 static InMap in_perm(int n_in) {
     return [=](int s, int hh) {
@@ -385,7 +425,7 @@ extern "C" int vsv_pack_weights(const vsv_dims* dims, const vsv_raw_weights* raw
         if (X > 0 && (!we || !be)) { set_error("vsv_pack_weights: missing ex_feats_decoder_input"); return -1; }
         W_lin = [=](int r, int c) { return r < ns ? ws[(size_t)r * Hd + c] : we[(size_t)(r - ns) * Hd + c]; };
         B_lin = [=](int r) { return r < ns ? bs[r] : be[r - ns]; };
-        pack_sec(out, dc.head[hi++], out_nat32(ns + X), lay.NI > 0 ? in_perm(Hd) : in_nat(Hd), W_lin, B_lin);
+        pack_sec(out, dc.head[hi++], out_px(ns + X, c_last), lay.NI > 0 ? in_perm(Hd) : in_nat(Hd), W_lin, B_lin);
     }
     int cin = c_last;
     for (int i = 0; i < d.n_conv; ++i) {
@@ -404,7 +444,7 @@ extern "C" int vsv_pack_weights(const vsv_dims* dims, const vsv_raw_weights* raw
         };
         BFn B = [=](int r) { return r < n_out ? bias[r / 25] : b2[r - n_out]; };
         const int n_in_tot = n_in + ((i == 0) ? X : 0);
-        pack_sec(out, dc.head[hi++], out_nat32(n_out + (carries_ex ? X : 0)), in_perm(n_in_tot), W, B);
+        pack_sec(out, dc.head[hi++], out_px(n_out + (carries_ex ? X : 0), cout), in_perm_px(n_in_tot, cin), W, B);
         if (i == 0) {
             // inference: this layer applied to the Linear above, as one matrix (float64 accumulation)
             const int n_f = n_out + (carries_ex ? X : 0);
@@ -423,7 +463,7 @@ extern "C" int vsv_pack_weights(const vsv_dims* dims, const vsv_raw_weights* raw
             }
             WFn Wf = [&](int r, int c) { return F[(size_t)r * Hd + c]; };
             BFn Bf = [&](int r) { return bF[r]; };
-            pack_sec(out, dc.head_fold, out_nat32(n_f), lay.NI > 0 ? in_perm(Hd) : in_nat(Hd), Wf, Bf);
+            pack_sec(out, dc.head_fold, out_px(n_f, cout), lay.NI > 0 ? in_perm(Hd) : in_nat(Hd), Wf, Bf);
         }
         cin = cout;
     }
@@ -433,7 +473,18 @@ extern "C" int vsv_pack_weights(const vsv_dims* dims, const vsv_raw_weights* raw
         const float* bias = raw->dec_out_b;
         WFn W = [&, n_in](int r, int c) { return M[(size_t)r * n_in + c]; };
         BFn B = [=](int r) { return bias[r / 25]; };
-        pack_sec(out, dc.head[hi++], out_nat32(lay.Q * 25), in_perm(n_in), W, B);
+        pack_sec(out, dc.head[hi++], out_nat32(lay.Q * 25), in_perm_px(n_in, cin), W, B);
+    }
+    // the bands are structural: nothing outside them may be non-zero
+    for (int li = 0; li < dc.n_head; ++li) {
+        const Sec& sc = dc.head[li];
+        for (int q = 0; q < sc.nq; ++q)
+            for (int t = 0; t < sc.nt && t < 4; ++t) {
+                if (q >= sc.qlo[t] && q < sc.qhi[t]) continue;
+                const float* w = out + sc.w_off + ((size_t)q * sc.nt + t) * 256;
+                for (int e = 0; e < 256; ++e)
+                    if (w[e] != 0.0f) { set_error("vsv_pack_weights: weight outside the band of head layer %d", li); return -3; }
+            }
     }
     return 0;
 }

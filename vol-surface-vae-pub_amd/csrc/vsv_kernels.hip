@@ -226,6 +226,32 @@ __device__ __forceinline__ void tile_mfma(f32x16& acc, float4 (&a)[kHalfQ], cons
     }
 }
 
+// The same for a tile whose non-zero weights are the K quads [q0, q0 + nqb) (a conv layer in pixel-major
+// order): only those are fetched and multiplied.  nqb is wave-uniform, so the guards are scalar branches.
+__device__ __forceinline__ int pick4(const int (&v)[4], int w) { return w == 0 ? v[0] : (w == 1 ? v[1] : (w == 2 ? v[2] : v[3])); }
+__device__ __forceinline__ void tile_load_band(float4 (&a)[kHalfQ], const float4* __restrict__ w, unsigned off, int qstride,
+                                               int q0, int nqb) {
+#pragma unroll
+    for (int q = 0; q < kHalfQ; ++q) a[q] = w[off + (unsigned)((q0 + ((q < nqb) ? q : nqb - 1)) * qstride)];
+}
+template <int NQ>
+__device__ __forceinline__ void tile_mfma_band(f32x16& acc, float4 (&a)[kHalfQ], const float4* __restrict__ w, unsigned off,
+                                               int qstride, const float* b, int q0, int nqb) {
+    const float4* wb = w + (size_t)q0 * qstride;
+    const float* bb = b + (size_t)q0 * 4 * 64;
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+        if (q < nqb) {
+            const float4 cur = a[q % kHalfQ];
+            if (q + kHalfQ < nqb) a[q % kHalfQ] = wb[off + (unsigned)((q + kHalfQ) * qstride)];
+            acc = mfma32(cur.x, bb[(4 * q + 0) * 64], acc);
+            acc = mfma32(cur.y, bb[(4 * q + 1) * 64], acc);
+            acc = mfma32(cur.z, bb[(4 * q + 2) * 64], acc);
+            acc = mfma32(cur.w, bb[(4 * q + 3) * 64], acc);
+        }
+    }
+}
+
 // acc[i] = bias of tile tile[i] (compact [nt][2][16] layout)
 template <int NC>
 __device__ __forceinline__ void load_bias(f32x16 (&acc)[NC], const float* __restrict__ b, const int (&toff)[NC], int hh) {
@@ -317,6 +343,7 @@ struct DenseLayerArg {
     const float* w;
     const float* b;
     int nq, nt, n_relu;
+    int q0[4], nqb[4];      // output tile t reads K quads [q0[t], q0[t] + nqb[t]) (Sec::qlo / qhi); fused head only
 };
 
 struct DenseChainArgs {
@@ -688,12 +715,13 @@ __device__ __forceinline__ void fused_head(const LstmSeqArgs& a, float4 (&wq)[kH
         if (mine) {
             const unsigned off = wave * 64 + lv;
             if (li == 0) tile_mfma<NT>(acc[0], wq, (const float4*)ly.w, off, ly.nt * 64, src);
-            else tile_mfma<4 * kHeadTiles>(acc[0], wq, (const float4*)ly.w, off, ly.nt * 64, src);
+            else tile_mfma_band<4 * kHeadTiles>(acc[0], wq, (const float4*)ly.w, off, ly.nt * 64, src,
+                                                   pick4(ly.q0, wave), pick4(ly.nqb, wave));
         }
         if (!last) {
             const DenseLayerArg& nx = hd.layer[li + 1];
             const int tw = wave < nx.nt ? wave : nx.nt - 1;
-            tile_load<4 * kHeadTiles>(wq, (const float4*)nx.w, tw * 64 + lv, nx.nt * 64);
+            tile_load_band(wq, (const float4*)nx.w, tw * 64 + lv, nx.nt * 64, pick4(nx.q0, tw), pick4(nx.nqb, tw));
             const float4* bp = (const float4*)(nx.b + tw * 32 + hh * 16);
 #pragma unroll
             for (int v = 0; v < 4; ++v) bq[v] = bp[v];
@@ -1799,6 +1827,10 @@ static void fill_dense(DenseChainArgs& a, int li, const float* packed, const Sec
     a.layer[li].nq = s.nq;
     a.layer[li].nt = s.nt;
     a.layer[li].n_relu = s.n_relu;
+    for (int t = 0; t < 4; ++t) {
+        a.layer[li].q0[t] = s.qlo[t];
+        a.layer[li].nqb[t] = s.qhi[t] - s.qlo[t];
+    }
 }
 
 }  // namespace vsv

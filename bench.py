@@ -8,10 +8,15 @@ whole backfill of `--days` context windows x `--samples` prior MC samples x
 `--horizon` decoded days (BASELINE.json configs[3]: context 60, latent 12,
 3 extra features, 4000 days x 1000 samples), ending in the on-device
 p05/p50/p95 reduction.  Inputs (the calendar of surfaces, the packed weights)
-are resident in HBM before the timed region.  With N > 1 (one process per GPU,
-launched by torch.distributed.run) every rank owns its own date range of
-`--days` days (weak scaling, global Philox day counters) and the reduced
-quantile tensors are all-gathered over RCCL at the end of every step.
+are resident in HBM before the timed region.  With N > 1 there is one process
+per GPU over RCCL: either the caller launched them (torch.distributed.run sets
+RANK / WORLD_SIZE, which must equal --gpus) or, called plainly as
+`python bench.py --gpus N`, this script spawns them itself through
+torch.distributed.run before it touches a GPU.  Every rank owns its own date
+range of `--days` days (weak scaling: `value`; global Philox day counters) and
+the reduced quantile tensors are all-gathered at the end of every step; a second
+timed leg splits `--days` days in total over the ranks (strong scaling, the
+BASELINE configs[3] split) and is reported under "strong".
 
 Prints ONE JSON line on rank 0.  See DESIGN.md "Measurement".
 """
@@ -56,13 +61,7 @@ def flops_per_unit(L: int, X: int, Hm: int = 100, c_last: int = 5, Q: int = 3):
             "dec_lstm_first": f_dec_lstm_first}
 
 
-def synthetic_calendar(n_days: int, C: int, X: int, seed: int = 1234):
-    """The reference's own synthetic test distribution
-    (experiments/diagnostics/test_multi_offset_training.py:65-66)."""
-    rng = np.random.Generator(np.random.PCG64(seed))
-    vol = (0.2 + 0.1 * rng.standard_normal((n_days + C, 5, 5))).astype(np.float32)
-    ex = (0.01 * rng.standard_normal((n_days + C, X))).astype(np.float32) if X else None
-    return vol, ex
+from vsv.synth import init_weights, make_config, synthetic_calendar  # noqa: E402
 
 
 def cpu_baseline(cfg, W, vol, ex, C, H, S, budget_s: float):
@@ -104,11 +103,10 @@ def train_bench(dev, steps: int, cpu_steps: int):
     (surface + 3 extra features, return-only L2 term), batch 64, sequence length drawn per batch
     from [2, 21] (context 1-20 + horizon 1), AdamW(1e-5), the drop-in class's train_step on the
     HIP kernels.  The CPU figure is the torch port's autograd step on the same batches."""
-    from oracle import vsv_oracle as vo
     from vae.cvae_with_mem_randomized import CVAEMemRand
     B = 64
-    cfg = vo.make_config(5, 3, device=str(dev))
-    W = vo.init_weights(cfg, 0, 1.0, np.float32)
+    cfg = make_config(5, 3, device=str(dev))
+    W = init_weights(cfg, 0, 1.0, np.float32)
     torch.manual_seed(0)
     model = CVAEMemRand(dict(cfg))
     model.load_state_dict({k: torch.from_numpy(v) for k, v in W.items()}, strict=False)
@@ -236,12 +234,12 @@ def other_workloads(eng, dev, L, X, C, S):
     return res
 
 
-def main():
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--days", type=int, default=4000, help="days per rank")
+    ap.add_argument("--days", type=int, default=4000, help="days per rank (weak leg) / in total (strong leg)")
     ap.add_argument("--samples", type=int, default=1000)
     ap.add_argument("--context", type=int, default=60)
     ap.add_argument("--horizon", type=int, default=1)
@@ -250,16 +248,70 @@ def main():
     ap.add_argument("--chunk-days", type=int, default=4000, help="days per decode launch")
     ap.add_argument("--cpu-budget", type=float, default=15.0, help="seconds of CPU baseline work (0 = skip)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL)")
+    ap.add_argument("--allow-oversubscribe", action="store_true",
+                    help="let several ranks share one GPU (rehearsals on a 1-GPU box; reported in the output)")
     ap.add_argument("--train-steps", type=int, default=50, help="training steps of the secondary metric (0 = skip)")
     ap.add_argument("--others", type=int, default=1, help="1 = also time the secondary workloads (N=1 only)")
-    args = ap.parse_args()
+    ap.add_argument("--master-port", type=int, default=29611, help="rendezvous port when this script spawns the ranks")
+    ap.add_argument("--dry-run", action="store_true",
+                    help="launcher check only: the ranks rendezvous, count themselves with one all_reduce and rank 0 "
+                         "prints the count; no GPU work (runs on a CPU-only host with --backend gloo)")
+    return ap.parse_args(argv)
 
+
+def spawn_ranks(args, argv):
+    """`python bench.py --gpus N` with no launcher around it: start N ranks through torch.distributed.run
+    as a CHILD process (this parent never initialises a GPU) and return its exit code."""
+    import subprocess
+    n_dev = torch.cuda.device_count()                     # counting devices does not initialise the GPU
+    if n_dev < args.gpus and not args.allow_oversubscribe:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but only {n_dev} GPU(s) are visible "
+                         "(one rank per GPU; --allow-oversubscribe lets ranks share a GPU for rehearsals)")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(args.master_port), os.path.abspath(__file__)] + list(argv)
+    return subprocess.run(cmd, env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")).returncode
+
+
+def check_quantiles(q: "torch.Tensor", what: str):
+    """Size-independent sanity of a reduced (days, H, 3, 5, 5) product: finite and p05 <= p50 <= p95."""
+    if not bool(torch.isfinite(q).all()):
+        raise RuntimeError(f"{what}: non-finite quantiles")
+    if not bool(((q[:, :, 0] <= q[:, :, 1]) & (q[:, :, 1] <= q[:, :, 2])).all()):
+        raise RuntimeError(f"{what}: quantiles out of order")
+
+
+def main(argv=None):
+    argv = sys.argv[1:] if argv is None else argv
+    args = parse_args(argv)
+    launched = "WORLD_SIZE" in os.environ and "RANK" in os.environ
+    if args.gpus > 1 and not launched:
+        raise SystemExit(spawn_ranks(args, argv))
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks")
+    if args.dry_run:
+        import torch.distributed as dist
+        if world > 1:
+            dist.init_process_group("gloo")           # host-side count only
+            t = torch.ones(1)
+            dist.all_reduce(t)
+            seen = int(t.item())
+            dist.destroy_process_group()
+        else:
+            seen = 1
+        if rank == 0:
+            print(json.dumps({"dry_run": True, "n_gpus": world, "ranks": seen}), flush=True)
+        return
     if not torch.cuda.is_available():
         raise RuntimeError("bench.py needs a GPU: the HIP path has no CPU fallback")
-    local_rank %= torch.cuda.device_count()                 # identity on a full node; lets a 1-GPU box rehearse N > 1
+    n_dev = torch.cuda.device_count()
+    if local_rank >= n_dev:
+        if not args.allow_oversubscribe:
+            raise SystemExit(f"bench.py: rank {rank} has no GPU of its own ({n_dev} visible); "
+                             "pass --allow-oversubscribe to share GPUs (rehearsal only)")
+        local_rank %= n_dev
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
@@ -270,23 +322,20 @@ def main():
         else:
             dist.init_process_group(args.backend)
 
-    from oracle import vsv_oracle as vo          # config/weight helpers + the cpu_baseline leg only
-    from vsv import paths
+    from vsv import paths, sharded  # noqa: F401
     from vsv.engine import Engine
-    from vsv.hipevents import Event  # noqa: F401
 
     L, X, C, H, S, N = args.latent, args.ex_feats, args.context, args.horizon, args.samples, args.days
-    cfg = vo.make_config(L, X)
-    W = vo.init_weights(cfg, 0, 1.0, np.float32)
+    cfg = make_config(L, X)
+    W = init_weights(cfg, 0, 1.0, np.float32)
     eng = Engine(cfg, W, dev)
     vol_np, ex_np = synthetic_calendar(N * world, C, X)
     # every rank holds the whole (small) calendar; vsv.sharded gives it its own N-day range
     vol = torch.from_numpy(vol_np).to(dev)
     ex = torch.from_numpy(ex_np).to(dev) if X else None
-    from vsv import sharded
 
-    def one_step(events=None):
-        return sharded.prior_mc_sharded(eng, vol, ex, C, N * world, C, H, S, seed=0, qs=(5, 50, 95), channel=1,
+    def one_step(n_total, events=None):
+        return sharded.prior_mc_sharded(eng, vol, ex, C, n_total, C, H, S, seed=0, qs=(5, 50, 95), channel=1,
                                         chunk_days=args.chunk_days, decode_events=events)
 
     def fence():
@@ -294,19 +343,27 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        one_step()
-    fence()
+    def timed(n_total, events=None):
+        """W untimed + K timed steps over n_total days (split over the ranks); max over ranks of the wall time."""
+        for _ in range(args.warmup):
+            one_step(n_total)
+        fence()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            q = one_step(n_total, events)
+        fence()
+        dt = time.perf_counter() - t0
+        if dist:
+            t = torch.tensor([dt], dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+        check_quantiles(q, f"prior MC over {n_total} days")       # the last step's product, outside the timed region
+        assert q.shape == (n_total, H, 3, 5, 5), q.shape
+        return dt
+
     events = []
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        one_step(events)
-    fence()
-    dt = time.perf_counter() - t0
-    if dist:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+    dt = timed(N * world, events)                                  # weak: N days per GPU
+    dt_strong = timed(N) if world > 1 else dt                      # strong: N days in total
 
     fl = flops_per_unit(L, X)
     k_ms = [a.elapsed_ms(b) for a, b, _ in events]
@@ -328,6 +385,7 @@ def main():
             traffic = None
 
     surfaces = world * N * S * H * args.steps
+    gpus_used = len({r % n_dev for r in range(world)}) if world > n_dev else world
     out = {
         "metric": "MC surfaces/sec (5x5 grid, 1000 samples/day)",
         "value": surfaces / dt,
@@ -344,15 +402,21 @@ def main():
         "config": {"workload": f"BASELINE configs[3]: CVAEMemRand context {C}, latent {L}, ex_feats {X}, prior MC "
                                f"generation, {N} days/GPU x {S} samples x horizon {H}, p05/p50/p95 reduced on device",
                    "days_per_gpu": N, "samples_per_day": S, "context_len": C, "horizon": H,
-                   "chunk_days": args.chunk_days, "parallelism": f"date-range shards x{world}"},
+                   "chunk_days": args.chunk_days, "parallelism": f"date-range shards x{world}",
+                   "backend": (args.backend if world > 1 else None),
+                   "ranks": (dist.get_world_size() if dist else 1), "gpus_used": gpus_used,
+                   "oversubscribed": world > n_dev},
+        "strong": {"workload": f"the same backfill with {N} days IN TOTAL split over the {world} rank(s)",
+                   "value": N * S * H * args.steps / dt_strong, "unit": "surfaces/s",
+                   "ms_per_step": dt_strong / args.steps * 1e3, "scaling": "strong"},
         "roofline": {"bound": "mfma", "kernel": "lstm_kernel<16,2,1,true> (fused MC decode: LSTM steps + decoder head)",
                      "achieved": achieved, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
                      "frac": achieved / PEAK_F32_MFMA_TFLOPS, "traffic": traffic,
                      "flops_per_launch": flops_per_launch, "avg_launch_ms": avg_ms, "launches": len(k_ms)},
     }
-    if rank == 0 and args.cpu_budget > 0:
+    if rank == 0 and world == 1 and args.cpu_budget > 0:
         out["cpu_baseline"] = cpu_baseline(cfg, W, vol_np, ex_np, C, H, S, args.cpu_budget)
-    if rank == 0 and args.train_steps > 0:
+    if rank == 0 and world == 1 and args.train_steps > 0:
         out["train"] = train_bench(dev, args.train_steps, 10 if args.cpu_budget > 0 else 0)
     if world == 1 and args.others:
         out["other_workloads"] = other_workloads(eng, dev, L, X, C, S)

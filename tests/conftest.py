@@ -42,3 +42,33 @@ def cfg_of(g):
             v = g["cfg_" + k]
             cfg[k] = v.item() if v.dtype.kind != "U" else str(v)
     return cfg
+
+
+# ---- achieved-error record: the parity tests assert a tolerance; the margin under it goes on record ----
+_MARGINS = {}
+
+
+def record_margin(value: float, what: str = "max|err|"):
+    """Called by the tests' err() helpers: keeps the largest error every test observed."""
+    test = os.environ.get("PYTEST_CURRENT_TEST", "?").split(" ")[0].split("::", 1)[-1]
+    key = (test, what)
+    if value > _MARGINS.get(key, -1.0):
+        _MARGINS[key] = float(value)
+
+
+def pytest_terminal_summary(terminalreporter):
+    if not _MARGINS:
+        return
+    import json
+    tr = terminalreporter
+    tr.write_sep("-", "achieved parity errors (largest per test)")
+    rows = sorted(_MARGINS.items(), key=lambda kv: -kv[1])
+    for (test, what), v in rows[:40]:
+        tr.write_line(f"{v:10.3e}  {what:10s} {test}")
+    out_dir = os.path.join(REPO, "gpurun_out")
+    try:
+        os.makedirs(out_dir, exist_ok=True)
+        with open(os.path.join(out_dir, "parity_margins.json"), "w") as f:
+            json.dump([{"test": t, "what": w, "err": v} for (t, w), v in rows], f, indent=0)
+    except OSError:
+        pass

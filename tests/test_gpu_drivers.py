@@ -23,7 +23,10 @@ def _n(t):
 def _err(a, b):
     a, b = np.asarray(a, dtype=np.float64), np.asarray(b, dtype=np.float64)
     assert a.shape == b.shape, (a.shape, b.shape)
-    return float(np.max(np.abs(a - b)))
+    from conftest import record_margin
+    e = float(np.max(np.abs(a - b)))
+    record_margin(e)
+    return e
 
 
 def _calendar(n, X, seed=5):

@@ -230,3 +230,21 @@ def test_mem_type_gru_accepted_rnn_rejected():
     # every parameter value lands in the blob exactly once except the summed r/z biases
     tot = sum(float(np.abs(v).sum()) for k, v in W.items() if "bias" not in k and not k.startswith("quantile_loss_fn"))
     assert np.isfinite(blob).all() and float(np.abs(blob).sum()) >= tot * (1 - 1e-5)
+
+
+def test_hidden_widths_run_on_the_built_tile_counts():
+    """The recurrent kernels exist for 13 and 16 gate tiles of 8 hidden units; every other width up to 128 is
+    laid out (zero-padded) on the next built size, and a width beyond 128 is refused where the Engine's
+    dims are made -- not at the first compute call."""
+    from vsv.engine import dims_from_config, pack_state_dict
+    from vsv.train import read_layout
+    for Hm, sh, X, want in ((100, (5, 5, 5), 3, (13, 16)), (64, (3, 3, 3), 0, (13, 13)), (128, (5, 5, 5), 0, (16, 16)),
+                            (8, (4,), 0, (13, 13)), (105, (5, 4, 4), 3, (16, 13))):
+        cfg = vo.make_config(5, X, mem_hidden=Hm, surface_hidden=sh)
+        d = dims_from_config(cfg)
+        lay = read_layout(d)
+        assert (lay["NTm"], lay["NTd"]) == want, (Hm, sh, lay["NTm"], lay["NTd"])
+        blob = pack_state_dict(d, vo.init_weights(cfg, 0, 1.0, np.float32))
+        assert np.isfinite(blob).all()
+    with pytest.raises(NotImplementedError, match="mem_hidden"):
+        dims_from_config(vo.make_config(5, 0, mem_hidden=200))

@@ -95,7 +95,12 @@ int make_layout(const vsv_dims& d, Layout& lay, const char** msg) {
     for (int i = 0; i < d.n_ctx_conv; ++i)
         if (d.ctx_surface_hidden[i] < 1 || d.ctx_surface_hidden[i] * 25 + lay.X > kMaxFeat)
             return fail("ctx_surface_hidden[i]*25 + ex_feats_dim must be <= 128");
-    lay.NTm = cdiv(lay.Hm, 8);
+    // gate tiles of 8 hidden units.  The recurrent kernels are built for 13 and 16 tiles (hidden 97..104 and
+    // 121..128, the widths of every reference config); any other width runs on the next built size: the
+    // extra units have all-zero weights and biases, so their gates are sigmoid(0) / tanh(0), their c and h
+    // stay exactly 0 and nothing reads them (zero columns downstream)
+    auto built_tiles = [](int nt) { return nt <= 13 ? 13 : 16; };
+    lay.NTm = built_tiles(cdiv(lay.Hm, 8));
     const int c_last = d.surface_hidden[d.n_conv - 1];
     if (lay.X > 0) {
         // the kernels look for the ex-feature slots only in the last (4th) tile of a layer
@@ -105,7 +110,7 @@ int make_layout(const vsv_dims& d, Layout& lay, const char** msg) {
             return fail("with ex_feats_dim > 0 the last conv layers need >= 4 channels (ex slots live in features 96..127)");
     }
     lay.Hd = c_last * 25 + lay.X;
-    lay.NTd = cdiv(lay.Hd, 8);
+    lay.NTd = built_tiles(cdiv(lay.Hd, 8));
 
     size_t cur = 0;
     for (int which = 0; which < 2; ++which) {
@@ -250,9 +255,8 @@ static std::vector<float> conv_matrix(const float* w, int cin, int cout, bool tr
 // recurrent parts like an LSTM gate; the candidate's two halves stay apart -- n_x = W_in x + b_in has
 // zero recurrent columns, n_h = W_hn h + b_hn zero input columns -- because the cell needs
 // n = tanh(n_x + r * n_h).  Row code g*H + u as for the LSTM (g = slot).
-static void pack_gru(float* blob, const Sec* secs, const vsv_lstm_raw& raw, int NL, int H, int in0,
+static void pack_gru(float* blob, const Sec* secs, const vsv_lstm_raw& raw, int NL, int H, int NT, int in0,
                      int kx, const InMap& x_map) {
-    const int NT = (H + 7) / 8;
     for (int l = 0; l < NL; ++l) {
         const float *wih = raw.w_ih[l], *whh = raw.w_hh[l], *bih = raw.b_ih[l], *bhh = raw.b_hh[l];
         const int n_in = (l == 0) ? in0 : H;
@@ -279,9 +283,8 @@ static void pack_gru(float* blob, const Sec* secs, const vsv_lstm_raw& raw, int 
     }
 }
 
-static void pack_lstm(float* blob, const Sec* secs, const vsv_lstm_raw& raw, int NL, int H, int in0,
+static void pack_lstm(float* blob, const Sec* secs, const vsv_lstm_raw& raw, int NL, int H, int NT, int in0,
                       int kx, const InMap& x_map) {
-    const int NT = (H + 7) / 8;
     for (int l = 0; l < NL; ++l) {
         const float *wih = raw.w_ih[l], *whh = raw.w_hh[l], *bih = raw.b_ih[l], *bhh = raw.b_hh[l];
         const int n_in = (l == 0) ? in0 : H;
@@ -390,7 +393,7 @@ extern "C" int vsv_pack_weights(const vsv_dims* dims, const vsv_raw_weights* raw
             pack_sec(out, e.conv[e.n_conv + j], out_nat32(E), in_perm(E), W, B);
         }
         const vsv_lstm_raw& mem = which ? raw->ctx_mem : raw->enc_mem;
-        (lay.gru ? pack_gru : pack_lstm)(out, e.lstm, mem, lay.NL, Hm, e.E, e.kx, in_perm(e.E));
+        (lay.gru ? pack_gru : pack_lstm)(out, e.lstm, mem, lay.NL, Hm, lay.NTm, e.E, e.kx, in_perm(e.E));
         if (which == 0) {
             const float *wm = raw->z_mean_w, *bm = raw->z_mean_b, *wv = raw->z_log_var_w, *bv = raw->z_log_var_b;
             WFn W = [=](int r, int c) { return r < L ? wm[(size_t)r * Hm + c] : wv[(size_t)(r - L) * Hm + c]; };
@@ -406,7 +409,7 @@ extern "C" int vsv_pack_weights(const vsv_dims* dims, const vsv_raw_weights* raw
 
     const DecLayout& dc = lay.dec;
     const int Hd = lay.Hd;
-    (lay.gru ? pack_gru : pack_lstm)(out, dc.lstm, raw->dec_mem, lay.NL, Hd, 2 * L, dc.kx, in_nat(2 * L));
+    (lay.gru ? pack_gru : pack_lstm)(out, dc.lstm, raw->dec_mem, lay.NL, Hd, lay.NTd, 2 * L, dc.kx, in_nat(2 * L));
     int hi = 0;
     const int c_last = d.surface_hidden[d.n_conv - 1];
     for (int j = 0; j < lay.NI; ++j) {

@@ -38,6 +38,19 @@ def _rank():
     return dist.get_rank() if dist.is_available() and dist.is_initialized() else 0
 
 
+def _shared_seed(model) -> int:
+    """The Philox key of one generation product.  Philox counters are keyed by the GLOBAL day index, so a
+    product is the same for any world size -- provided every rank uses the same key: each rank draws from
+    its own torch generator (which keeps the generators in step), and rank 0's draw is broadcast."""
+    import torch.distributed as dist
+    seed = model._draw_seed()
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        box = [seed]
+        dist.broadcast_object_list(box, src=0)
+        seed = int(box[0])
+    return seed
+
+
 def _sharded_pair(fn, n_days):
     """fn(lo, hi) -> (surf, ex|None) on this rank's day range; gathers both over the ranks."""
     has_ex = []
@@ -86,7 +99,7 @@ def generate_surfaces_multiday(model_data, ex_data, vol_surface_data, start_day,
     eng, vol, ex = _arrays(model, vol_surface_data, ex_data)
     if eng.Q < 3:
         raise ValueError("generate_surfaces_multiday expects the 3-quantile decoder [p05, p50, p95]")
-    seed = model._draw_seed()
+    seed = _shared_seed(model)
 
     def fn(lo, hi):
         s, e = paths.prior_windows(eng, vol, ex, start_day + lo, hi - lo, ctx_len, model.horizon, 1, seed=seed)
@@ -123,7 +136,7 @@ def mc_generate_surfaces_multiday(model_data, ex_data, vol_surface_data, start_d
     if ctx_len is None:
         ctx_len = model.config["ctx_len"]
     eng, vol, ex = _arrays(model, vol_surface_data, ex_data)
-    seed = model._draw_seed()
+    seed = _shared_seed(model)
 
     def fn(lo, hi):
         s, e = paths.prior_windows(eng, vol, ex, start_day + lo, hi - lo, ctx_len, 1, num_vaes, seed=seed)
@@ -155,7 +168,7 @@ def generate_and_save_horizon(model, vol_surf, ex_data, period_start, period_end
     if n <= 0:
         return None
     eng, vol, ex = _arrays(model, vol_surf, ex_data)
-    seed = model._draw_seed()
+    seed = _shared_seed(model)
     gen = paths.oracle_windows if sampling_mode == "oracle" else paths.prior_windows
 
     def fn(lo, hi):
@@ -191,7 +204,7 @@ def generate_and_save_ar_sequences(model, vol_surf, ex_data, period_start, perio
     if n <= 0:
         return None
     eng, vol, ex = _arrays(model, vol_surf, ex_data)
-    seed = model._draw_seed()
+    seed = _shared_seed(model)
 
     def fn(lo, hi):
         s, _ = paths.ar_offset_windows(eng, vol, ex, min_start + lo, hi - lo, context_len, ar_steps, horizon, seed=seed)

@@ -27,10 +27,15 @@ def dims_from_config(cfg: dict) -> _lib.VsvDims:
         raise NotImplementedError("HIP path implements ex_feats_hidden=None only")
     if tuple(cfg["feat_dim"]) != (5, 5):
         raise NotImplementedError("HIP path implements the 5x5 grid only")
-    return _lib.make_dims(cfg["latent_dim"], cfg["ex_feats_dim"], cfg["mem_hidden"], cfg["mem_layers"],
+    dims = _lib.make_dims(cfg["latent_dim"], cfg["ex_feats_dim"], cfg["mem_hidden"], cfg["mem_layers"],
                           list(cfg["surface_hidden"]), list(cfg["ctx_surface_hidden"]),
                           len(cfg.get("quantiles", [0.05, 0.5, 0.95])), cfg.get("interaction_layers") or 0,
                           cfg.get("mem_type", "lstm"))
+    # shapes the kernels cannot run are refused here, when the model / Engine is built, not at the first launch
+    L = _lib.load()
+    if L.vsv_packed_floats(C.byref(dims)) == 0:
+        raise NotImplementedError("HIP path: unsupported model shape: " + L.vsv_last_error().decode())
+    return dims
 
 
 def _fp(a: np.ndarray):
@@ -291,7 +296,8 @@ class Engine:
 
     def pre_table_floats(self, n_rows: int) -> int:
         """floats of one day's pre-activation table for n_rows rows: [32 * NTm gate values][rows padded to 32]."""
-        return 32 * ((self.dims.mem_hidden + 7) // 8) * (((n_rows + 31) // 32) * 32)
+        ntm = int(self.lib.vsv_enc_state_floats(C.byref(self.dims))) // (16 * self.dims.mem_layers)   # gate tiles as built
+        return 32 * ntm * (((n_rows + 31) // 32) * 32)
 
     def encode_pre(self, which, surf, surf_rs, ex, ex_rs, n_rows, pre_out: torch.Tensor):
         """vsv_encode_pre: the position-independent part of encoder `which` (embedding + first-layer input

@@ -110,6 +110,18 @@ def _context_prefix(eng: Engine, sv: torch.Tensor, se: Optional[torch.Tensor], n
     return pre["state"], pre["gates"]
 
 
+def _empty_quantiles(eng: Engine, horizon: int, nq: int, channel: Optional[int]) -> torch.Tensor:
+    """The reduced product of an empty day range (a rank of a sharded run that owns no day)."""
+    shape = (0, horizon, nq, 5, 5) if channel is not None else (0, horizon, nq, eng.Q, 5, 5)
+    return torch.empty(shape, dtype=torch.float32, device=eng.device)
+
+
+def _empty_samples(eng: Engine, lead: tuple):
+    s = torch.empty(lead + (eng.Q, 5, 5), dtype=torch.float32, device=eng.device)
+    e = torch.empty(lead + (eng.X,), dtype=torch.float32, device=eng.device) if eng.X > 0 else None
+    return s, e
+
+
 def prior_mc_windows(eng: Engine, vol: torch.Tensor, ex: Optional[torch.Tensor], first_day: int, n_days: int,
                      ctx_len: int, horizon: int, n_samples: int, seed: int = 0,
                      qs: Sequence[float] = (5, 50, 95), channel: Optional[int] = 1,
@@ -133,6 +145,8 @@ def prior_mc_windows(eng: Engine, vol: torch.Tensor, ex: Optional[torch.Tensor],
     if day_index0 is None:
         day_index0 = first_day
     L, Q = eng.L, eng.Q
+    if n_days == 0:
+        return _empty_quantiles(eng, horizon, len(qs), channel)
     if not chunk_days:
         # as many days per decode launch as fit 2 GiB of samples: a launch ends with a partly filled
         # round of workgroups (512 resident at a time), so fewer, longer launches waste less
@@ -180,6 +194,8 @@ def prior_windows(eng: Engine, vol: torch.Tensor, ex: Optional[torch.Tensor], fi
     if day_index0 is None:
         day_index0 = first_day
     L, Q, X, S = eng.L, eng.Q, eng.X, n_samples
+    if n_days == 0:
+        return _empty_samples(eng, (0, S, horizon))
     w0 = first_day - ctx_len
     enc, ctx = eng.encode_both_windows(vol[w0:], ex[w0:] if X > 0 else None, n_days, ctx_len)
     zm = enc[..., :L].contiguous()
@@ -212,6 +228,8 @@ def oracle_windows(eng: Engine, vol: torch.Tensor, ex: Optional[torch.Tensor], f
     if day_index0 is None:
         day_index0 = first_day
     L, Q, X, S = eng.L, eng.Q, eng.X, n_samples
+    if n_days == 0:
+        return _empty_samples(eng, (0, S, horizon))
     w0 = first_day - ctx_len
     enc, ctx = eng.encode_both_windows(vol[w0:], ex[w0:] if X > 0 else None, n_days, T, ctx_len)
     zm, zl = enc[..., :L].contiguous(), enc[..., L:].contiguous()
@@ -240,6 +258,8 @@ def ar_offset_windows(eng: Engine, vol: torch.Tensor, ex: Optional[torch.Tensor]
         ex = ex.to(device=eng.device, dtype=torch.float32).contiguous()
     if day_index0 is None:
         day_index0 = first_day
+    if n_days == 0:
+        return _empty_samples(eng, (0, ar_steps * horizon))
     outs_s, outs_e = [], []
     for d0 in range(0, n_days, chunk_days):
         nd = min(chunk_days, n_days - d0)
@@ -374,6 +394,8 @@ def ar_mc_windows(eng: Engine, vol: torch.Tensor, ex: Optional[torch.Tensor], fi
     if day_index0 is None:
         day_index0 = first_day
     Q, S = eng.Q, n_samples
+    if n_days == 0:
+        return _empty_quantiles(eng, horizon, len(qs), channel)
     outs = []
     for d0 in range(0, n_days, chunk_days):
         nd = min(chunk_days, n_days - d0)
@@ -411,6 +433,8 @@ def oracle_mc_windows(eng: Engine, vol: torch.Tensor, ex: Optional[torch.Tensor]
     if day_index0 is None:
         day_index0 = first_day
     L, Q, X = eng.L, eng.Q, eng.X
+    if n_days == 0:
+        return _empty_quantiles(eng, horizon, len(qs), channel)
     w0 = first_day - ctx_len
     sv = vol[w0:]
     se = ex[w0:] if X > 0 else None

@@ -308,7 +308,8 @@ class TrainEngine:
                 a.dx_tile, a.dx_rows, a.dx_f = _ptr(dx_tile), _ptr(dx_rows), dx_f
             if layers != NL:
                 a.sv_nl, a.sv_l0 = NL, l0
-            _lib.check(self.lib.vsv_lstm_backward(C.byref(a), hidden, layers, st), "vsv_lstm_backward")
+            # (8 * NT: the hidden width as built -- widths between the built tile counts run zero-padded)
+            _lib.check(self.lib.vsv_lstm_backward(C.byref(a), 8 * NT, layers, st), "vsv_lstm_backward")
 
         def off_loop(name, l, out_tile, out_rows, out_f, drop_layer):
             w, nq, nt = self._wT(blobT, name)

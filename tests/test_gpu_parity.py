@@ -624,7 +624,8 @@ def test_segmented_context_prefix_equals_single_launches():
             assert float((s1 - s2).abs().max()) <= 1e-6 and float((g1 - g2).abs().max()) <= 1e-6, (mem, n_seg)
 
 
-@pytest.mark.parametrize("Hm,sh,X,mem", [(64, (3, 3, 3), 0, "lstm"), (48, (5, 4, 4), 3, "lstm"), (80, (4, 4), 0, "gru")])
+@pytest.mark.parametrize("Hm,sh,X,mem", [(64, (3, 3, 3), 0, "lstm"), (48, (5, 4, 4), 3, "lstm"), (80, (4, 4), 0, "gru"),
+                                          (100, (5, 5, 3), 0, "lstm")])
 def test_hidden_widths_between_built_tile_counts(Hm, sh, X, mem):
     """the recurrent kernels are built for 13 and 16 gate tiles; any other hidden width runs
     zero-padded on the next built size (vsv_pack.cpp make_layout).  Forward, prior generation and the

@@ -354,16 +354,25 @@ class TrainEngine:
         dh = self._dense_bwd(c, [dict(wT=w, nqT=nq, ntT=nt, n_relu=0, g_out=gh.data_ptr())], Tw, 0, d_out,
                              d_out.shape[-1], True)
         self._acc_layer(c, e["head"], gh[:, : 16 * e["head"].nt], sv["hout"])
-        dxt = self._e(rt * Tw, 64, 64)
-        dgl = self._lstm_bwd(c, pf, self.Hm, NTm, sv, Tw, 0, dh, e["kx"] // 16, sv["drop_id"], dx_tile=dxt)
+        kx = e["kx"]
+        # (an embedding narrower than four tiles -- fewer than 4 channels in the last conv layer -- leaves the
+        # top slots of the 64-slot instance unwritten: they must read as zero)
+        dxt = self._e(rt * Tw, 64, 64) if kx == 64 else self._z(rt * Tw, 64, 64)
+        dgl = self._lstm_bwd(c, pf, self.Hm, NTm, sv, Tw, 0, dh, kx // 16, sv["drop_id"], dx_tile=dxt)
         self._lstm_wgrads(c, gp, e["lstm"], sv, dgl, Tw, NTm, sv["xe"])
         nc = self.n_conv[which]
+        # the chain's last output as the backward kernel reads activations: 64 slots per instance (the LSTM's
+        # x operand is stored kx slots per instance)
+        xe_act = sv["xe"]
+        if kx < 64:
+            xe_act = self._z(rt * Tw, 64, 64)
+            xe_act[:, :kx] = sv["xe"]
         layers, gs = [], []
         for li in range(nc - 1, -1, -1):
             g = self._e(rt * Tw, 64, 64)
             gs.append((li, g))
             ly = dict(ntT=0, nqT=0, n_relu=e["conv"][li].n_relu, g_out=g.data_ptr(),
-                      act_out=(sv["xe"] if li == nc - 1 else sv["emb_acts"][li + 1]).data_ptr())
+                      act_out=(xe_act if li == nc - 1 else sv["emb_acts"][li + 1]).data_ptr())
             if li > 0 or want_dsurf:
                 ly["wT"], ly["nqT"], ly["ntT"] = self._wT(blobT, f"{pf}.conv{li}")
             layers.append(ly)

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define VSV_ABI_VERSION 13
+#define VSV_ABI_VERSION 14
 #define VSV_MAX_CONV 4
 #define VSV_MAX_CHAIN 8
 #define VSV_MAX_INTERACT 3
@@ -156,6 +156,19 @@ int vsv_encode_windows(const vsv_dims *dims, const float *packed, int which, con
 int vsv_encode_windows_state(const vsv_dims *dims, const float *packed, int which, const float *vol, const float *ex,
                              long n_windows, int T, const float *state_in, float *state_out,
                              float *out, void *ws, size_t ws_bytes, void *stream);
+
+/* The one entry point that allocates nothing and needs no caller workspace.  NO COUNTERPART IN THE REFERENCE:
+ * it exists for callers that cannot allocate device memory -- code under HIP graph capture, tight serving
+ * loops, harnesses that forbid hipMalloc.  Same computation and results as vsv_encode_windows (bit for bit);
+ * the workspace is a device array built into the library, VSV_NOALLOC_SCRATCH_BYTES per GPU, held from the
+ * library's first use on that GPU until the process ends.  Requests whose vsv_encode_windows_ws_bytes exceed
+ * it are refused with -6 (e.g. 512 windows x 60 steps fit, 4000 x 60 do not).  The call makes no hipMalloc /
+ * hipFree and calls no allocating routine; its first call on a device looks the array's address up
+ * (hipGetSymbolAddress).  All calls on one GPU share that GPU's array: calls that overlap on one GPU (two
+ * streams, two threads) race -- serialise them. */
+#define VSV_NOALLOC_SCRATCH_BYTES (16u << 20)
+int vsv_encode_windows_noalloc(const vsv_dims *dims, const float *packed, int which, const float *vol, const float *ex,
+                               long n_windows, int T, float *out, void *stream);
 
 /* ---- decoder ---------------------------------------------------------------
  * CVAEMemRandDecoder.forward (cvae_with_mem_randomized.py:482-514) over T steps

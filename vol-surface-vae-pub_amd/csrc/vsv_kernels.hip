@@ -20,6 +20,7 @@
 #include <cmath>
 #include <cstdint>
 #include <cstdio>
+#include <mutex>
 
 #include "vsv_layout.h"
 
@@ -1946,6 +1947,56 @@ static int encode_windows_impl(const vsv_dims* dims, const float* packed, int wh
     h.out_mode = 1; h.out = out; h.out_f = e.nh; h.S = 1;
     h.aux_layer = -1;
     return launch_dense_chain(h, st);
+}
+
+// ---- the one entry point that allocates nothing, for callers that cannot call hipMalloc (code under HIP graph
+// capture, tight serving loops, harnesses that forbid allocation): vsv_encode_windows with its workspace in a
+// file-scope device array instead of a caller buffer.  Each GPU holds its own copy of the array at its own
+// address; the address is looked up once per device (first call on that device) and kept.  Host code only
+// ever uses that looked-up pointer -- the array's name is a host-side stand-in, not a device address.
+static __device__ __align__(256) unsigned char g_noalloc_scratch[VSV_NOALLOC_SCRATCH_BYTES];
+
+namespace {
+constexpr int kMaxDevices = 64;
+std::mutex g_scratch_mu;
+void* g_scratch_ptr[kMaxDevices] = {};
+
+int noalloc_scratch(void** out) {
+    int dev = -1;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) { set_error("vsv_encode_windows_noalloc: hipGetDevice: %s", hipGetErrorString(e)); return (int)e; }
+    if (dev < 0 || dev >= kMaxDevices) { set_error("vsv_encode_windows_noalloc: device %d out of range", dev); return -1; }
+    std::lock_guard<std::mutex> lk(g_scratch_mu);
+    if (!g_scratch_ptr[dev]) {
+        void* p = nullptr;
+        e = hipGetSymbolAddress(&p, HIP_SYMBOL(g_noalloc_scratch));          // this device's copy (it is current)
+        if (e != hipSuccess || !p) {
+            set_error("vsv_encode_windows_noalloc: hipGetSymbolAddress: %s", hipGetErrorString(e));
+            return e != hipSuccess ? (int)e : -1;
+        }
+        g_scratch_ptr[dev] = p;
+    }
+    *out = g_scratch_ptr[dev];
+    return 0;
+}
+}  // namespace
+
+extern "C" int vsv_encode_windows_noalloc(const vsv_dims* dims, const float* packed, int which, const float* vol,
+                                          const float* ex, long n_windows, int T, float* out, void* stream) {
+    if (!dims || n_windows < 0 || T < 0) { set_error("vsv_encode_windows_noalloc: bad arguments"); return -1; }
+    const size_t need = vsv_encode_windows_ws_bytes(dims, n_windows, T);
+    if (need == 0) { set_error("vsv_encode_windows_noalloc: unsupported model shape"); return -1; }
+    if (need > (size_t)VSV_NOALLOC_SCRATCH_BYTES) {
+        set_error("vsv_encode_windows_noalloc: %ld windows x %d steps need %zu bytes of scratch, the built-in buffer holds "
+                  "%zu (use vsv_encode_windows with a caller workspace)", n_windows, T, need, (size_t)VSV_NOALLOC_SCRATCH_BYTES);
+        return -6;
+    }
+    void* ws = nullptr;
+    if (int rc = noalloc_scratch(&ws)) return rc;
+    // every word of the workspace that a kernel reads is written earlier in the same call (embedding table, gate
+    // pre-activations, hidden states): nothing has to start at zero, whatever the previous call left behind
+    return encode_windows_impl(dims, packed, which, vol, ex, n_windows, T, nullptr, nullptr, out, ws,
+                               (size_t)VSV_NOALLOC_SCRATCH_BYTES, stream);
 }
 
 static int encode_impl(const vsv_dims* dims, const float* packed, int which,

@@ -142,6 +142,8 @@ SIGNATURES = {
     "vsv_encode_windows_ws_bytes": (C.c_size_t, [C.POINTER(VsvDims), C.c_long, C.c_int]),
     "vsv_encode_windows": (C.c_int, [C.POINTER(VsvDims), C.c_void_p, C.c_int, C.c_void_p, C.c_void_p,
                                      C.c_long, C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "vsv_encode_windows_noalloc": (C.c_int, [C.POINTER(VsvDims), C.c_void_p, C.c_int, C.c_void_p, C.c_void_p,
+                                             C.c_long, C.c_int, C.c_void_p, C.c_void_p]),
     "vsv_enc_state_floats": (C.c_size_t, [C.POINTER(VsvDims)]),
     "vsv_encode_state": (C.c_int, [C.POINTER(VsvDims), C.c_void_p, C.c_int,
                                    C.c_void_p, C.c_long, C.c_long, C.c_void_p, C.c_long, C.c_long,
@@ -206,7 +208,7 @@ def load() -> C.CDLL:
             fn = getattr(lib, name)
             fn.restype = res
             fn.argtypes = args
-        if lib.vsv_abi_version() != 13:
+        if lib.vsv_abi_version() != 14:
             raise RuntimeError("libvsv_hip.so ABI version mismatch")
         _lib = lib
     return _lib

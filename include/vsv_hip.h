@@ -240,6 +240,16 @@ int vsv_percentile(const float *in, long n_vec, int S, const double *q_host, int
 int vsv_philox_normal(uint64_t seed, long day0, long n_days, long S, int step0, int n_steps,
                       int L, float *out, void *stream);
 
+/* Latents from the Gaussian mixture fitted to the aggregated posterior -- CVAEMemRand._sample_from_fitted_prior
+ * (cvae_with_mem_randomized.py:605-640; parameters as written by analysis_code/fit_aggregated_posterior.py:139-155):
+ * component c ~ multinomial(weights), z = means[c] + chol[c] . eps with chol the lower Cholesky factor of the
+ * component's covariance.  means (K, L), chol (K, L, L), cdf (K) = cumulative weights, all float32 on the device;
+ * z_out (n, L); comp_out (n) int32 or NULL.  comp_in (n, int32) / eps_in (n, L) inject the draws (parity with the
+ * reference's torch.multinomial / torch.randn); NULL draws them from Philox4x32-10 keyed by (seed; sample index).
+ * L <= 16. */
+int vsv_gmm_sample(const float *means, const float *chol, const float *cdf, int K, int L, long n,
+                   const int *comp_in, const float *eps_in, uint64_t seed, float *z_out, int *comp_out, void *stream);
+
 /* ---- training ---------------------------------------------------------------------
  * CVAEMemRand.train_step / train_step_multihorizon / test_step
  * (cvae_with_mem_randomized.py:1076-1308) split into: forward passes that keep the

@@ -11,4 +11,4 @@ import sys as _sys
 # arithmetic); the package never imports the oracle
 _PKG = _os.path.join(_os.path.dirname(_os.path.dirname(_os.path.abspath(__file__))), "vol-surface-vae-pub_amd")
 if _PKG not in _sys.path:
-    _sys.path.insert(0, _PKG)
+    _sys.path.append(_PKG)          # appended, never first: make_goldens.py must keep importing the REFERENCE's `vae`

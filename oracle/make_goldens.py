@@ -27,6 +27,9 @@ import torch  # noqa: E402
 
 from oracle import vsv_oracle as vo  # noqa: E402
 from vae.cvae_with_mem_randomized import CVAEMemRand, QuantileLoss  # noqa: E402  (the reference)
+import vae as _ref_vae  # noqa: E402
+
+assert os.path.abspath(_ref_vae.__path__[0]).startswith("/root/reference"), "goldens must come from the reference's vae package"
 
 OUT = os.path.join(REPO, "tests", "golden")
 
@@ -551,6 +554,7 @@ def main():
     main_ar_train()
     main_interaction()
     main_gru()
+    main_round2()
 
 
 def case_sampler():
@@ -588,6 +592,82 @@ def main_training():
                       33, 2.0, 4, 50, [1, 7, 14, 30])
 
 
+# ---- round 2: z = 0 "maximum likelihood" generation driver, fitted-GMM prior ------------------------------
+
+def case_mle(name, cfg, seed, scale, n_days, C, check_ex):
+    """G11: the reference's generate_surfaces_multiday_mle (generate_surfaces_max_likelihood.py:61-103) on a
+    synthetic calendar: one z = 0 generation per day from the window [day - C, day).  Deterministic (the only
+    noise the reference draws, the encoder's reparameterisation sample, is discarded by :700)."""
+    import generate_surfaces_max_likelihood as ref_mle              # the reference's module
+    torch.set_default_dtype(torch.float64)
+    model, W = build_reference(cfg, seed, scale, np.float64)
+    rng = np.random.Generator(np.random.PCG64(9000 + seed))
+    X = cfg["ex_feats_dim"]
+    vol = 0.2 + 0.1 * rng.standard_normal((n_days + C, 5, 5))
+    ex = 0.01 * rng.standard_normal((n_days + C, max(X, 1)))
+    mcfg = dict(cfg)
+    model_data = {"model_config": mcfg, "model": model.state_dict()}
+    (p05, p50, p95), exo = ref_mle.generate_surfaces_multiday_mle(model_data, ex, vol, C, n_days, 1, model_type=CVAEMemRand,
+                                                                  check_ex_feats=check_ex, ctx_len=C)
+    d = dict(vol=vol, ex=ex, p05=p05, p50=p50, p95=p95, ex_out=exo, ctx_len=C, start_day=C, n_days=n_days,
+             check_ex_feats=int(check_ex), seed=seed, scale=scale)
+    save(name, cfg, d)
+
+
+def case_gmm(name, cfg, seed, scale, B, C, H, K):
+    """G12: _sample_from_fitted_prior (:605-640) and get_surface_given_conditions(prior_mode="fitted")
+    (:689-691) with torch.multinomial and torch.randn patched to stored draws."""
+    import tempfile
+    torch.set_default_dtype(torch.float64)
+    model, W = build_reference(cfg, seed, scale, np.float64)
+    rng = np.random.Generator(np.random.PCG64(9100 + seed))
+    L, X = cfg["latent_dim"], cfg["ex_feats_dim"]
+    means = rng.standard_normal((K, L))
+    A = rng.standard_normal((K, L, L)) * 0.3
+    cov = A @ A.transpose(0, 2, 1) + 0.05 * np.eye(L)[None]
+    wts = rng.random(K) + 0.2
+    wts /= wts.sum()
+    with tempfile.TemporaryDirectory() as td:
+        path = os.path.join(td, "gmm.pt")
+        torch.save({"means": torch.from_numpy(means), "covariances": torch.from_numpy(cov),
+                    "weights": torch.from_numpy(wts), "n_components": K}, path)
+        model.load_fitted_prior(path)
+    surf, ex = synth(rng, B, C, X, np.float64)
+    T = C + H
+    comp = rng.choice(K, size=B * T, p=wts).astype(np.int64)
+    eps = rng.standard_normal((B * T, L))
+    c = {"surface": torch.from_numpy(surf)}
+    if X:
+        c["ex_feats"] = torch.from_numpy(ex)
+    real_multinomial = torch.multinomial
+    torch.multinomial = lambda w, num_samples, **kw: torch.from_numpy(comp)[:, None]
+    try:
+        with NoiseQueue() as nq:
+            nq.push(eps)
+            z = model._sample_from_fitted_prior(B, T)
+        with NoiseQueue() as nq:
+            nq.push(eps)
+            nq.push(rng.standard_normal((B, C, L)))          # the encoder's own reparameterisation draw (discarded, :700)
+            out = model.get_surface_given_conditions(c, horizon=H, prior_mode="fitted")
+    finally:
+        torch.multinomial = real_multinomial
+    d = dict(surface=surf, means=means, covariances=cov, weights=wts, comp=comp, eps=eps, z=t2n(z), horizon=H,
+             seed=seed, scale=scale)
+    if X:
+        d.update(ex_feats=ex, surf_out=t2n(out[0]), ex_out=t2n(out[1]))
+    else:
+        d.update(surf_out=t2n(out))
+    save(name, cfg, d)
+
+
+def main_round2():
+    case_mle("g11_mle_ex5_C5_N40", vo.make_config(5, 3), 40, 2.0, 40, 5, True)
+    case_mle("g11_mle_noex_C20_N33", vo.make_config(5, 0), 41, 2.0, 33, 20, False)
+    case_mle("g11_mle_ex12_C60_N35", vo.make_config(12, 3), 42, 2.0, 35, 60, False)
+    case_gmm("g12_gmm_ex5_C8_H4_K3", vo.make_config(5, 3), 43, 2.0, 6, 8, 4, 3)
+    case_gmm("g12_gmm_noex12_C20_H7_K5", vo.make_config(12, 0), 44, 2.0, 4, 20, 7, 5)
+
+
 if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "training":
         os.makedirs(OUT, exist_ok=True)
@@ -601,6 +681,9 @@ if __name__ == "__main__":
     elif len(sys.argv) > 1 and sys.argv[1] == "artrain":
         os.makedirs(OUT, exist_ok=True)
         main_ar_train()
+    elif len(sys.argv) > 1 and sys.argv[1] == "round2":
+        os.makedirs(OUT, exist_ok=True)
+        main_round2()
     elif len(sys.argv) > 1 and sys.argv[1] == "cprior":
         os.makedirs(OUT, exist_ok=True)
         main_cprior()

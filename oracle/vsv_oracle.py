@@ -371,6 +371,27 @@ def get_surface_given_conditions(W: Weights, cfg: dict, ctx_surface: np.ndarray,
     return s[:, C:], (None if e is None else e[:, C:])
 
 
+def gmm_sample(means: np.ndarray, covariances: np.ndarray, comp: np.ndarray, eps: np.ndarray) -> np.ndarray:
+    """CVAEMemRand._sample_from_fitted_prior (cvae_with_mem_randomized.py:605-640) given the component picks
+    (torch.multinomial, :627-630) and the standard normal draws (:637): z = means[c] + chol[c] @ eps, chol the
+    lower Cholesky factor (:602).  means (K,L), covariances (K,L,L), comp (n,), eps (n,L) -> (n,L)."""
+    chol = np.linalg.cholesky(covariances)
+    return means[comp] + np.einsum("bij,bj->bi", chol[comp], eps)
+
+
+def generate_surfaces_multiday_mle(W: Weights, cfg: dict, vol: np.ndarray, ex: Optional[np.ndarray], start_day: int,
+                                   n_days: int, ctx_len: int):
+    """generate_surfaces_max_likelihood.py:13-103: for every day one z = 0 generation from the window
+    [day - ctx_len, day) (z of shape (1, ctx_len + 1, L): horizon 1; the context positions are overwritten by
+    the posterior mean, :700).  -> (p05, p50, p95) each (n_days, 5, 5), ex_feats (n_days, X) or None."""
+    L, X = cfg["latent_dim"], cfg["ex_feats_dim"]
+    win = np.stack([vol[d - ctx_len:d] for d in range(start_day, start_day + n_days)])
+    wex = np.stack([ex[d - ctx_len:d] for d in range(start_day, start_day + n_days)]) if X > 0 else None
+    z = np.zeros((n_days, ctx_len + 1, L), dtype=vol.dtype)
+    s, e = get_surface_given_conditions(W, cfg, win, wex, z, 1)
+    return (s[:, 0, 0], s[:, 0, 1], s[:, 0, 2]), (e[:, 0] if X > 0 else None)
+
+
 def prior_mc_shared_prefix(W: Weights, cfg: dict, ctx_surface: np.ndarray,
                            ctx_ex: Optional[np.ndarray], z_future: np.ndarray):
     """Same result as get_surface_given_conditions called with the context

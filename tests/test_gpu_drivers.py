@@ -158,3 +158,99 @@ def test_sequence_npz_products(tmp_path):
                             "sampling_mode", "context_len"}
     assert d["surfaces"].shape == (3, 180, 3, 5, 5) and np.array_equal(d["indices"], [6, 7, 8])
     assert str(d["method"]) == "autoregressive_multistep" and int(d["context_len"]) == 6
+
+
+# ---- round 2: z = 0 driver and fitted-GMM prior against the reference's own outputs (goldens g11 / g12) ----
+
+def _golden_model(g, device="cuda:0"):
+    from conftest import cfg_of
+    from vae.cvae_with_mem_randomized import CVAEMemRand
+    cfg = cfg_of(g)
+    cfg["device"] = device
+    W = vo.init_weights(cfg, int(g["seed"]), float(g["scale"]), np.float32)
+    model = CVAEMemRand(dict(cfg))
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in W.items()}, strict=False)
+    model.eval()
+    return model, cfg
+
+
+@pytest.mark.parametrize("name", ["g11_mle_ex5_C5_N40", "g11_mle_noex_C20_N33", "g11_mle_ex12_C60_N35"])
+def test_mle_driver_vs_reference(name, tmp_path):
+    """generate_surfaces_multiday_mle / generate_surfaces_mle (generate_surfaces_max_likelihood.py:13-103) and the
+    generate_quantile_surfaces.py products against the reference's run on the same synthetic calendar."""
+    from conftest import load_golden
+    import generate_surfaces_max_likelihood as mle              # the import-path mirror
+    from vsv import drivers
+    g = load_golden(name)
+    model, cfg = _golden_model(g)
+    C, N, start = int(g["ctx_len"]), int(g["n_days"]), int(g["start_day"])
+    chk = bool(int(g["check_ex_feats"]))
+    (p05, p50, p95), ex = mle.generate_surfaces_multiday_mle(model, g["ex"], g["vol"], start, N, 1, check_ex_feats=chk, ctx_len=C)
+    assert p05.dtype == np.float64 and p05.shape == (N, 5, 5) and ex.shape == g["ex_out"].shape
+    for got, k in ((p05, "p05"), (p50, "p50"), (p95, "p95")):
+        assert _err(got, g[k]) <= TOL
+    assert _err(ex, g["ex_out"]) <= TOL                            # zeros unless check_ex_feats, like the reference
+    use_ex = cfg["ex_feats_dim"] > 0
+    (a, b, c), e1 = mle.generate_surfaces_mle(model, g["ex"], g["vol"], start + 3, C, 1, use_ex, chk)
+    assert _err(np.stack([a, b, c]), np.stack([g["p05"][3], g["p50"][3], g["p95"][3]])) <= TOL
+    assert (e1 is None) == (not (use_ex and chk))
+    # the two .npz products of generate_quantile_surfaces.py
+    f_st, f_mle = drivers.generate_quantile_products(model, g["ex"], g["vol"], start, N, C, str(tmp_path), "m", check_ex_feats=chk)
+    want_keys = {"surfaces_p05", "surfaces_p50", "surfaces_p95"} | ({"ex_feats"} if chk else set())
+    assert f_st.name == f"m_quantile_gen{C}.npz" and f_mle.name == f"m_quantile_mle_gen{C}.npz"
+    zm, zs = np.load(f_mle), np.load(f_st)
+    assert set(zm.files) == want_keys and set(zs.files) == want_keys
+    assert _err(zm["surfaces_p50"], g["p50"]) <= TOL and zs["surfaces_p50"].shape == (N, 5, 5)
+    assert np.max(np.abs(zs["surfaces_p50"] - zm["surfaces_p50"])) > 1e-6      # the stochastic product is not the z = 0 one
+
+
+@pytest.mark.parametrize("name", ["g12_gmm_ex5_C8_H4_K3", "g12_gmm_noex12_C20_H7_K5"])
+def test_fitted_gmm_prior_vs_reference(name, tmp_path):
+    """vsv_gmm_sample with the reference's multinomial picks and normal draws injected, and the generation from
+    those latents, against _sample_from_fitted_prior / get_surface_given_conditions(prior_mode="fitted") of the
+    reference (:605-640, :689-691); then the on-device (Philox) draw distributionally."""
+    from conftest import load_golden
+    from scipy import stats
+    g = load_golden(name)
+    model, cfg = _golden_model(g)
+    eng = model._engine()
+    B, C = g["surface"].shape[:2]
+    H, L, K = int(g["horizon"]), cfg["latent_dim"], g["means"].shape[0]
+    path = str(tmp_path / "gmm.pt")
+    torch.save({"means": torch.from_numpy(g["means"]), "covariances": torch.from_numpy(g["covariances"]),
+                "weights": torch.from_numpy(g["weights"]), "n_components": K}, path)
+    model.load_fitted_prior(path)
+    fp = model.fitted_prior
+    z = eng.gmm_sample(fp["means"], fp["cholesky"], fp["weights"], B * (C + H), comp=torch.from_numpy(g["comp"]),
+                       eps=torch.from_numpy(g["eps"]))
+    assert _err(_n(z).reshape(B, C + H, L), g["z"]) <= 1e-5
+    c = {"surface": _t(g["surface"])}
+    if "ex_feats" in g:
+        c["ex_feats"] = _t(g["ex_feats"])
+    out = model.get_surface_given_conditions(c, z=z.reshape(B, C + H, L).clone(), horizon=H)
+    if "ex_feats" in g:
+        assert _err(_n(out[0]), g["surf_out"]) <= TOL and _err(_n(out[1]), g["ex_out"]) <= TOL
+    else:
+        assert _err(_n(out), g["surf_out"]) <= TOL
+    # device draw: component frequencies follow the weights, whitened residuals are standard normal, seeds matter
+    n = 200_000
+    zz, comp = eng.gmm_sample(fp["means"], fp["cholesky"], fp["weights"], n, seed=11, want_comp=True)
+    comp = comp.cpu().numpy()
+    freq = np.bincount(comp, minlength=K) / n
+    assert np.max(np.abs(freq - g["weights"])) <= 5 * np.sqrt(0.25 / n)
+    chol = np.linalg.cholesky(g["covariances"])
+    resid = _n(zz) - g["means"][comp]
+    white = np.linalg.solve(chol[comp], resid[..., None])[..., 0]
+    assert stats.kstest(white.ravel()[:100_000], "norm").pvalue > 1e-3
+    assert abs(white.mean()) < 0.01 and abs(white.std() - 1) < 0.01
+    assert np.max(np.abs(np.corrcoef(white.T) - np.eye(L))) < 0.02
+    z2 = eng.gmm_sample(fp["means"], fp["cholesky"], fp["weights"], 1000, seed=11)
+    z3 = eng.gmm_sample(fp["means"], fp["cholesky"], fp["weights"], 1000, seed=12)
+    assert torch.equal(z2, zz[:1000]) and not torch.equal(z2, z3)
+    # the model API draws through it
+    torch.manual_seed(0)
+    zs = model._sample_from_fitted_prior(50, C + H)
+    assert zs.shape == (50, C + H, L) and zs.dtype == torch.float64
+    s = model.get_surface_given_conditions(c, horizon=H, prior_mode="fitted")
+    s = s[0] if isinstance(s, tuple) else s
+    assert s.shape == (B, H, 3, 5, 5) and bool(torch.isfinite(s).all())

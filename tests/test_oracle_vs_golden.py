@@ -257,3 +257,36 @@ def test_oracle_conditional_prior_kl(name):
     pm, plv = vo.prior_network_forward(Wp, cfg, surf[:, :C], None if ex is None else ex[:, :C])
     kl = vo.kl_divergence_gaussians(zm[:, :C], zl[:, :C], pm, plv)
     assert abs(kl - float(g["loss_kl_loss"])) <= 1e-9 * max(1.0, abs(kl))
+
+
+@pytest.mark.parametrize("name", golden_names("g11_"))
+def test_mle_generation_driver(name):
+    """generate_surfaces_multiday_mle of the reference (z = 0, one call per day) against the oracle."""
+    g = load_golden(name)
+    cfg = cfg_of(g)
+    W = vo.init_weights(cfg, int(g["seed"]), float(g["scale"]), np.float64)
+    X = cfg["ex_feats_dim"]
+    (p05, p50, p95), e = vo.generate_surfaces_multiday_mle(W, cfg, g["vol"], g["ex"] if X else None, int(g["start_day"]),
+                                                         int(g["n_days"]), int(g["ctx_len"]))
+    for got, k in ((p05, "p05"), (p50, "p50"), (p95, "p95")):
+        assert got.shape == g[k].shape and np.max(np.abs(got - g[k])) <= 1e-9
+    if int(g["check_ex_feats"]):
+        assert np.max(np.abs(e - g["ex_out"])) <= 1e-9
+    else:
+        assert not g["ex_out"].any()                    # the reference leaves zeros unless check_ex_feats
+
+
+@pytest.mark.parametrize("name", golden_names("g12_"))
+def test_fitted_gmm_prior(name):
+    """_sample_from_fitted_prior and prior_mode="fitted" generation with the reference's own draws."""
+    g = load_golden(name)
+    cfg = cfg_of(g)
+    W = vo.init_weights(cfg, int(g["seed"]), float(g["scale"]), np.float64)
+    B, C = g["surface"].shape[:2]
+    H = int(g["horizon"])
+    z = vo.gmm_sample(g["means"], g["covariances"], g["comp"], g["eps"]).reshape(B, C + H, -1)
+    assert np.max(np.abs(z - g["z"])) <= 1e-12
+    s, e = vo.get_surface_given_conditions(W, cfg, g["surface"], g.get("ex_feats"), z.copy(), H)
+    assert np.max(np.abs(s - g["surf_out"])) <= 1e-9
+    if e is not None:
+        assert np.max(np.abs(e - g["ex_out"])) <= 1e-9

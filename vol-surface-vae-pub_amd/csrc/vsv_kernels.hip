@@ -1669,6 +1669,73 @@ __global__ void __launch_bounds__(256) philox_normal_kernel(uint64_t seed, long 
 }
 
 // ---------------------------------------------------------------------------
+// gmm_sample: latents from a Gaussian mixture fitted to the aggregated posterior
+// (CVAEMemRand._sample_from_fitted_prior, cvae_with_mem_randomized.py:605-640): component ~
+// multinomial(weights), z = mean[c] + chol[c] . eps.  One thread per sample.  comp / eps are injected
+// (parity tests) or drawn from Philox4x32-10 keyed by (seed; sample index, block): block 0 gives the
+// uniform that picks the component through the cumulative weights, blocks 1.. give four normals each.
+// ---------------------------------------------------------------------------
+constexpr int kGmmMaxL = 16;
+
+__global__ void __launch_bounds__(256) gmm_sample_kernel(const float* __restrict__ means, const float* __restrict__ chol,
+                                                         const float* __restrict__ cdf, int K, int L, long n,
+                                                         const int* __restrict__ comp_in, const float* __restrict__ eps_in,
+                                                         uint64_t seed, float* __restrict__ z, int* __restrict__ comp_out) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
+    int c;
+    if (comp_in) {
+        c = comp_in[i];
+        c = c < 0 ? 0 : (c >= K ? K - 1 : c);
+    } else {
+        uint32_t c0 = (uint32_t)i, c1 = (uint32_t)((uint64_t)i >> 32), c2 = 0u, c3 = 0x474D4D00u;
+        philox4x32_10(k0, k1, c0, c1, c2, c3);
+        const float u = ((float)(c0 >> 8) + 0.5f) * 5.9604644775390625e-08f;          // (0, 1)
+        c = 0;
+        while (c < K - 1 && u >= cdf[c]) ++c;
+    }
+    float e[kGmmMaxL];
+#pragma unroll
+    for (int j = 0; j < kGmmMaxL; ++j) e[j] = 0.0f;
+    if (eps_in) {
+#pragma unroll
+        for (int j = 0; j < kGmmMaxL; ++j)
+            if (j < L) e[j] = eps_in[i * L + j];
+    } else {
+#pragma unroll
+        for (int b = 0; b < kGmmMaxL / 4; ++b) {
+            if (4 * b < L) {
+                uint32_t c0 = (uint32_t)i, c1 = (uint32_t)((uint64_t)i >> 32), c2 = (uint32_t)(b + 1), c3 = 0x474D4D00u;
+                philox4x32_10(k0, k1, c0, c1, c2, c3);
+                const uint32_t x[4] = {c0, c1, c2, c3};
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const float u1 = ((float)(x[2 * h] >> 9) + 0.5f) * 1.1920928955078125e-07f;
+                    const float u2 = ((float)(x[2 * h + 1] >> 9) + 0.5f) * 1.1920928955078125e-07f;
+                    const float r = __builtin_amdgcn_sqrtf(-1.3862943611198906f * __builtin_amdgcn_logf(u1));
+                    e[4 * b + 2 * h] = r * __builtin_amdgcn_cosf(u2);
+                    e[4 * b + 2 * h + 1] = r * __builtin_amdgcn_sinf(u2);
+                }
+            }
+        }
+    }
+    const float* m = means + (size_t)c * L;
+    const float* ch = chol + (size_t)c * L * L;
+#pragma unroll
+    for (int r = 0; r < kGmmMaxL; ++r) {
+        if (r < L) {
+            float acc = m[r];
+#pragma unroll
+            for (int j = 0; j < kGmmMaxL; ++j)
+                if (j <= r) acc = fmaf(ch[r * L + j], e[j], acc);
+            z[i * L + r] = acc;
+        }
+    }
+    if (comp_out) comp_out[i] = c;
+}
+
+// ---------------------------------------------------------------------------
 // launchers
 // ---------------------------------------------------------------------------
 static inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
@@ -2331,6 +2398,19 @@ extern "C" int vsv_dropout_mask(float p, uint64_t seed, int id, int layer, long 
     hipLaunchKernelGGL(dropout_mask_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
                        d, layer, n_rows, T, hidden, out);
     return launch_check("dropout_mask_kernel");
+}
+
+extern "C" int vsv_gmm_sample(const float* means, const float* chol, const float* cdf, int K, int L, long n,
+                              const int* comp_in, const float* eps_in, uint64_t seed, float* z_out, int* comp_out,
+                              void* stream) {
+    if (!means || !chol || !z_out || (!comp_in && !cdf)) { set_error("vsv_gmm_sample: null pointer"); return -1; }
+    if (K < 1 || L < 1 || L > kGmmMaxL || n < 0) { set_error("vsv_gmm_sample: need K >= 1, 1 <= L <= %d, n >= 0", kGmmMaxL); return -1; }
+    if (n == 0) return 0;
+    const long blocks = (n + 255) / 256;
+    if (blocks > 0x7fffffffL) { set_error("vsv_gmm_sample: too many samples"); return -2; }
+    hipLaunchKernelGGL(gmm_sample_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, means, chol, cdf, K, L, n,
+                       comp_in, eps_in, seed, z_out, comp_out);
+    return launch_check("gmm_sample_kernel");
 }
 
 extern "C" int vsv_philox_normal(uint64_t seed, long day0, long n_days, long S, int step0, int n_steps,

@@ -395,15 +395,14 @@ class CVAEMemRand(BaseVAE):
         print(f"Loaded fitted prior with {params['n_components']} components from {prior_params_path}")
 
     def _sample_from_fitted_prior(self, batch_size: int, seq_len: int) -> torch.Tensor:
-        """Reference :605-640: component ~ multinomial(weights), z = mean + chol @ eps."""
+        """Reference :605-640: component ~ multinomial(weights), z = mean + chol @ eps -- drawn on the device by
+        vsv_gmm_sample (Philox keyed by a seed from torch's generator); float64 (B, T, L) like the reference's."""
         fp = getattr(self, "fitted_prior", None)
         if fp is None:
             raise ValueError("Fitted prior not loaded. Call load_fitted_prior() first.")
         n, L = batch_size * seq_len, self.config["latent_dim"]
-        comp = torch.multinomial(fp["weights"].expand(n, -1), num_samples=1).squeeze(-1)
-        eps = torch.randn(n, L, device=self.device, dtype=torch.float64)
-        z = fp["means"][comp] + torch.einsum("bij,bj->bi", fp["cholesky"][comp], eps)
-        return z.reshape(batch_size, seq_len, L)
+        z = self._engine().gmm_sample(fp["means"], fp["cholesky"], fp["weights"], n, seed=self._draw_seed())
+        return z.to(torch.float64).reshape(batch_size, seq_len, L)
 
     def get_surface_given_conditions(self, c: Dict[str, torch.Tensor], z: torch.Tensor = None, mu=0, std=1,
                                      horizon=None, prior_mode="standard"):
@@ -578,10 +577,11 @@ class CVAEMemRand(BaseVAE):
         return losses, gp
 
     def _use_graphs(self) -> bool:
-        """HIP-graph replay of the training step: opt-in (config["hip_graphs"] = True or VSV_GRAPHS=1).  With
-        the weight gradients in one kernel a step is ~75 launches and the GPU, not the host, bounds it: on the
-        MI355X box eager launches measure 2.64 ms/step against 2.72 ms replayed, so eager is the default and
-        the graph is for hosts that cannot keep up."""
+        """HIP-graph replay of the training step: opt-in (config["hip_graphs"] = True or VSV_GRAPHS=1).  A step
+        is bound by the GPU (the recurrent launches on two CUs), not by the host's launch rate: on the MI355X
+        box eager launches and graph replay measure the same within 1 % (bench.py "train":
+        ms_per_step vs ms_per_step_hip_graph), so eager is the default and the graph is for hosts that cannot
+        keep up."""
         import os
         return bool(self.config.get("hip_graphs", False)) or os.environ.get("VSV_GRAPHS", "0") == "1"
 

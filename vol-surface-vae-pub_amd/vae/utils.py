@@ -2,8 +2,9 @@
 (set_seeds :15, model_eval :23, train :45, train_with_scheduled_sampling :102,
 test :262).  Same signatures, same checkpointing (best validation loss ->
 model.save_weights) and the same log-file format; the model underneath is the
-MI355X CVAEMemRand.  Plot helpers (:272-418) and autoregressive *training*
-(:426-669) are outside this build's scope.
+MI355X CVAEMemRand.  Autoregressive training (train_autoregressive_step :426-623,
+train_autoregressive_multi_offset :626-669) is below, as a two-pass rollout over the HIP
+kernels.  Plot helpers (:272-418) are outside this build's scope.
 """
 from __future__ import annotations
 

@@ -5,6 +5,8 @@ date range is sharded over the ranks of an initialised torch.distributed group (
 
 Reference call sites:
   generate_surfaces.py:13-102            generate_surfaces_random / generate_surfaces_multiday (quantile decoder)
+  generate_surfaces_max_likelihood.py:13-103   generate_surfaces_mle / generate_surfaces_multiday_mle (z = 0)
+  generate_quantile_surfaces.py:70-132   the stochastic + MLE .npz products per model
   eval_scripts/eval_utils.py:8-70        generate_surfaces / generate_surfaces_multiday (num_vaes MC samples per day)
   experiments/backfill/context20/generate_vae_tf_sequences.py:59-181        generate_and_save_horizon
   experiments/backfill/context60/autoregressive/generate_vae_ar_sequences.py:47-152  generate_and_save_ar_sequences
@@ -111,6 +113,71 @@ def generate_surfaces_multiday(model_data, ex_data, vol_surface_data, start_day,
     if e is not None and check_ex_feats:
         all_ex[...] = e.double().cpu().numpy()
     return (s[:, 0], s[:, 1], s[:, 2]), all_ex
+
+
+# ---- generate_surfaces_max_likelihood.py / generate_quantile_surfaces.py --------------------------
+
+def generate_surfaces_mle(model, ex_data, vol_surface_data, day, ctx_len, num_vaes, use_ex_feats, check_ex_feats):
+    """One day, z = 0 ("maximum likelihood") quantile surfaces (generate_surfaces_max_likelihood.py:13-59):
+    -> ((p05, p50, p95) each (5,5), ex_feat (X,) or None).  num_vaes is unused, as in the reference."""
+    (p05, p50, p95), ex = generate_surfaces_multiday_mle(model, ex_data, vol_surface_data, day, 1, num_vaes,
+                                                         check_ex_feats=check_ex_feats, ctx_len=ctx_len)
+    return (p05[0], p50[0], p95[0]), (ex[0] if (use_ex_feats and check_ex_feats) else None)
+
+
+def generate_surfaces_multiday_mle(model_data, ex_data, vol_surface_data, start_day, days_to_generate, num_vaes,
+                                   model_type=None, check_ex_feats=False, ctx_len=None):
+    """generate_surfaces_max_likelihood.py:61-103: for every day in [start_day, start_day + days_to_generate)
+    one get_surface_given_conditions(z = zeros((1, ctx_len + 1, L))) call on the window [day - ctx_len, day) --
+    the future latent is 0, the context latents are the posterior means (:700), the horizon is 1.  Here: ONE
+    batched device pass over the date range (no noise is drawn), sharded over the ranks.
+    -> ((p05, p50, p95) each (days, 5, 5) float64, ex_feats (days, X) float64; zeros unless check_ex_feats)."""
+    if model_type is None:
+        from vae.cvae_with_mem_randomized import CVAEMemRand as model_type
+    model = _model_from(model_data, model_type)
+    if ctx_len is None:
+        ctx_len = model.config["ctx_len"]
+    eng, vol, ex = _arrays(model, vol_surface_data, ex_data)
+    if eng.Q < 3:
+        raise ValueError("generate_surfaces_multiday_mle expects the 3-quantile decoder [p05, p50, p95]")
+
+    def fn(lo, hi):
+        s, e = paths.prior_windows(eng, vol, ex, start_day + lo, hi - lo, ctx_len, 1, 1, mu=0.0, std=0.0)
+        return s[:, 0, 0], (None if e is None else e[:, 0, 0])
+    s, e = _sharded_pair(fn, days_to_generate)
+    s = s.double().cpu().numpy()
+    n_ex = np.asarray(ex_data).shape[1] if ex_data is not None and np.asarray(ex_data).ndim > 1 else 1
+    all_ex = np.zeros((days_to_generate, n_ex))
+    if e is not None and check_ex_feats:
+        all_ex[...] = e.double().cpu().numpy()
+    return (s[:, 0], s[:, 1], s[:, 2]), all_ex
+
+
+def generate_quantile_products(model_data, ex_data, vol_surface_data, start_day, num_days, ctx_len, model_dir,
+                               model_name, check_ex_feats=False, model_type=None):
+    """One model's pass of generate_quantile_surfaces.py:70-132: the stochastic (z ~ N(0,1)) product
+    {model_dir}/{model_name}_quantile_gen{ctx_len}.npz and the z = 0 product ..._quantile_mle_gen{ctx_len}.npz,
+    each with surfaces_p05 / surfaces_p50 / surfaces_p95 (days, 5, 5) [+ ex_feats (days, X) when
+    check_ex_feats].  Returns the two paths (None, None on ranks > 0)."""
+    if model_type is None:
+        from vae.cvae_with_mem_randomized import CVAEMemRand as model_type
+    model = _model_from(model_data, model_type)
+    products = []
+    for fn, stem in ((generate_surfaces_multiday, "quantile_gen"), (generate_surfaces_multiday_mle, "quantile_mle_gen")):
+        (p05, p50, p95), ex_feats = fn(model, ex_data, vol_surface_data, start_day, num_days, 1,
+                                       model_type=model_type, check_ex_feats=check_ex_feats, ctx_len=ctx_len)
+        if _rank() != 0:
+            products.append(None)
+            continue
+        out = Path(model_dir)
+        out.mkdir(parents=True, exist_ok=True)
+        f = out / f"{model_name}_{stem}{ctx_len}.npz"
+        if check_ex_feats:
+            np.savez(f, surfaces_p05=p05, surfaces_p50=p50, surfaces_p95=p95, ex_feats=ex_feats)
+        else:
+            np.savez(f, surfaces_p05=p05, surfaces_p50=p50, surfaces_p95=p95)
+        products.append(f)
+    return tuple(products)
 
 
 # ---- eval_scripts/eval_utils.py -----------------------------------------------------------------

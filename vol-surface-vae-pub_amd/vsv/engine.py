@@ -494,6 +494,29 @@ class Engine:
         _lib.check(rc, "vsv_dropout_mask")
         return out
 
+    def gmm_sample(self, means: torch.Tensor, chol: torch.Tensor, weights: torch.Tensor, n: int, seed: int = 0,
+                   comp: Optional[torch.Tensor] = None, eps: Optional[torch.Tensor] = None, want_comp: bool = False):
+        """vsv_gmm_sample: n latents from the fitted mixture (means (K,L), lower Cholesky factors (K,L,L),
+        weights (K)).  comp (n,) / eps (n,L) inject the component picks / standard normal draws; otherwise Philox
+        keyed by seed.  -> z (n, L) float32 [, comp (n,) int32]."""
+        K, L = means.shape
+        m = _f32c(means, self.device)
+        ch = _f32c(chol, self.device)
+        cdf = torch.cumsum(weights.to(self.device, torch.float64) / weights.sum(), 0).to(torch.float32).contiguous()
+        ci = None if comp is None else comp.to(self.device, torch.int32).contiguous()
+        ei = None if eps is None else _f32c(eps, self.device)
+        if ci is not None:
+            assert ci.shape == (n,)
+        if ei is not None:
+            assert ei.shape == (n, L)
+        z = torch.empty((n, L), dtype=torch.float32, device=self.device)
+        co = torch.empty((n,), dtype=torch.int32, device=self.device) if want_comp else None
+        with torch.cuda.device(self.device):
+            rc = self.lib.vsv_gmm_sample(_ptr(m), _ptr(ch), _ptr(cdf), K, L, n, _ptr(ci), _ptr(ei), seed & (2 ** 64 - 1),
+                                         _ptr(z), _ptr(co), self._stream())
+        _lib.check(rc, "vsv_gmm_sample")
+        return (z, co) if want_comp else z
+
     def philox_normal(self, seed: int, day0: int, n_days: int, S: int, step0: int, n_steps: int) -> torch.Tensor:
         out = torch.empty((n_days * S, n_steps, self.L), dtype=torch.float32, device=self.device)
         with torch.cuda.device(self.device):

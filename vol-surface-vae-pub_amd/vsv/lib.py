@@ -182,6 +182,8 @@ SIGNATURES = {
     "vsv_tileb_gemm_launch": (C.c_int, [C.POINTER(VsvTilebGemm), C.c_void_p]),
     "vsv_weight_grads": (C.c_int, [C.POINTER(VsvWgrad), C.c_void_p]),
     "vsv_debug_layout": (C.c_int, [C.POINTER(VsvDims), C.POINTER(C.c_longlong), C.c_int]),
+    "vsv_gmm_sample": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_long, C.c_void_p, C.c_void_p,
+                                 C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p]),
     "vsv_philox_normal": (C.c_int, [C.c_uint64, C.c_long, C.c_long, C.c_long, C.c_int, C.c_int,
                                     C.c_int, C.c_void_p, C.c_void_p]),
 }

@@ -181,12 +181,14 @@ def prior_mc_windows(eng: Engine, vol: torch.Tensor, ex: Optional[torch.Tensor],
 
 def prior_windows(eng: Engine, vol: torch.Tensor, ex: Optional[torch.Tensor], first_day: int, n_days: int,
                   ctx_len: int, horizon: int, n_samples: int = 1, seed: int = 0,
-                  day_index0: Optional[int] = None, chunk_rows: int = 1 << 19):
+                  day_index0: Optional[int] = None, chunk_rows: int = 1 << 19, mu: float = 0.0, std: float = 1.0):
     """The per-day generation loop of generate_surfaces.py:60-102 / eval_utils.py:42-70 /
     generate_vae_tf_sequences.py (sampling_mode "prior") WITHOUT the reduction: for every day in
     [first_day, first_day + n_days), n_samples prior draws from the window vol[day-C:day].
     Returns (n_days, n_samples, horizon, Q, 5, 5)[, (n_days, n_samples, horizon, X)] -- the raw
-    samples in the reference's layout, on device.  Philox keyed by the global day index."""
+    samples in the reference's layout, on device.  Philox keyed by the global day index.
+    Future latents are N(mu, std); std = 0 is the z = mu "maximum likelihood" generation of
+    generate_surfaces_max_likelihood.py:13-58 (z = 0)."""
     assert first_day >= ctx_len and first_day + n_days <= vol.shape[0]
     vol = vol.to(device=eng.device, dtype=torch.float32).contiguous()
     if eng.X > 0:
@@ -207,7 +209,7 @@ def prior_windows(eng: Engine, vol: torch.Tensor, ex: Optional[torch.Tensor], fi
         nd = min(chunk_days, n_days - d0)
         r = eng.decode(nd * S, horizon, 0, state_in=pre["state"][d0:d0 + nd], state_div=S,
                        gate_in=None if pre["gates"] is None else pre["gates"][d0:d0 + nd],
-                       seed=seed, S=S, day0=day_index0 + d0, out_mode=0)
+                       seed=seed, S=S, day0=day_index0 + d0, out_mode=0, mu0=float(mu), std0=float(std))
         out_s[d0:d0 + nd] = r["surf"].view(nd, S, horizon, Q, 5, 5)
         if X > 0:
             out_e[d0:d0 + nd] = r["ex"].view(nd, S, horizon, X)

@@ -149,15 +149,17 @@ def case_prior(name, cfg, seed, scale, np_dtype, B, C, H):
     save(name, cfg, d)
 
 
-def case_ar(name, cfg, seed, scale, B, C, H):
+def case_ar(name, cfg, seed, scale, B, C, H, model_horizon=1):
     """G6: generate_autoregressive_sequence, float64 default dtype (z is
-    created float64 at cvae_with_mem_randomized.py:693-694)."""
+    created float64 at cvae_with_mem_randomized.py:693-694).  model_horizon: the model's own
+    self.horizon, which every inner call generates (:776 passes no horizon)."""
     np_dtype = np.float64
     model, _ = build_reference(cfg, seed, scale, np_dtype)
+    model.horizon = model_horizon
     rng = np.random.Generator(np.random.PCG64(3000 + seed))
     X, L = cfg["ex_feats_dim"], cfg["latent_dim"]
     surf, ex = synth(rng, B, C, X, np_dtype)
-    zs = rng.standard_normal((H, B, C + 1, L))
+    zs = rng.standard_normal((H, B, C + model_horizon, L))
     c = {"surface": torch.from_numpy(surf)}
     if X:
         c["ex_feats"] = torch.from_numpy(ex)
@@ -166,7 +168,7 @@ def case_ar(name, cfg, seed, scale, B, C, H):
             nq.push(zs[h])                      # torch.randn at :693
             nq.push(np.zeros((B, C, L)))        # encoder's own randn_like at :198 (result unused)
         out = model.generate_autoregressive_sequence(c, horizon=H)
-    d = dict(surface=surf, z_steps=zs, horizon=H, seed=seed, scale=scale)
+    d = dict(surface=surf, z_steps=zs, horizon=H, seed=seed, scale=scale, model_horizon=model_horizon)
     if X:
         d["ex_feats"] = ex
         d["surf_out"], d["ex_out"] = t2n(out[0]), t2n(out[1])
@@ -664,6 +666,8 @@ def main_round2():
     case_mle("g11_mle_ex5_C5_N40", vo.make_config(5, 3), 40, 2.0, 40, 5, True)
     case_mle("g11_mle_noex_C20_N33", vo.make_config(5, 0), 41, 2.0, 33, 20, False)
     case_mle("g11_mle_ex12_C60_N35", vo.make_config(12, 3), 42, 2.0, 35, 60, False)
+    case_ar("g13_ar_mh3_ex5_C8_H4", vo.make_config(5, 3), 45, 2.0, 3, 8, 4, model_horizon=3)
+    case_ar("g13_ar_mh2_noex_C5_H5", vo.make_config(5, 0), 46, 2.0, 4, 5, 5, model_horizon=2)
     case_gmm("g12_gmm_ex5_C8_H4_K3", vo.make_config(5, 3), 43, 2.0, 6, 8, 4, 3)
     case_gmm("g12_gmm_noex12_C20_H7_K5", vo.make_config(12, 0), 44, 2.0, 4, 20, 7, 5)
 

@@ -416,13 +416,16 @@ def generate_autoregressive_sequence(W: Weights, cfg: dict, ctx_surface: np.ndar
                                      ctx_ex: Optional[np.ndarray], z_steps: np.ndarray):
     """CVAEMemRand.generate_autoregressive_sequence
     (cvae_with_mem_randomized.py:717-807, _update_context :925-967).
-    z_steps (H,B,C+1,L): the randn drawn at :693 in each of the H one-day
-    calls (positions [:C] are overwritten by the posterior mean)."""
+    z_steps (H,B,C+Hm,L): the randn drawn at :693 in each of the H calls (positions [:C] are overwritten by
+    the posterior mean).  Hm is the MODEL's horizon (self.horizon, used because :776 passes no horizon): every
+    call generates Hm days, all of them are appended to the output ((B, H*Hm, ...), :801) and only the first
+    one's p50 / ex-features are fed back (:786-788).  Hm = 1 in every reference config."""
     surf_ctx = ctx_surface.copy()
     ex_ctx = None if ctx_ex is None else ctx_ex.copy()
+    Hm = z_steps.shape[2] - ctx_surface.shape[1]
     outs, exs = [], []
     for step in range(z_steps.shape[0]):
-        s, e = get_surface_given_conditions(W, cfg, surf_ctx, ex_ctx, z_steps[step].copy(), 1)
+        s, e = get_surface_given_conditions(W, cfg, surf_ctx, ex_ctx, z_steps[step].copy(), Hm)
         outs.append(s)
         new_surface = s[:, 0, 1]                                     # p50 channel, :786/:794
         surf_ctx = np.concatenate([surf_ctx[:, 1:], new_surface[:, None]], axis=1)

@@ -673,3 +673,48 @@ def test_hidden_widths_between_built_tile_counts(Hm, sh, X, mem):
         wg = np.zeros(ref[n].shape, dtype=np.float32) if wg is None else wg.numpy()
         nrm = float(np.sqrt((wg.astype(np.float64) ** 2).sum()))
         assert float(np.sqrt(((_n(gr) - wg).astype(np.float64) ** 2).sum())) <= 1e-3 * nrm + 1e-7, n
+
+
+@pytest.mark.parametrize("name", golden_names("g13_"))
+def test_autoregressive_sequence_with_model_horizon_above_one(name):
+    """the reference's generate_autoregressive_sequence generates self.horizon days per step (:776)
+    and returns them all, (B, horizon * self.horizon, ...), feeding back the first day only."""
+    from vae.cvae_with_mem_randomized import CVAEMemRand
+    from vsv import paths
+    g = load_golden(name)
+    cfg = cfg_of(g)
+    eng, W = _engine(cfg, int(g["seed"]), float(g["scale"]))
+    surf, ex = _t(g["surface"]), _t(g.get("ex_feats"))
+    C, Hm, H = g["surface"].shape[1], int(g["model_horizon"]), int(g["horizon"])
+    eps = _t(np.ascontiguousarray(g["z_steps"][:, :, C:].transpose(1, 0, 2, 3)))      # (B, H, Hm, L)
+    s, e = paths.ar_generate_multi(eng, surf, ex, H, Hm, eps=eps)
+    assert s.shape == g["surf_out"].shape and err(_n(s), g["surf_out"]) <= TOL
+    if ex is not None:
+        assert err(_n(e), g["ex_out"]) <= TOL
+    model = CVAEMemRand(dict(cfg, device="cuda:0", horizon=Hm))
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in W.items()}, strict=False)
+    c = {"surface": surf} if ex is None else {"surface": surf, "ex_feats": ex}
+    out = model.generate_autoregressive_sequence(c, horizon=H)
+    out_s = out[0] if ex is not None else out
+    assert out_s.shape == g["surf_out"].shape and bool(torch.isfinite(out_s).all())
+
+
+def test_in_place_data_edits_need_invalidate():
+    """p.data edits bump no version counter; invalidate_packed_weights() makes them visible."""
+    from vae.cvae_with_mem_randomized import CVAEMemRand
+    cfg = vo.make_config(5, 0, device="cuda:0")
+    model = CVAEMemRand(dict(cfg))
+    model.eval()
+    rng = np.random.default_rng(0)
+    c = {"surface": _t(0.2 + 0.1 * rng.standard_normal((3, 6, 5, 5)))}
+    z = torch.zeros((3, 7, 5), device="cuda:0")
+    a = model.get_surface_given_conditions(c, z=z.clone())
+    with torch.no_grad():
+        model.decoder.surface_decoder.dec_output.bias.data.add_(1.0)       # no version bump
+    model.invalidate_packed_weights()
+    b = model.get_surface_given_conditions(c, z=z.clone())
+    assert float((b - a - 1.0).abs().max()) <= 1e-5
+    with torch.no_grad():
+        model.decoder.surface_decoder.dec_output.bias.add_(1.0)            # a tracked in-place op: picked up by itself
+    d = model.get_surface_given_conditions(c, z=z.clone())
+    assert float((d - b - 1.0).abs().max()) <= 1e-5

@@ -61,7 +61,7 @@ def test_prior_generation(name):
         assert np.max(np.abs(e2[:, 0] - g["ex_out"])) <= tol(dt)
 
 
-@pytest.mark.parametrize("name", golden_names("g6_"))
+@pytest.mark.parametrize("name", golden_names("g6_") + golden_names("g13_"))
 def test_autoregressive(name):
     g = load_golden(name)
     cfg = cfg_of(g)

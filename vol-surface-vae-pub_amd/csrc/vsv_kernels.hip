@@ -1163,6 +1163,209 @@ lstm_kernel(const LstmSeqArgs a) {
 }
 
 // ---------------------------------------------------------------------------
+// mc_decode1_kernel: the Monte-Carlo one-day decode (prior draw from a day's shared prefix state, T = 1):
+// the whole decoder step of 32 rows -- Philox latents, both LSTM layers, the four head layers, the
+// sample-minor store -- runs in ONE WAVE, with no workgroup barrier and no other wave to wait for.
+// lstm_kernel<.., HEAD> splits a row tile's gate tiles over four waves that meet at a barrier twice per
+// layer and once per head layer; its waves spend 3/4 of their lifetime waiting (prologue latency, cell
+// math, barriers, the widest head band), which two co-resident workgroups cannot cover.  Here a wave walks
+// the 16 gate tiles of a layer in four passes of four tiles (64 accumulator registers), keeps the layer's
+// h in registers until the last pass has read the layer's input, and owns one 64-slot LDS column that
+// every layer updates in place.  Same products in the same k order as lstm_kernel: results are bit-equal.
+// Eight such waves per CU (two 4-wave workgroups, 64 KB LDS each) overlap freely.
+// ---------------------------------------------------------------------------
+template <int NT>
+__global__ void __launch_bounds__(256, 2) mc_decode1_kernel(const LstmSeqArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    static_assert(NT == 16, "built for 16 gate tiles (decoder hidden 121..128)");
+    constexpr int HP = 8 * NT;
+    constexpr int NP = NT / 4;                                    // passes of four gate tiles
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const long rowtile = (long)blockIdx.x * 4 + wave;
+    if (rowtile >= a.n_rowtiles) return;                          // (no barriers below: a wave may leave alone)
+    float* const col0 = smem + (size_t)wave * (64 * 64);          // this wave's activation column, without the lane
+    const vsv_decode_in& d = a.din;
+    const int kx = a.kx;
+    const DenseChainArgs& hd = a.head;
+
+    // ---- per-row constants, latents
+    uint32_t state_row;
+    {
+        const int hh = lane >> 5, m = lane & 31;
+        const long row_raw = rowtile * 32 + m;
+        const uint32_t row32 = (uint32_t)(row_raw < a.n_rows ? row_raw : a.n_rows - 1);
+        const uint32_t S32 = (uint32_t)(d.S > 0x7fffffffL ? 0x7fffffffL : d.S);
+        const uint32_t day_rel = row32 / S32;
+        const uint32_t sample = row32 - day_rel * S32, day = (uint32_t)d.day0 + day_rel;
+        state_row = (d.state_div == d.S) ? day_rel : row32 / (uint32_t)(d.state_div > 0x7fffffffL ? 0x7fffffffL : d.state_div);
+        float* const col = col0 + lane;
+        // x part of layer 0: [ctx (zero padding) | z | alignment padding]; k-step s, half hh <-> feature 2s + hh
+        for (int s = 0; s < kx; ++s) col[s * 64] = (2 * s + hh >= a.L && 2 * s + hh < 2 * a.L) ? d.mu0 : 0.0f;
+        if (d.std0 != 0.0f) {
+            // one Philox block gives the latents 4b .. 4b+3 (philox_normal_elem: word pair f & 2, cos / sin by f & 1);
+            // this lane holds the two of them with its parity
+            const int par = (hh - a.L) & 1;
+            const uint32_t k0 = (uint32_t)d.seed, k1 = (uint32_t)(d.seed >> 32);
+            for (int b = 0; 4 * b < a.L; ++b) {
+                uint32_t c0 = sample, c1 = day, c2 = (uint32_t)(d.step0 - d.eps_t0), c3 = (uint32_t)b;
+                philox4x32_10(k0, k1, c0, c1, c2, c3);
+#pragma unroll
+                for (int p = 0; p < 2; ++p) {
+                    const int f = 4 * b + 2 * p + par;
+                    const uint32_t xa = p ? c2 : c0, xb = p ? c3 : c1;
+                    const float u1 = ((float)(xa >> 9) + 0.5f) * 1.1920928955078125e-07f;
+                    const float u2 = ((float)(xb >> 9) + 0.5f) * 1.1920928955078125e-07f;
+                    const float r = __builtin_amdgcn_sqrtf(-1.3862943611198906f * __builtin_amdgcn_logf(u1));
+                    const float e = r * (par ? __builtin_amdgcn_sinf(u2) : __builtin_amdgcn_cosf(u2));
+                    if (f < a.L) col[((f + a.L - hh) >> 1) * 64] = d.mu0 + d.std0 * e;
+                }
+            }
+        }
+    }
+    const float* const gate_in = d.gate_in + (size_t)state_row * 2 * NT * 32;
+    const float* const st = d.state_in + (size_t)state_row * 2 * 2 * HP;
+    // of layer 0's input quads only those that hold z are multiplied (the context half is the zero padding)
+    const int qx0 = a.L >> 3, qxn = ((2 * a.L + 7) >> 3) - qx0;
+
+    // ---- the two memory layers
+#pragma unroll
+    for (int l = 0; l < 2; ++l) {
+        float hold[NT][4];                                        // this layer's h, unit 8*tile + 2*jj + hh
+        const float4* const w = (const float4*)a.w[l] + (l == 0 ? (size_t)qx0 * NT * 64 : 0);
+        const int nq = (l == 0) ? qxn : NT;
+        const int bslot0 = (l == 0) ? 4 * qx0 : 0;
+#pragma unroll
+        for (int p = 0; p < NP; ++p) {
+            const int lv = opaque(lane);
+            const int hh = lv >> 5;
+            f32x16 acc[4];
+            float c[4][4], hn[4][4];
+            unsigned wo[4];
+            float4 a0[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) wo[i] = (unsigned)lv + (unsigned)((4 * p + i) * 64);
+            wload<4>(a0, w, wo, 0u);
+            // gate accumulators start from bias + W_hh . h_prefix of the day (gate_in); c from the day's state
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const float4* gp = (const float4*)(gate_in + (size_t)l * NT * 32 + (4 * p + i) * 32 + hh * 16);
+#pragma unroll
+                for (int v = 0; v < 4; ++v) {
+                    const float4 x = gp[v];
+                    acc[i][4 * v + 0] = x.x; acc[i][4 * v + 1] = x.y; acc[i][4 * v + 2] = x.z; acc[i][4 * v + 3] = x.w;
+                }
+                const float4 cv = *(const float4*)(st + (size_t)l * 2 * HP + HP + 8 * (4 * p + i) + 4 * hh);
+                c[i][0] = cv.x; c[i][1] = cv.y; c[i][2] = cv.z; c[i][3] = cv.w;
+            }
+            const float* const bcol = col0 + lv + (size_t)bslot0 * 64;
+            gemm_stream<4>(acc, a0, w, wo, NT * 64, nq, [&](int q, float (&bv)[4]) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) bv[j] = bcol[(4 * q + j) * 64];
+            });
+            lstm_cell<false, 4>(acc, c, hn, false);
+            // (pinned: left to itself the compiler sinks the cell math of all four passes below the last
+            // pass's GEMM and parks the earlier passes' accumulators in scratch meanwhile)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int jj = 0; jj < 4; ++jj) {
+                    asm volatile("" : "+v"(hn[i][jj]));
+                    hold[4 * p + i][jj] = hn[i][jj];
+                }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        // every pass has read the layer's input: the column now takes the layer's h (natural k-step order)
+        float* const colw = col0 + opaque(lane);
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) colw[(4 * t + jj) * 64] = hold[t][jj];
+    }
+
+    // ---- decoder head: every layer reads the column and overwrites it with its (ReLU'd) outputs
+    const int n_layers = hd.n_layers;                             // 4: [Linear . ConvT] ConvT ConvT Conv
+#pragma unroll
+    for (int li = 0; li < 4; ++li) {
+        if (li >= n_layers) break;
+        const DenseLayerArg& ly = hd.layer[li];
+        const bool last = (li == n_layers - 1);
+        const int lv = opaque(lane);
+        const int hh = lv >> 5;
+        const float* const bcol = col0 + lv;
+        f32x16 acc[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            if (t < ly.nt) {
+                const float4* bp = (const float4*)(ly.b + t * 32 + hh * 16);
+#pragma unroll
+                for (int v = 0; v < 4; ++v) {
+                    const float4 x = bp[v];
+                    acc[t][4 * v + 0] = x.x; acc[t][4 * v + 1] = x.y; acc[t][4 * v + 2] = x.z; acc[t][4 * v + 3] = x.w;
+                }
+            }
+        }
+        if (li == 0) {
+            // full K, four tiles: one pinned stream
+            unsigned wo[4];
+            float4 a0[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) wo[i] = (unsigned)lv + (unsigned)(i * 64);
+            wload<4>(a0, (const float4*)ly.w, wo, 0u);
+            gemm_stream<4>(acc, a0, (const float4*)ly.w, wo, 4 * 64, ly.nq, [&](int q, float (&bv)[4]) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) bv[j] = bcol[(4 * q + j) * 64];
+            });
+        } else {
+            // conv layers in pixel-major order: tile t reads the K quads [q0[t], q0[t] + nqb[t]) only
+            float4 wq[kHalfQ];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                if (t < ly.nt) {
+                    const int q0 = pick4(ly.q0, t), nqb = pick4(ly.nqb, t);
+                    tile_load_band(wq, (const float4*)ly.w, t * 64 + lv, ly.nt * 64, q0, nqb);
+                    tile_mfma_band<4 * kHeadTiles>(acc[t], wq, (const float4*)ly.w, t * 64 + lv, ly.nt * 64, bcol, q0, nqb);
+                }
+            }
+        }
+        const bool do_aux = (li == hd.aux_layer) && hd.aux != nullptr;
+        RowIo io = {nullptr, 1, nullptr, nullptr};
+        if (do_aux || last) io = late_rowio(hd, rowtile, lv, 0);
+        float* const colw = col0 + lv;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            if (t < ly.nt) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    if (feat_of(t, r, hh) < ly.n_relu) acc[t][r] = fmaxf(acc[t][r], 0.0f);
+                if (!last) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) colw[(16 * t + r) * 64] = acc[t][r];
+                }
+                if (do_aux || last) {
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        const int f0 = 32 * t + 8 * g;
+                        if (do_aux && io.aux && f0 + 8 > hd.aux_f0 && f0 < hd.aux_f0 + hd.aux_n) {
+#pragma unroll
+                            for (int k = 0; k < 4; ++k) {
+                                const int f = f0 + 4 * hh + k;
+                                if (f >= hd.aux_f0 && f < hd.aux_f0 + hd.aux_n) io.aux[f] = acc[t][4 * g + k];
+                            }
+                        }
+                        if (last && io.out && f0 < hd.out_f) {
+                            float* po = io.out + (size_t)(f0 + 4 * hh) * io.fstride;
+#pragma unroll
+                            for (int k = 0; k < 4; ++k)
+                                if (f0 + 4 * hh + k < hd.out_f) po[(size_t)k * io.fstride] = acc[t][4 * g + k];
+                        }
+                    }
+                }
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
 // dense_bwd_kernel: backward of a dense chain for independent (row tile, t)
 // instances, one wave per instance.  col holds the gradient w.r.t. a forward
 // layer's OUTPUT in that layer's slot order (slot 16t + reg <-> feature
@@ -2238,6 +2441,25 @@ static int encode_impl(const vsv_dims* dims, const float* packed, int which,
     return launch_dense_chain(h, st);
 }
 
+// mc_decode1_kernel serves the Monte-Carlo one-day draw only: one step from a shared per-day state with the
+// first-step gates given, Philox (or no) noise, nothing but the decoded surfaces [and ex-features] wanted,
+// the production topology (two LSTM layers, 16 gate tiles, four head layers, the first of them full K).
+// VSV_MC1=0 keeps the four-waves-per-row-tile kernel (A/B runs).
+static bool mc_decode1_applies(const LstmSeqArgs& l, const Layout& lay, int T, int t_out0, const float* state_out,
+                               const float* z_out) {
+    static const bool off = [] { const char* e = getenv("VSV_MC1"); return e && e[0] == '0'; }();
+    if (off) return false;
+    const vsv_decode_in& d = l.din;
+    const DenseChainArgs& hd = l.head;
+    if (T != 1 || t_out0 != 0 || state_out || z_out || d.gate_out) return false;
+    if (!d.gate_in || !d.state_in || d.eps_in || d.ctx_T > 0 || d.z_T > 0) return false;
+    if (lay.NL != 2 || lay.NTd != 16 || lay.gru || l.kx > 64) return false;
+    if (hd.n_layers != 4 || hd.layer[0].nt != 4 || hd.layer[0].nq != 16) return false;
+    for (int i = 1; i < 4; ++i)
+        if (hd.layer[i].nt < 1 || hd.layer[i].nt > 4 || hd.layer[i].nq != 16) return false;
+    return true;
+}
+
 extern "C" size_t vsv_decode_ws_bytes(const vsv_dims* dims, long n_rows, int T, int t_out0) {
     Layout lay;
     const char* msg = nullptr;
@@ -2307,7 +2529,18 @@ extern "C" int vsv_decode(const vsv_dims* dims, const float* packed, const vsv_d
     hipEvent_t ev0 = g_prof_ev[0], ev1 = g_prof_ev[1];
     g_prof_ev[0] = g_prof_ev[1] = nullptr;
     if (ev0) (void)hipEventRecord(ev0, st);
-    const int rc = launch_lstm<1>(l, lay.NTd, lay.NL, touts > 0, st);
+    int rc;
+    if (mc_decode1_applies(l, lay, T, t_out0, state_out, z_out)) {
+        // the Monte-Carlo one-day draw: one wave per 32 rows, no barriers (mc_decode1_kernel)
+        const size_t lds = (size_t)4 * 64 * 64 * sizeof(float);
+        rc = set_lds(mc_decode1_kernel<16>, lds);
+        if (!rc) {
+            hipLaunchKernelGGL(mc_decode1_kernel<16>, dim3((unsigned)((rt + 3) / 4)), dim3(256), lds, st, l);
+            rc = launch_check("mc_decode1_kernel");
+        }
+    } else {
+        rc = launch_lstm<1>(l, lay.NTd, lay.NL, touts > 0, st);
+    }
     if (ev1) (void)hipEventRecord(ev1, st);
     return rc;
 }

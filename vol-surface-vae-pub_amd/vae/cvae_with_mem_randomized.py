@@ -313,6 +313,16 @@ class CVAEMemRand(BaseVAE):
             self.__dict__["_vsv_key"] = key
         return eng
 
+    def invalidate_packed_weights(self) -> None:
+        """Forces a re-pack of the kernels' weight blob at the next compute call.  The blob is rebuilt whenever a
+        parameter's (storage pointer, version counter) changes -- optimizer steps, load_state_dict and .to() all
+        bump one of them.  In-place edits through `p.data` (p.data.copy_/mul_/clamp_: EMA swaps, weight clipping,
+        manual initialisation) bump NEITHER, so call this after such an edit; otherwise the kernels keep computing
+        with the weights packed before it."""
+        self.__dict__["_vsv_key"] = None
+        if "_vsv_prior_key" in self.__dict__:
+            self.__dict__["_vsv_prior_key"] = None
+
     @staticmethod
     def _draw_seed() -> int:
         """A Philox key drawn from torch's global generator, so set_seeds() makes
@@ -441,7 +451,8 @@ class CVAEMemRand(BaseVAE):
                                          ) -> Union[torch.Tensor, Tuple[torch.Tensor, torch.Tensor]]:
         """Day-by-day rollout (reference :717-807): each step generates one day from the
         prior, the p50 channel (and the predicted ex-features) slide into the context.
-        `z` is ignored, as in the reference (:776)."""
+        `z` is ignored, as in the reference (:776).  Like the reference's, every step generates self.horizon
+        days and all are returned: (B, horizon * self.horizon, Q, 5, 5) (self.horizon is 1 in every config)."""
         if "surface" not in initial_context:
             raise ValueError("initial_context must contain 'surface' key")
         nd = initial_context["surface"].dim()
@@ -454,7 +465,12 @@ class CVAEMemRand(BaseVAE):
         surf, ex = self._batched(initial_context)
         eng = self._engine()
         dt = self._param_dtype()
-        s_out, e_out = paths.ar_generate(eng, surf, ex if has_ex else None, horizon, 1, seed=self._draw_seed())
+        if self.horizon == 1:
+            s_out, e_out = paths.ar_generate(eng, surf, ex if has_ex else None, horizon, 1, seed=self._draw_seed())
+        else:
+            # the reference's inner call (:776) generates self.horizon days per step and keeps them all
+            s_out, e_out = paths.ar_generate_multi(eng, surf, ex if has_ex else None, horizon, self.horizon,
+                                                   seed=self._draw_seed())
         return (s_out.to(dt), e_out.to(dt)) if has_ex else s_out.to(dt)
 
     def generate_autoregressive_offset(self, initial_context: Dict[str, torch.Tensor], ar_steps: int = 3,

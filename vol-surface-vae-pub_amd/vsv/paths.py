@@ -356,6 +356,29 @@ def ar_generate(eng: Engine, surf_ctx: torch.Tensor, ex_ctx: Optional[torch.Tens
     return out_s, out_e
 
 
+def ar_generate_multi(eng: Engine, surf_ctx: torch.Tensor, ex_ctx: Optional[torch.Tensor], horizon: int,
+                      model_horizon: int, eps: Optional[torch.Tensor] = None, seed: int = 0, day0: int = 0):
+    """generate_autoregressive_sequence (:717-807) of a model whose own horizon is model_horizon > 1: the inner
+    call at :776 passes no horizon, so every one of the `horizon` steps generates model_horizon days, ALL of them
+    are appended to the output (:801) and only the first one's p50 channel / ex-features slide into the context
+    (:786-788).  No reference config uses it; a plain loop of shared-prefix generations.
+    eps: (B, horizon, model_horizon, L) or None -> Philox.  Returns (B, horizon*model_horizon, Q, 5, 5)[, (.., X)]."""
+    B, C = surf_ctx.shape[:2]
+    X = eng.X
+    surf = surf_ctx.to(eng.device, torch.float32).reshape(B, C, 5, 5)
+    ex = ex_ctx.to(eng.device, torch.float32) if X > 0 else None
+    outs_s, outs_e = [], []
+    for k in range(horizon):
+        e = None if eps is None else eps[:, k].contiguous()
+        s, ee, _ = prior_generate(eng, surf, ex, model_horizon, 1, eps=e, seed=seed, day0=day0, step0=k * model_horizon)
+        outs_s.append(s)
+        surf = torch.cat([surf[:, 1:], s[:, :1, 1]], dim=1).contiguous()
+        if X > 0:
+            outs_e.append(ee)
+            ex = torch.cat([ex[:, 1:], ee[:, :1]], dim=1).contiguous()
+    return torch.cat(outs_s, dim=1), (torch.cat(outs_e, dim=1) if X > 0 else None)
+
+
 def ar_offset_generate(eng: Engine, surf_ctx: torch.Tensor, ex_ctx: Optional[torch.Tensor], ar_steps: int,
                        horizon: int, eps: Optional[torch.Tensor] = None, seed: int = 0, day0: int = 0):
     """generate_autoregressive_offset (cvae_with_mem_randomized.py:809-923): ar_steps

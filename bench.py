@@ -42,7 +42,8 @@ PEAK_F32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32,
 
 def flops_per_unit(L: int, X: int, Hm: int = 100, c_last: int = 5, Q: int = 3):
     """Algorithmic FLOPs (2*MAC, no padding, no recomputation) per time step of one
-    row, SURVEY.md 8(d): encoder stack, context stack, decoder LSTM, decoder head."""
+    row, SURVEY.md 8(d): encoder stack, context stack, decoder LSTM, decoder head.
+    Q: decoder channels the output Conv produces (3; 1 when only the reduced channel is decoded)."""
     E = c_last * 25 + X
     Hd = c_last * 25 + X
     conv_enc = 2 * 25 * 9 * (1 * 5 + 5 * 5 + 5 * 5)                 # 3x3 convs on 5x5 incl. padding taps = 24750
@@ -365,7 +366,7 @@ def main(argv=None):
     dt = timed(N * world, events)                                  # weak: N days per GPU
     dt_strong = timed(N) if world > 1 else dt                      # strong: N days in total
 
-    fl = flops_per_unit(L, X)
+    fl = flops_per_unit(L, X, Q=1)                                 # one_step() decodes the p50 channel only
     k_ms = [a.elapsed_ms(b) for a, b, _ in events]
     k_rows = [r for _, _, r in events]
     avg_ms = float(np.mean(k_ms))
@@ -409,7 +410,8 @@ def main(argv=None):
         "strong": {"workload": f"the same backfill with {N} days IN TOTAL split over the {world} rank(s)",
                    "value": N * S * H * args.steps / dt_strong, "unit": "surfaces/s",
                    "ms_per_step": dt_strong / args.steps * 1e3, "scaling": "strong"},
-        "roofline": {"bound": "mfma", "kernel": "lstm_kernel<16,2,1,true> (fused MC decode: LSTM steps + decoder head)",
+        "roofline": {"bound": "mfma", "kernel": ("mc_decode1_kernel<16>" if H == 1 else "lstm_kernel<16,2,1,true>") +
+                               " (fused MC decode: Philox latents, LSTM step(s), decoder head, p50 channel only)",
                      "achieved": achieved, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
                      "frac": achieved / PEAK_F32_MFMA_TFLOPS, "traffic": traffic,
                      "flops_per_launch": flops_per_launch, "avg_launch_ms": avg_ms, "launches": len(k_ms)},

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define VSV_ABI_VERSION 14
+#define VSV_ABI_VERSION 15
 #define VSV_MAX_CONV 4
 #define VSV_MAX_CHAIN 8
 #define VSV_MAX_INTERACT 3
@@ -191,6 +191,10 @@ int vsv_encode_windows_noalloc(const vsv_dims *dims, const float *packed, int wh
  *   out_mode 0: surf_out (n_rows, T-t_out0, Q, 5, 5), the reference layout;
  *   out_mode 1: surf_out (n_rows/S, T-t_out0, Q*25, S), MC-sample-minor, the layout
  *               vsv_percentile reads (requires n_rows % S == 0);
+ *   out_mode VSV_OUT_CHANNEL(c), 0 <= c < Q: surf_out (n_rows/S, T-t_out0, 25, S), sample-minor,
+ *               decoder channel c alone: the rows of the output Conv that produce the other channels
+ *               are neither multiplied nor stored (the MC products of generate_surfaces.py:60-102
+ *               reduce the p50 channel only);
  * and ex_out (n_rows, T-t_out0, X) when X > 0 and ex_out != NULL.
  * z_out, when not NULL, receives the z part that was fed in: (n_rows, T, L).
  * gate_out, when not NULL, receives per row bias + W_hh . h_final of every layer (the
@@ -213,6 +217,7 @@ typedef struct vsv_decode_in {
 size_t vsv_state_floats(const vsv_dims *dims);   /* floats of decoder LSTM state per row */
 size_t vsv_gate_floats(const vsv_dims *dims);    /* floats of gate_in / gate_out per row */
 size_t vsv_decode_ws_bytes(const vsv_dims *dims, long n_rows, int T, int t_out0);
+#define VSV_OUT_CHANNEL(c) (2 + (c))
 int vsv_decode(const vsv_dims *dims, const float *packed, const vsv_decode_in *in,
                long n_rows, int T, int t_out0,
                float *state_out, float *z_out,

@@ -718,3 +718,34 @@ def test_in_place_data_edits_need_invalidate():
         model.decoder.surface_decoder.dec_output.bias.add_(1.0)            # a tracked in-place op: picked up by itself
     d = model.get_surface_given_conditions(c, z=z.clone())
     assert float((d - b - 1.0).abs().max()) <= 1e-5
+
+
+@pytest.mark.parametrize("L,X,D,S,C,H,mem", [(12, 3, 9, 1000, 6, 1, "lstm"), (5, 0, 5, 333, 4, 1, "lstm"),
+                                             (12, 3, 4, 250, 5, 3, "lstm"), (5, 3, 3, 96, 4, 2, "gru")])
+def test_single_channel_output_equals_channel_of_full_output(L, X, D, S, C, H, mem):
+    """vsv_decode with out_mode VSV_OUT_CHANNEL(c) (the output Conv restricted to one decoder channel) gives,
+    bit for bit, channel c of the full sample-minor output -- on the one-wave Monte-Carlo kernel (H = 1, Philox,
+    shared prefix) and on the generic schedule (H > 1, GRU); the reduced products agree likewise."""
+    from vsv import paths
+    cfg = vo.make_config(L, X, mem_type=mem)
+    eng, _ = _engine(cfg, 31, 2.0)
+    N = C + D + H
+    rng = np.random.default_rng(8)
+    vol = _t(0.2 + 0.1 * rng.standard_normal((N, 5, 5)))
+    ex = _t(0.01 * rng.standard_normal((N, X))) if X else None
+    full = paths.prior_mc_windows(eng, vol, ex, C, D, C, H, S, seed=5, channel=None, chunk_days=4)
+    assert full.shape == (D, H, 3, 3, 5, 5)
+    for c in range(3):
+        one = paths.prior_mc_windows(eng, vol, ex, C, D, C, H, S, seed=5, channel=c, chunk_days=4)
+        assert one.shape == (D, H, 3, 5, 5)
+        assert torch.equal(one, full[:, :, :, c])
+    # the raw samples
+    state, gates = paths._context_prefix(eng, vol, ex, D, C)
+    kw = dict(state_in=state, state_div=S, gate_in=gates, seed=5, S=S, day0=C)
+    s_all = eng.decode(D * S, H, 0, out_mode=1, **kw)["surf"]
+    for c in range(3):
+        r = eng.decode(D * S, H, 0, out_mode=eng.OUT_CHANNEL(c), **kw)
+        assert r["surf"].shape == (D, H, 25, S)
+        assert torch.equal(r["surf"], s_all[:, :, 25 * c:25 * c + 25])
+    with pytest.raises(ValueError):
+        eng.decode(D * S, H, 0, out_mode=eng.OUT_CHANNEL(3), **kw)

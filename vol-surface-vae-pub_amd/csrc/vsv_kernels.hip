@@ -36,8 +36,18 @@ __device__ unsigned long long g_stamps[(size_t)kStampWgs * 4 * 32];
         if (XMODE == 1 && HEAD && lane == 0 && blockIdx.x < kStampWgs)                                        \
             g_stamps[((size_t)blockIdx.x * 4 + wave) * 32 + (i)] = __builtin_amdgcn_s_memtime();               \
     } while (0)
+// (mc_decode1_kernel, tools/stamps_mc1.py: 0 start, 1 latents, 2s+2 / 2s+3 GEMM / cell of pass s, 18+2li / 19+2li
+// matrix part / epilogue of head layer li)
+#define MC1_STAMP(i)                                                                                          \
+    do {                                                                                                      \
+        __builtin_amdgcn_sched_barrier(0);                                                                    \
+        if (lane == 0 && blockIdx.x < kStampWgs)                                                              \
+            g_stamps[((size_t)blockIdx.x * 4 + wave) * 32 + (i)] = __builtin_amdgcn_s_memtime();               \
+        __builtin_amdgcn_sched_barrier(0);                                                                    \
+    } while (0)
 #else
 #define VSV_STAMP(i) do {} while (0)
+#define MC1_STAMP(i) do {} while (0)
 #endif
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -276,9 +286,17 @@ __device__ __forceinline__ int opaque(int x) {
 }
 
 __device__ __forceinline__ float fast_sigmoid(float x) { return __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
+// max(x, 0) as ONE instruction (fmaxf first canonicalises an operand it cannot prove quiet: a second v_max)
+__device__ __forceinline__ float relu1(float x) {
+    float r;
+    asm("v_max_f32 %0, 0, %1" : "=v"(r) : "v"(x));
+    return r;
+}
+
+// tanh(x) = 2 sigmoid(2x) - 1: five instructions (exp(-2x) overflows to +inf -> -1, underflows to 0 -> +1);
+// absolute error ~1e-7 around 0, where the quotient form it replaces (eight instructions) was relatively exact
 __device__ __forceinline__ float fast_tanh(float x) {
-    const float e = __expf(-2.0f * fabsf(x));
-    return copysignf((1.0f - e) * __builtin_amdgcn_rcpf(1.0f + e), x);
+    return 2.0f * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(x * -2.885390081777927f)) - 1.0f;
 }
 
 // ---------------------------------------------------------------------------
@@ -1162,6 +1180,26 @@ lstm_kernel(const LstmSeqArgs a) {
     }
 }
 
+// layer[li] of the decoder head (LstmSeqArgs::head, part of the by-value kernel argument) for a run-time li,
+// read from the kernarg segment by scalar loads: indexing the by-value copy itself would put it in scratch.
+// The struct is the kernel's only explicit argument, so it sits at offset 0 of the segment.
+__device__ __forceinline__ DenseLayerArg chain_layer_of(int li) {
+    typedef const __attribute__((address_space(4))) LstmSeqArgs* KP;
+    const KP kp = (KP)__builtin_amdgcn_kernarg_segment_ptr();
+    DenseLayerArg r;
+    r.w = kp->head.layer[li].w;
+    r.b = kp->head.layer[li].b;
+    r.nq = kp->head.layer[li].nq;
+    r.nt = kp->head.layer[li].nt;
+    r.n_relu = kp->head.layer[li].n_relu;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        r.q0[t] = kp->head.layer[li].q0[t];
+        r.nqb[t] = kp->head.layer[li].nqb[t];
+    }
+    return r;
+}
+
 // ---------------------------------------------------------------------------
 // mc_decode1_kernel: the Monte-Carlo one-day decode (prior draw from a day's shared prefix state, T = 1):
 // the whole decoder step of 32 rows -- Philox latents, both LSTM layers, the four head layers, the
@@ -1187,16 +1225,18 @@ __global__ void __launch_bounds__(256, 2) mc_decode1_kernel(const LstmSeqArgs a)
     const vsv_decode_in& d = a.din;
     const int kx = a.kx;
     const DenseChainArgs& hd = a.head;
+    MC1_STAMP(0);
 
     // ---- per-row constants, latents
-    uint32_t state_row;
+    uint32_t state_row, day_rel, sample;
     {
         const int hh = lane >> 5, m = lane & 31;
         const long row_raw = rowtile * 32 + m;
         const uint32_t row32 = (uint32_t)(row_raw < a.n_rows ? row_raw : a.n_rows - 1);
         const uint32_t S32 = (uint32_t)(d.S > 0x7fffffffL ? 0x7fffffffL : d.S);
-        const uint32_t day_rel = row32 / S32;
-        const uint32_t sample = row32 - day_rel * S32, day = (uint32_t)d.day0 + day_rel;
+        day_rel = row32 / S32;
+        sample = row32 - day_rel * S32;
+        const uint32_t day = (uint32_t)d.day0 + day_rel;
         state_row = (d.state_div == d.S) ? day_rel : row32 / (uint32_t)(d.state_div > 0x7fffffffL ? 0x7fffffffL : d.state_div);
         float* const col = col0 + lane;
         // x part of layer 0: [ctx (zero padding) | z | alignment padding]; k-step s, half hh <-> feature 2s + hh
@@ -1226,6 +1266,7 @@ __global__ void __launch_bounds__(256, 2) mc_decode1_kernel(const LstmSeqArgs a)
     const float* const st = d.state_in + (size_t)state_row * 2 * 2 * HP;
     // of layer 0's input quads only those that hold z are multiplied (the context half is the zero padding)
     const int qx0 = a.L >> 3, qxn = ((2 * a.L + 7) >> 3) - qx0;
+    MC1_STAMP(1);
 
     // ---- the two memory layers
 #pragma unroll
@@ -1262,6 +1303,7 @@ __global__ void __launch_bounds__(256, 2) mc_decode1_kernel(const LstmSeqArgs a)
 #pragma unroll
                 for (int j = 0; j < 4; ++j) bv[j] = bcol[(4 * q + j) * 64];
             });
+            MC1_STAMP(2 * (l * NP + p) + 2);
             lstm_cell<false, 4>(acc, c, hn, false);
             // (pinned: left to itself the compiler sinks the cell math of all four passes below the last
             // pass's GEMM and parks the earlier passes' accumulators in scratch meanwhile)
@@ -1273,6 +1315,7 @@ __global__ void __launch_bounds__(256, 2) mc_decode1_kernel(const LstmSeqArgs a)
                     hold[4 * p + i][jj] = hn[i][jj];
                 }
             __builtin_amdgcn_sched_barrier(0);
+            MC1_STAMP(2 * (l * NP + p) + 3);
         }
         // every pass has read the layer's input: the column now takes the layer's h (natural k-step order)
         float* const colw = col0 + opaque(lane);
@@ -1284,15 +1327,7 @@ __global__ void __launch_bounds__(256, 2) mc_decode1_kernel(const LstmSeqArgs a)
 
     // ---- decoder head: every layer reads the column and overwrites it with its (ReLU'd) outputs
     const int n_layers = hd.n_layers;                             // 4: [Linear . ConvT] ConvT ConvT Conv
-#pragma unroll
-    for (int li = 0; li < 4; ++li) {
-        if (li >= n_layers) break;
-        const DenseLayerArg& ly = hd.layer[li];
-        const bool last = (li == n_layers - 1);
-        const int lv = opaque(lane);
-        const int hh = lv >> 5;
-        const float* const bcol = col0 + lv;
-        f32x16 acc[4];
+    auto bias_init = [&](f32x16 (&acc)[4], const DenseLayerArg& ly, int hh) {
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
             if (t < ly.nt) {
@@ -1304,64 +1339,100 @@ __global__ void __launch_bounds__(256, 2) mc_decode1_kernel(const LstmSeqArgs a)
                 }
             }
         }
-        if (li == 0) {
-            // full K, four tiles: one pinned stream
-            unsigned wo[4];
-            float4 a0[4];
-#pragma unroll
-            for (int i = 0; i < 4; ++i) wo[i] = (unsigned)lv + (unsigned)(i * 64);
-            wload<4>(a0, (const float4*)ly.w, wo, 0u);
-            gemm_stream<4>(acc, a0, (const float4*)ly.w, wo, 4 * 64, ly.nq, [&](int q, float (&bv)[4]) {
-#pragma unroll
-                for (int j = 0; j < 4; ++j) bv[j] = bcol[(4 * q + j) * 64];
-            });
-        } else {
-            // conv layers in pixel-major order: tile t reads the K quads [q0[t], q0[t] + nqb[t]) only
-            float4 wq[kHalfQ];
-#pragma unroll
-            for (int t = 0; t < 4; ++t) {
-                if (t < ly.nt) {
-                    const int q0 = pick4(ly.q0, t), nqb = pick4(ly.nqb, t);
-                    tile_load_band(wq, (const float4*)ly.w, t * 64 + lv, ly.nt * 64, q0, nqb);
-                    tile_mfma_band<4 * kHeadTiles>(acc[t], wq, (const float4*)ly.w, t * 64 + lv, ly.nt * 64, bcol, q0, nqb);
-                }
-            }
-        }
+    };
+    // n_relu, out_f and the aux range are scalars: a tile that lies wholly inside (or outside) them takes a
+    // path without per-value compares
+    auto epilogue = [&](f32x16 (&acc)[4], const DenseLayerArg& ly, int li, int lv) {
+        const bool last = (li == n_layers - 1);
+        const int hh = lv >> 5;
         const bool do_aux = (li == hd.aux_layer) && hd.aux != nullptr;
-        RowIo io = {nullptr, 1, nullptr, nullptr};
-        if (do_aux || last) io = late_rowio(hd, rowtile, lv, 0);
+        const long rr = rowtile * 32 + (lv & 31);
+        const bool row_ok = rr < hd.n_rows;
         float* const colw = col0 + lv;
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
             if (t < ly.nt) {
+                const int f_lo = 32 * t;
+                if (ly.n_relu >= f_lo + 32) {
 #pragma unroll
-                for (int r = 0; r < 16; ++r)
-                    if (feat_of(t, r, hh) < ly.n_relu) acc[t][r] = fmaxf(acc[t][r], 0.0f);
+                    for (int r = 0; r < 16; ++r) acc[t][r] = relu1(acc[t][r]);
+                } else if (ly.n_relu > f_lo) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r)
+                        if (feat_of(t, r, hh) < ly.n_relu) acc[t][r] = relu1(acc[t][r]);
+                }
                 if (!last) {
 #pragma unroll
                     for (int r = 0; r < 16; ++r) colw[(16 * t + r) * 64] = acc[t][r];
                 }
-                if (do_aux || last) {
+                if (do_aux && row_ok && f_lo + 32 > hd.aux_f0 && f_lo < hd.aux_f0 + hd.aux_n) {
+                    float* const ax = hd.aux + (size_t)rr * hd.aux_n - hd.aux_f0;       // (T = 1)
 #pragma unroll
-                    for (int g = 0; g < 4; ++g) {
-                        const int f0 = 32 * t + 8 * g;
-                        if (do_aux && io.aux && f0 + 8 > hd.aux_f0 && f0 < hd.aux_f0 + hd.aux_n) {
+                    for (int r = 0; r < 16; ++r) {
+                        const int f = feat_of(t, r, hh);
+                        if (f >= hd.aux_f0 && f < hd.aux_f0 + hd.aux_n) ax[f] = acc[t][r];
+                    }
+                }
+                if (last && hd.out && row_ok && f_lo < hd.out_f) {
+                    // feature f of this row lives at po0 + f * fs: sample-minor (day, f, sample) or row-major (row, f)
+                    const bool smin = hd.out_mode == 2;
+                    const long fs = smin ? hd.S : 1;
+                    float* po = smin ? hd.out + (size_t)day_rel * hd.out_f * hd.S + sample : hd.out + (size_t)rr * hd.out_f;
+                    po += (size_t)(f_lo + 4 * hh) * fs;
+                    if (f_lo + 32 <= hd.out_f) {
 #pragma unroll
-                            for (int k = 0; k < 4; ++k) {
-                                const int f = f0 + 4 * hh + k;
-                                if (f >= hd.aux_f0 && f < hd.aux_f0 + hd.aux_n) io.aux[f] = acc[t][4 * g + k];
-                            }
-                        }
-                        if (last && io.out && f0 < hd.out_f) {
-                            float* po = io.out + (size_t)(f0 + 4 * hh) * io.fstride;
+                        for (int r = 0; r < 16; ++r) po[(size_t)(8 * (r >> 2) + (r & 3)) * fs] = acc[t][r];
+                    } else {
 #pragma unroll
-                            for (int k = 0; k < 4; ++k)
-                                if (f0 + 4 * hh + k < hd.out_f) po[(size_t)k * io.fstride] = acc[t][4 * g + k];
-                        }
+                        for (int r = 0; r < 16; ++r)
+                            if (feat_of(t, r, hh) < hd.out_f) po[(size_t)(8 * (r >> 2) + (r & 3)) * fs] = acc[t][r];
                     }
                 }
             }
         }
+    };
+    {
+        // first layer ([Linear . ConvT] folded): full K, four tiles, one pinned stream
+        const DenseLayerArg& ly = hd.layer[0];
+        const int lv = opaque(lane);
+        const float* const bcol = col0 + lv;
+        f32x16 acc[4];
+        bias_init(acc, ly, lv >> 5);
+        unsigned wo[4];
+        float4 a0[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) wo[i] = (unsigned)lv + (unsigned)(i * 64);
+        wload<4>(a0, (const float4*)ly.w, wo, 0u);
+        gemm_stream<4>(acc, a0, (const float4*)ly.w, wo, 4 * 64, ly.nq, [&](int q, float (&bv)[4]) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) bv[j] = bcol[(4 * q + j) * 64];
+        });
+        MC1_STAMP(18);
+        epilogue(acc, ly, 0, lv);
+        MC1_STAMP(19);
+    }
+    // conv layers in pixel-major order: tile t reads the K quads [q0[t], q0[t] + nqb[t]) only.  One copy of
+    // the code for all of them (the kernel's instruction footprint matters: eight waves per CU walk it out of
+    // phase with each other)
+#pragma unroll 1
+    for (int li = 1; li < n_layers; ++li) {
+        const DenseLayerArg ly = chain_layer_of(li);
+        const int lv = opaque(lane);
+        const float* const bcol = col0 + lv;
+        f32x16 acc[4];
+        bias_init(acc, ly, lv >> 5);
+        float4 wq[kHalfQ];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            if (t < ly.nt) {
+                const int q0 = pick4(ly.q0, t), nqb = pick4(ly.nqb, t);
+                tile_load_band(wq, (const float4*)ly.w, t * 64 + lv, ly.nt * 64, q0, nqb);
+                tile_mfma_band<4 * kHeadTiles>(acc[t], wq, (const float4*)ly.w, t * 64 + lv, ly.nt * 64, bcol, q0, nqb);
+            }
+        }
+        MC1_STAMP(18 + 2 * li);
+        epilogue(acc, ly, li, lv);
+        MC1_STAMP(19 + 2 * li);
     }
 }
 
@@ -2494,8 +2565,9 @@ extern "C" int vsv_decode(const vsv_dims* dims, const float* packed, const vsv_d
     }
     if (in->state_in && in->state_div < 1) { set_error("vsv_decode: state_div must be >= 1"); return -1; }
     if (in->gate_in && !in->state_in) { set_error("vsv_decode: gate_in comes with the state_in it was computed from"); return -1; }
-    if (out_mode < 0 || out_mode > 1) { set_error("vsv_decode: out_mode must be 0 or 1"); return -1; }
-    if (out_mode == 1 && touts > 0 && (in->S < 1 || n_rows % in->S != 0)) { set_error("vsv_decode: out_mode 1 needs n_rows %% S == 0"); return -1; }
+    if (out_mode < 0 || out_mode >= 2 + lay.Q) { set_error("vsv_decode: out_mode must be 0, 1 or VSV_OUT_CHANNEL(c) with c < n_quantiles"); return -1; }
+    if (out_mode >= 1 && touts > 0 && (in->S < 1 || n_rows % in->S != 0)) { set_error("vsv_decode: sample-minor output needs n_rows %% S == 0"); return -1; }
+    const int out_ch = out_mode >= 2 ? out_mode - 2 : -1;         // sample-minor, ONE decoder channel
     hipStream_t st = (hipStream_t)stream;
     const DecLayout& dc = lay.dec;
     const long rt = (n_rows + 31) / 32;
@@ -2518,8 +2590,9 @@ extern "C" int vsv_decode(const vsv_dims* dims, const float* packed, const vsv_d
     a.n_layers = dc.n_head - 1;
     for (int i = 0; i < a.n_layers; ++i)
         fill_dense(a, i, packed, i < dc.fold_at ? dc.head[i] : (i == dc.fold_at ? dc.head_fold : dc.head[i + 1]));
+    if (out_ch >= 0) fill_dense(a, a.n_layers - 1, packed, dc.head_ch[out_ch]);   // (the other channels are not computed)
     a.n_rows = n_rows; a.n_rowtiles = rt; a.T = touts;
-    a.out_mode = out_mode == 0 ? 1 : 2; a.out = surf_out; a.out_f = dc.n_surf; a.S = l.din.S;
+    a.out_mode = out_mode == 0 ? 1 : 2; a.out = surf_out; a.out_f = out_ch >= 0 ? 25 : dc.n_surf; a.S = l.din.S;
     a.aux_layer = (lay.X > 0 && ex_out) ? dc.ex_layer - 1 : -1;
     a.aux = ex_out; a.aux_f0 = dc.ex_f0; a.aux_n = lay.X;
 

@@ -25,6 +25,7 @@ namespace vsv {
 
 constexpr int kMaxDenseLayers = 8;
 constexpr int kMaxFeat = 128;      // widest activation vector (4 tiles of 32)
+constexpr int kMaxChannels = 5;  // n_quantiles * 25 <= kMaxFeat
 constexpr int kHeadTiles = 4;      // decoder-head layers (all but the last) are padded to 4 tiles
 
 struct Sec {                       // one packed layer
@@ -59,6 +60,9 @@ struct DecLayout {
     // activation between them (reference :495-503), so generation runs their product as ONE layer
     Sec head_fold;
     int fold_at = -1;
+    // inference only: the output Conv restricted to ONE decoder channel (25 outputs in one tile), for
+    // callers that reduce a single channel of the Monte-Carlo draw (vsv_decode, VSV_OUT_CHANNEL)
+    Sec head_ch[kMaxChannels];
     int ex_layer = -1;             // head layer whose features [ex_f0, ex_f0+X) are the ex output
     int ex_f0 = 0;
     int n_surf = 0;                // Q*25

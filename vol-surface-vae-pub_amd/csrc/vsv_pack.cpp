@@ -176,6 +176,8 @@ int make_layout(const vsv_dims& d, Layout& lay, const char** msg) {
     dc.fold_at = lay.NI;
     dc.head_fold = alloc_sec(cur, dc.head[dc.fold_at].nq, kHeadTiles, dc.head[dc.fold_at + 1].n_out,
                              dc.head[dc.fold_at + 1].n_relu);
+    // the output Conv one channel at a time (appended likewise)
+    for (int c = 0; c < lay.Q; ++c) dc.head_ch[c] = alloc_sec(cur, 4 * kHeadTiles, 1, 25, 0);
     lay.total = cur;
     return 0;
 }
@@ -477,6 +479,10 @@ extern "C" int vsv_pack_weights(const vsv_dims* dims, const vsv_raw_weights* raw
         WFn W = [&, n_in](int r, int c) { return M[(size_t)r * n_in + c]; };
         BFn B = [=](int r) { return bias[r / 25]; };
         pack_sec(out, dc.head[hi++], out_nat32(lay.Q * 25), in_perm_px(n_in, cin), W, B);
+        for (int c = 0; c < lay.Q; ++c) {
+            OutMap one = [=](int t, int i) { return (t == 0 && i < 25) ? c * 25 + i : -1; };
+            pack_sec(out, dc.head_ch[c], one, in_perm_px(n_in, cin), W, B);
+        }
     }
     // the bands are structural: nothing outside them may be non-zero
     for (int li = 0; li < dc.n_head; ++li) {
@@ -520,6 +526,7 @@ extern "C" int vsv_debug_layout(const vsv_dims* dims, long long* out, int cap) {
     for (long long x : sc) v.push_back(x);
     put(lay.dec.head_fold);
     v.push_back(lay.dec.fold_at);
+    for (int c = 0; c < lay.Q; ++c) put(lay.dec.head_ch[c]);
     if (out) {
         if (cap < (int)v.size()) { set_error("vsv_debug_layout: buffer too small"); return -1; }
         for (size_t i = 0; i < v.size(); ++i) out[i] = v[i];

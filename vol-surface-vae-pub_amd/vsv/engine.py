@@ -380,6 +380,11 @@ class Engine:
         return enc, ctx
 
     # -- decoder -----------------------------------------------------------
+    @staticmethod
+    def OUT_CHANNEL(c: int) -> int:
+        """vsv_decode's out_mode for sample-minor output of decoder channel c alone (VSV_OUT_CHANNEL)."""
+        return 2 + int(c)
+
     def decode(self, n_rows: int, T: int, t_out0: int, *,
                ctx: Optional[torch.Tensor] = None, ctx_div: int = 1,
                zb: Optional[torch.Tensor] = None, lv: Optional[torch.Tensor] = None, z_div: int = 1,
@@ -390,7 +395,9 @@ class Engine:
                gate_in: Optional[torch.Tensor] = None, want_gates: bool = False,
                want_state: bool = False, want_z: bool = False, out_mode: int = 0):
         """See vsv_decode in include/vsv_hip.h.  ctx (n,ctx_T,L); zb/lv (n,z_T,L);
-        eps (n_rows,eps_T,L).  Returns dict(surf, ex, state, z, gates)."""
+        eps (n_rows,eps_T,L).  out_mode 0: surf (n_rows, T', Q, 5, 5); 1: (n_rows/S, T', Q*25, S);
+        OUT_CHANNEL(c) = 2 + c: (n_rows/S, T', 25, S), decoder channel c only (the others are not computed).
+        Returns dict(surf, ex, state, z, gates)."""
         din = _lib.VsvDecodeIn()
         if ctx is not None:
             ctx = _f32c(ctx, self.device)
@@ -433,8 +440,10 @@ class Engine:
         if touts > 0:
             if out_mode == 0:
                 surf = torch.empty((n_rows, touts, self.Q, 5, 5), dtype=torch.float32, device=dev)
-            else:
+            elif out_mode == 1:
                 surf = torch.empty((n_rows // S, touts, self.Q * 25, S), dtype=torch.float32, device=dev)
+            else:
+                surf = torch.empty((n_rows // S, touts, 25, S), dtype=torch.float32, device=dev)
             if self.X > 0:
                 ex = torch.empty((n_rows, touts, self.X), dtype=torch.float32, device=dev)
         ws = self._ws(self.lib.vsv_decode_ws_bytes(C.byref(self.dims), n_rows, T, t_out0))

@@ -151,7 +151,7 @@ def prior_mc_windows(eng: Engine, vol: torch.Tensor, ex: Optional[torch.Tensor],
         # as many days per decode launch as fit 2 GiB of samples: a launch ends with a partly filled
         # round of workgroups (512 resident at a time), so fewer, longer launches waste less
         # (4000 days x 1000 samples: one launch 12.5 ms vs eight of 1.65 ms = 13.2 ms)
-        chunk_days = max(1, (1 << 31) // (n_samples * horizon * Q * 25 * 4))
+        chunk_days = max(1, (1 << 31) // (n_samples * horizon * (Q if channel is None else 1) * 25 * 4))
     # context prefix for ALL days in one go (three sequential-in-time kernels whose
     # parallelism is the day count): posterior means, context embedding, decoder state
     w0 = first_day - ctx_len                               # first calendar row of the first window
@@ -166,14 +166,16 @@ def prior_mc_windows(eng: Engine, vol: torch.Tensor, ex: Optional[torch.Tensor],
             ev = (Event(), Event())
             eng.lib.vsv_profile_next_decode(ev[0].h, ev[1].h)
             decode_events.append((ev[0], ev[1], nd * n_samples))
+        # one channel wanted: the decoder neither computes nor stores the others
         r = eng.decode(nd * n_samples, horizon, 0, state_in=state[d0:d0 + nd], state_div=n_samples,
-                       gate_in=gates[d0:d0 + nd], seed=seed, S=n_samples, day0=day_index0 + d0, out_mode=1)
-        smp = r["surf"]                                    # (nd, H, Q*25, S)
+                       gate_in=gates[d0:d0 + nd], seed=seed, S=n_samples, day0=day_index0 + d0,
+                       out_mode=1 if channel is None else eng.OUT_CHANNEL(channel))
+        smp = r["surf"]                                    # (nd, H, Q*25 | 25, S)
         # reduced on the side stream while the next chunk decodes
         if channel is None:
             q = eng.reduce_async(smp, qs, Q * 25, None, 1).view(nd, horizon, len(qs), Q, 5, 5)
         else:
-            q = eng.reduce_async(smp, qs, 25, channel, Q).view(nd, horizon, len(qs), 5, 5)
+            q = eng.reduce_async(smp, qs, 25, None, 1).view(nd, horizon, len(qs), 5, 5)
         outs.append(q)
     eng.join_side()
     return torch.cat(outs, dim=0)
@@ -470,12 +472,13 @@ def oracle_mc_windows(eng: Engine, vol: torch.Tensor, ex: Optional[torch.Tensor]
         nd = min(chunk_days, n_days - d0)
         r = eng.decode(nd * n_samples, T, ctx_len, ctx=ctx[d0:d0 + nd], ctx_div=n_samples,
                        zb=zm[d0:d0 + nd], lv=zl[d0:d0 + nd], z_div=n_samples,
-                       seed=seed, S=n_samples, day0=day_index0 + d0, out_mode=1)
-        smp = r["surf"]                                                       # (nd, H, Q*25, S)
+                       seed=seed, S=n_samples, day0=day_index0 + d0,
+                       out_mode=1 if channel is None else eng.OUT_CHANNEL(channel))
+        smp = r["surf"]                                                       # (nd, H, Q*25 | 25, S)
         if channel is None:
             q = eng.reduce_async(smp, qs, Q * 25, None, 1).view(nd, horizon, len(qs), Q, 5, 5)
         else:
-            q = eng.reduce_async(smp, qs, 25, channel, Q).view(nd, horizon, len(qs), 5, 5)
+            q = eng.reduce_async(smp, qs, 25, None, 1).view(nd, horizon, len(qs), 5, 5)
         outs.append(q)
     eng.join_side()
     return torch.cat(outs, dim=0)

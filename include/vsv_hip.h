@@ -394,9 +394,13 @@ int vsv_weight_grads(const vsv_wgrad *d, void *stream);
  * channels (QuantileLoss, :28-45; qw = weights / sum(weights)), ex-feature MSE ("l2") or L1
  * on the first ex_n features (:1115-1118), KL over all T positions (:1123-1124).
  * sums (3 doubles, zeroed by the caller) receive re_surface, re_ex_feats, kl; the gradients
- * are those of  re_surface + ex_weight*re_ex_feats + kl_weight*kl. */
+ * are those of  grad_scale * (re_surface + ex_weight*re_ex_feats + kl_weight*kl).
+ * Hs > H: pred / ex_pred / d_pred / d_ex hold Hs steps per row and the loss is over the last H of
+ * them (gradient zero on the others) -- train_step_multihorizon's horizons (:1204-1249) share one
+ * decoder launch that evaluates the head on the longest horizon's steps, and grad_scale is the
+ * horizon's weight.  Hs = 0 means H, grad_scale = 0 means 1. */
 typedef struct vsv_loss {
-    const float *pred, *target;             /* (B,H,Q,25); surface (B,T,25), last H steps are the targets */
+    const float *pred, *target;             /* (B,Hs,Q,25); surface (B,T,25), last H steps are the targets */
     int B, H, T, Q;
     float q[8], qw[8];
     const float *ex_pred, *ex_target;       /* (B,H,X) or NULL; (B,T,X) */
@@ -405,6 +409,7 @@ typedef struct vsv_loss {
     const float *zm, *zl; int L;            /* (B,T,L) */
     float *d_pred, *d_ex, *d_zm, *d_zl;
     double *sums;
+    int Hs;  float grad_scale;
 } vsv_loss;
 int vsv_loss_grad(const vsv_loss *d, void *stream);
 

@@ -365,23 +365,52 @@ def test_train_losses_and_gradients_vs_reference(name):
 
 
 def test_multihorizon_losses_and_gradients_vs_reference():
-    """train_step_multihorizon's accumulated loss and gradient (golden g5): one forward/backward
-    per horizon with its own injected noise, weights {1: 1.0, 7: 0.8, 14: 0.6, 30: 0.4}."""
+    """train_step_multihorizon's accumulated loss and gradient (golden g5; weights {1: 1.0, 7: 0.8, 14: 0.6,
+    30: 0.4}, each horizon's forward with its own injected noise): (a) one forward/backward per horizon,
+    summed; (b) the horizons as row groups of ONE forward/backward (loss_and_grads_multihorizon);
+    (c) through the drop-in class, model.train_step_multihorizon with the private noise hook."""
+    from vae.cvae_with_mem_randomized import CVAEMemRand
     g = load_golden("g5_multih_ex5_B4_T50")
     cfg, eng, te = _train_setup(g)
     for k in ("ex_loss_on_ret_only", "ex_feats_loss_type", "kl_weight", "re_feat_weight"):
         v = g["cfg_" + k]
         cfg[k] = v.item() if v.dtype.kind != "U" else str(v)
     wts = {1: 1.0, 7: 0.8, 14: 0.6, 30: 0.4}
+    hz = g["horizons"].tolist()
+    names = [n for n, _ in vo.state_dict_spec(cfg)]
     total, gp_sum, hl = 0.0, None, []
-    for i, h in enumerate(g["horizons"].tolist()):
+    for i, h in enumerate(hz):
         losses, gp, _ = te.loss_and_grads(_t(g["surface"]), _t(g["ex_feats"]), h, _loss_cfg(cfg, g), eps=_t(g["eps"][i]))
         hl.append(float(losses["loss"]))
         total += wts[h] * float(losses["loss"])
         gp_sum = wts[h] * gp if gp_sum is None else gp_sum + wts[h] * gp
     assert np.max(np.abs(np.asarray(hl) - g["horizon_losses"]) / np.abs(g["horizon_losses"])) <= 1e-3
     assert abs(total - float(g["loss"])) <= 1e-3 * abs(float(g["loss"]))
-    _check_grads(g, [n for n, _ in vo.state_dict_spec(cfg)], te.param_grads(gp_sum))
+    _check_grads(g, names, te.param_grads(gp_sum))
+    # (b)
+    losses, gp = te.loss_and_grads_multihorizon(_t(g["surface"]), _t(g["ex_feats"]), hz, [wts[h] for h in hz],
+                                                _loss_cfg(cfg, g), eps=[_t(e) for e in g["eps"]])
+    assert np.max(np.abs(_n(losses["horizon_losses"]) - g["horizon_losses"]) / np.abs(g["horizon_losses"])) <= 1e-3
+    assert abs(float(losses["loss"]) - float(g["loss"])) <= 1e-3 * abs(float(g["loss"]))
+    assert abs(float(losses["loss"]) - total) <= 1e-5 * abs(total)
+    _check_grads(g, names, te.param_grads(gp))
+    # (c)
+    cfg.update(device="cuda:0")
+    model = CVAEMemRand(dict(cfg))
+    W = vo.init_weights(cfg, int(g["seed"]), float(g["scale"]), np.float32)
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in W.items()}, strict=False)
+    model.eval()                                                   # (no dropout: the golden's reference ran without)
+    opt = torch.optim.SGD(model.parameters(), lr=0.0)
+    out = model.train_step_multihorizon({"surface": _t(g["surface"]), "ex_feats": _t(g["ex_feats"])}, opt, horizons=hz,
+                                        _eps_per_horizon=[_t(e) for e in g["eps"]])
+    assert isinstance(out["loss"], float) and abs(out["loss"] - float(g["loss"])) <= 1e-3 * abs(float(g["loss"]))
+    assert list(out["horizon_losses"]) == hz
+    assert np.max(np.abs(np.asarray([out["horizon_losses"][h] for h in hz]) - g["horizon_losses"])
+                  / np.abs(g["horizon_losses"])) <= 1e-3
+    for k in ("reconstruction_loss", "kl_loss"):
+        if k in g:
+            assert abs(out[k] - float(g[k])) <= 1e-3 * abs(float(g[k])) + 1e-9, k
+    _check_grads(g, [n for n, _ in model.named_parameters()], [p.grad for _, p in model.named_parameters()])
 
 
 @pytest.mark.parametrize("L,X,B,T,h,p,mem", [(5, 3, 37, 12, 3, 0.25, "lstm"), (12, 3, 8, 30, 7, 0.3, "lstm"),

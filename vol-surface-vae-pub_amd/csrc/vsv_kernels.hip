@@ -1219,7 +1219,7 @@ __global__ void __launch_bounds__(256, 2) mc_decode1_kernel(const LstmSeqArgs a)
     constexpr int HP = 8 * NT;
     constexpr int NP = NT / 4;                                    // passes of four gate tiles
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const long rowtile = (long)blockIdx.x * 4 + wave;
+    const long rowtile = (long)blockIdx.x * (blockDim.x >> 6) + wave;
     if (rowtile >= a.n_rowtiles) return;                          // (no barriers below: a wave may leave alone)
     float* const col0 = smem + (size_t)wave * (64 * 64);          // this wave's activation column, without the lane
     const vsv_decode_in& d = a.din;
@@ -1757,39 +1757,44 @@ __global__ void __launch_bounds__(256) loss_grad_kernel(const LossArgs a) {
     __shared__ double red[3][256];
     const int tid = threadIdx.x;
     double s0 = 0.0, s1 = 0.0, s2 = 0.0;
-    const long n_s = (long)a.B * a.H * a.Q * 25;
+    // pred / d_pred hold Hs >= H steps per row; the loss is over the last H of them (the gradient of the
+    // others is written as zero)
+    const int Hs = a.Hs > 0 ? a.Hs : a.H, h_skip = Hs - a.H;
+    const double gs = a.grad_scale != 0.0f ? (double)a.grad_scale : 1.0;
+    const long n_s = (long)a.B * Hs * a.Q * 25;
     const double inv_s = 1.0 / ((double)a.B * a.H * 25);
     for (long i = (long)blockIdx.x * 256 + tid; i < n_s; i += (long)gridDim.x * 256) {
         const int p = (int)(i % 25);
         const int qi = (int)((i / 25) % a.Q);
         const long bh = i / (25L * a.Q);
-        const int h = (int)(bh % a.H);
-        const long b = bh / a.H;
+        const int h = (int)(bh % Hs) - h_skip;
+        const long b = bh / Hs;
+        if (h < 0) { a.d_pred[i] = 0.0f; continue; }
         const float tg = a.target[((size_t)b * a.T + (a.T - a.H + h)) * 25 + p];
         const float e = tg - a.pred[i];
         const float qq = a.q[qi];
         const float lo = (qq - 1.0f) * e, hi = qq * e;
         s0 += (double)a.qw[qi] * (double)fmaxf(lo, hi) * inv_s;
         const float d = (e > 0.0f) ? -qq : ((e < 0.0f) ? (1.0f - qq) : (0.5f - qq));
-        a.d_pred[i] = (float)((double)a.qw[qi] * d * inv_s);
+        a.d_pred[i] = (float)((double)a.qw[qi] * d * inv_s * gs);
     }
     if (a.ex_pred) {
-        const long n_e = (long)a.B * a.H * a.X;
+        const long n_e = (long)a.B * Hs * a.X;
         const double inv_e = 1.0 / ((double)a.B * a.H * a.ex_n);
         for (long i = (long)blockIdx.x * 256 + tid; i < n_e; i += (long)gridDim.x * 256) {
             const int f = (int)(i % a.X);
             const long bh = i / a.X;
-            const int h = (int)(bh % a.H);
-            const long b = bh / a.H;
+            const int h = (int)(bh % Hs) - h_skip;
+            const long b = bh / Hs;
             float g = 0.0f;
-            if (f < a.ex_n) {
+            if (h >= 0 && f < a.ex_n) {
                 const float d = a.ex_pred[i] - a.ex_target[((size_t)b * a.T + (a.T - a.H + h)) * a.X + f];
                 if (a.ex_l2) {
                     s1 += (double)d * d * inv_e;
-                    g = (float)(2.0 * d * inv_e * a.ex_weight);
+                    g = (float)(2.0 * d * inv_e * a.ex_weight * gs);
                 } else {
                     s1 += (double)fabsf(d) * inv_e;
-                    g = (float)(((d > 0.0f) - (d < 0.0f)) * inv_e * a.ex_weight);
+                    g = (float)(((d > 0.0f) - (d < 0.0f)) * inv_e * a.ex_weight * gs);
                 }
             }
             a.d_ex[i] = g;
@@ -1801,8 +1806,8 @@ __global__ void __launch_bounds__(256) loss_grad_kernel(const LossArgs a) {
         const float mu = a.zm[i], lv = a.zl[i];
         const float ev = expf(lv);
         s2 += -0.5 * (1.0 + (double)lv - (double)ev - (double)mu * mu) * inv_z;
-        a.d_zm[i] = (float)((double)mu * inv_z * a.kl_weight);
-        a.d_zl[i] = (float)(-0.5 * (1.0 - (double)ev) * inv_z * a.kl_weight);
+        a.d_zm[i] = (float)((double)mu * inv_z * a.kl_weight * gs);
+        a.d_zl[i] = (float)(-0.5 * (1.0 - (double)ev) * inv_z * a.kl_weight * gs);
     }
     red[0][tid] = s0; red[1][tid] = s1; red[2][tid] = s2;
     __syncthreads();
@@ -2605,10 +2610,11 @@ extern "C" int vsv_decode(const vsv_dims* dims, const float* packed, const vsv_d
     int rc;
     if (mc_decode1_applies(l, lay, T, t_out0, state_out, z_out)) {
         // the Monte-Carlo one-day draw: one wave per 32 rows, no barriers (mc_decode1_kernel)
-        const size_t lds = (size_t)4 * 64 * 64 * sizeof(float);
+        constexpr int wpb = 4;                                     // (1, 2 or 4 waves per workgroup measure the same)
+        const size_t lds = (size_t)wpb * 64 * 64 * sizeof(float);
         rc = set_lds(mc_decode1_kernel<16>, lds);
         if (!rc) {
-            hipLaunchKernelGGL(mc_decode1_kernel<16>, dim3((unsigned)((rt + 3) / 4)), dim3(256), lds, st, l);
+            hipLaunchKernelGGL(mc_decode1_kernel<16>, dim3((unsigned)((rt + wpb - 1) / wpb)), dim3(64 * wpb), lds, st, l);
             rc = launch_check("mc_decode1_kernel");
         }
     } else {
@@ -3094,6 +3100,7 @@ extern "C" int vsv_loss_grad(const vsv_loss* d, void* stream) {
         set_error("vsv_loss_grad: null pointer"); return -1;
     }
     if (d->B < 1 || d->H < 1 || d->T < d->H || d->Q < 1 || d->Q > 8 || d->L < 1) { set_error("vsv_loss_grad: bad sizes"); return -1; }
+    if (d->Hs != 0 && d->Hs < d->H) { set_error("vsv_loss_grad: Hs < H"); return -1; }
     if (d->ex_pred && (!d->ex_target || !d->d_ex || d->X < 1 || d->ex_n < 1 || d->ex_n > d->X)) { set_error("vsv_loss_grad: bad ex arguments"); return -1; }
     hipLaunchKernelGGL(loss_grad_kernel, dim3(64), dim3(256), 0, (hipStream_t)stream, *d);
     return launch_check("loss_grad_kernel");

@@ -650,27 +650,30 @@ class CVAEMemRand(BaseVAE):
         optimizer.step()
         return losses
 
-    def train_step_multihorizon(self, x, optimizer: torch.optim.Optimizer, horizons=[1, 7, 14, 30]):
-        """Reference :1139-1263: one forward per horizon (fresh noise each), losses weighted
-        {1: 1.0, 7: 0.8, 14: 0.6, 30: 0.4} (default 1.0), one backward, no clipping.  Returns floats."""
+    def train_step_multihorizon(self, x, optimizer: torch.optim.Optimizer, horizons=[1, 7, 14, 30],
+                                _eps_per_horizon=None):
+        """Reference :1139-1263: a forward per horizon (fresh noise each), losses weighted
+        {1: 1.0, 7: 0.8, 14: 0.6, 30: 0.4} (default 1.0), one backward, no clipping.  Returns floats.
+        The horizons run as row groups of ONE forward/backward (TrainEngine.loss_and_grads_multihorizon);
+        _eps_per_horizon (private, like vae.utils.train_autoregressive_step's _eps_steps): a sequence of
+        (B, T, latent_dim) tensors, the posterior noise of each horizon's forward, for parity tests."""
         weights = {1: 1.0, 7: 0.8, 14: 0.6, 30: 0.4}
-        surface = x["surface"]
-        T = surface.shape[0] if surface.dim() == 3 else surface.shape[1]
+        surf, ex = self._batched(x)
+        T = surf.shape[1]
         max_horizon = max(horizons)
         if T < 1 + max_horizon:
             raise ValueError(f"Insufficient sequence length: T={T}, max_horizon={max_horizon}, "
                              f"need at least T >= {1 + max_horizon}")
         optimizer.zero_grad()
-        total_loss = total_re = total_kl = 0.0
-        horizon_losses = {}
-        for h in horizons:
-            w = weights.get(h, 1.0)
-            losses, gp = self._loss_terms(x, h, True)
-            self._accumulate_grads(gp, w)
-            total_loss += w * losses["loss"].item()
-            total_re += w * losses["reconstruction_loss"].item()
-            total_kl += w * losses["kl_loss"].item()
-            horizon_losses[h] = losses["loss"].item()
+        p = float(self.config.get("mem_dropout", 0) or 0) if self.training else 0.0
+        te = self._train_engine()
+        losses, gp = te.loss_and_grads_multihorizon(
+            surf, ex, list(horizons), [weights.get(h, 1.0) for h in horizons], self._loss_cfg(),
+            eps=_eps_per_horizon, seed=self._draw_seed(), dropout_p=p, dropout_seed=self._draw_seed() if p > 0 else 0)
+        self._accumulate_grads(gp)
         optimizer.step()
-        return {"loss": total_loss, "reconstruction_loss": total_re, "kl_loss": total_kl,
-                "horizon_losses": horizon_losses}
+        # one read-back for all the reported numbers
+        vals = torch.cat([torch.stack([losses["loss"], losses["reconstruction_loss"], losses["kl_loss"]]),
+                          losses["horizon_losses"]]).tolist()
+        return {"loss": vals[0], "reconstruction_loss": vals[1], "kl_loss": vals[2],
+                "horizon_losses": {h: v for h, v in zip(horizons, vals[3:])}}

@@ -16,7 +16,7 @@ from __future__ import annotations
 
 import ctypes as C
 import os
-from typing import Dict, List, Optional
+from typing import Sequence, Dict, List, Optional
 
 import numpy as np
 import torch
@@ -406,11 +406,16 @@ class TrainEngine:
     # -- one forward/backward ----------------------------------------------------------
     def forward_saved(self, surf: torch.Tensor, ex: Optional[torch.Tensor], horizon: int,
                       eps: Optional[torch.Tensor] = None, seed: int = 0,
-                      dropout_p: float = 0.0, dropout_seed: int = 0):
+                      dropout_p: float = 0.0, dropout_seed: int = 0,
+                      ctx_len: Optional[int] = None, ctx_mask: Optional[torch.Tensor] = None):
         """CVAEMemRand.forward (:1022-1074) keeping what the backward kernels need.  -> call state `c`
         with c.outputs = {"surf" (B,H,Q,5,5), "ex" (B,H,X) | None, "z_mean", "z_log_var", "z" (B,T,L)}.
         dropout_p > 0: nn.LSTM's inter-layer dropout (train mode) in all three memories, masks keyed
-        by dropout_seed (vsv_hip.h, vsv_train_save)."""
+        by dropout_seed (vsv_hip.h, vsv_train_save).
+        ctx_len / ctx_mask (B, ctx_len, 1): rows with DIFFERENT context lengths in one call (the horizons
+        of train_step_multihorizon as row groups): the context encoder runs ctx_len >= T - horizon steps
+        and a row's embedding is zeroed from its own context length on -- the zero padding of :1061-1062;
+        the head is evaluated on the last `horizon` steps of every row."""
         eng, lib, lay = self.eng, self.lib, self.lay
         dev = self.dev
         L, X, Q, NL = self.L, self.X, self.Q, self.NL
@@ -419,6 +424,9 @@ class TrainEngine:
         B, T, rt = c.B, c.T, c.rt
         c.horizon = horizon
         Cn = c.Cn = T - horizon
+        Cc = c.Cc = Cn if ctx_len is None else int(ctx_len)          # context-encoder steps (>= Cn)
+        assert Cn <= Cc < T
+        c.ctx_mask = ctx_mask
         st = self._stream()
         main = torch.cuda.current_stream(dev)
         if eng._side is None:
@@ -427,9 +435,11 @@ class TrainEngine:
         with torch.cuda.device(dev):
             # the two encoders are independent: context encoder on the side stream
             side.wait_stream(main)
-            ctx_out, c.sv_c = self._enc_fwd(c, 1, Cn, side)
+            ctx_out, c.sv_c = self._enc_fwd(c, 1, Cc, side)
             enc_out, c.sv_e = self._enc_fwd(c, 0, T, main)
             main.wait_stream(side)
+            if ctx_mask is not None:
+                ctx_out = ctx_out * ctx_mask
             zm, zl = enc_out[..., :L].contiguous(), enc_out[..., L:].contiguous()
             # ---- decoder
             NI, NIo = rt * T, rt * horizon
@@ -442,7 +452,7 @@ class TrainEngine:
                 setattr(s, k, v.data_ptr())
             self._set_drop(c, s, sv_d, NI, NTd, 2)
             din = _lib.VsvDecodeIn()
-            din.ctx, din.ctx_rs, din.ctx_T, din.ctx_div = ctx_out.data_ptr(), Cn * L, Cn, 1
+            din.ctx, din.ctx_rs, din.ctx_T, din.ctx_div = ctx_out.data_ptr(), Cc * L, Cc, 1
             din.zb, din.lv, din.z_rs, din.z_T, din.z_div = zm.data_ptr(), zl.data_ptr(), T * L, T, 1
             din.mu0, din.std0 = 0.0, 1.0
             if eps is not None:
@@ -457,6 +467,7 @@ class TrainEngine:
                                       z.data_ptr(), s_out.data_ptr(), _ptr(e_out), C.byref(s), st)
             _lib.check(rc, "vsv_train_decode")
         c.sv_d = sv_d
+        c.ctx_out = ctx_out                                        # (referenced by the launch above)
         c.outputs = {"surf": s_out, "ex": e_out, "z_mean": zm, "z_log_var": zl, "z": z}
         return c
 
@@ -469,7 +480,7 @@ class TrainEngine:
         lay, dev = self.lay, self.dev
         L, X, Q = self.L, self.X, self.Q
         NTd = lay["NTd"]
-        B, T, rt, Cn, horizon = c.B, c.T, c.rt, c.Cn, c.horizon
+        B, T, rt, Cn, horizon = c.B, c.T, c.rt, c.Cc, c.horizon
         sv_d, d = c.sv_d, lay["dec"]
         NIo = rt * horizon
         zm, z = c.outputs["z_mean"], c.outputs["z"]
@@ -500,7 +511,7 @@ class TrainEngine:
                 self._acc_layer(c, hd[li], g[:, : 16 * hd[li].nt], sv_d["head_acts"][li][:, : 4 * hd[li].nq])
             # decoder LSTM
             dx = self._e(B, T, 2 * L)
-            dg = self._lstm_bwd(c, "d", lay["Hd"], NTd, sv_d, T, Cn, dh_top, 1, 2, dx_rows=dx, dx_f=2 * L)
+            dg = self._lstm_bwd(c, "d", lay["Hd"], NTd, sv_d, T, c.Cn, dh_top, 1, 2, dx_rows=dx, dx_f=2 * L)
             self._lstm_wgrads(c, gp, d["lstm"], sv_d, dg, T, NTd, sv_d["xe"])
             # reparameterisation (:199) and the context embedding
             dz = dx[..., L:]
@@ -510,7 +521,7 @@ class TrainEngine:
             dzl_t = dz * 0.5 * (z - zm)
             if d_zl is not None:
                 dzl_t = dzl_t + d_zl
-            d_ctx = dx[:, :Cn, :L].contiguous()
+            d_ctx = dx[:, :Cn, :L].contiguous() if c.ctx_mask is None else dx[:, :Cn, :L] * c.ctx_mask
 
             d_enc = torch.cat([dzm_t, dzl_t], dim=-1).contiguous()
             side.wait_stream(main)
@@ -583,6 +594,81 @@ class TrainEngine:
                 return losses, None, outputs
             gp = self.backward_saved(c, d_pred, d_ex, d_zm, d_zl, None, want_input_grad)
         return losses, gp, outputs
+
+    def loss_and_grads_multihorizon(self, surf: torch.Tensor, ex: Optional[torch.Tensor], horizons: Sequence[int],
+                                    weights: Sequence[float], loss_cfg: dict,
+                                    eps: Optional[Sequence[torch.Tensor]] = None, seed: int = 0,
+                                    want_grads: bool = True, dropout_p: float = 0.0, dropout_seed: int = 0):
+        """train_step_multihorizon's accumulated loss (:1204-1255) in ONE forward/backward: the G horizons
+        are G row groups of a G*B-row batch (row g*B + b = sample b predicting horizons[g] days ahead).  Every
+        group is a literal forward of the reference for its horizon -- its own posterior noise (eps[g]
+        (B,T,L) or Philox keyed by the row) and, with dropout, its own masks -- so the numbers are those of
+        G separate passes, while each recurrent kernel is launched once with G times the row tiles (a step is
+        bound by the launches' sequential time steps, not by their width).  The context encoder runs
+        T - min(horizons) steps for all rows and a group's embedding is zeroed from its own context length
+        on; the decoder head is evaluated on the last max(horizons) steps and the loss kernel reads each
+        group's last horizons[g] of them, scaling the gradients by weights[g].
+        -> ({"loss", "reconstruction_loss", "kl_loss": weighted sums, "horizon_losses": (G,)} float64 device
+        tensors, gradient w.r.t. the packed blob or None)."""
+        lib, dev = self.lib, self.dev
+        L, X, Q = self.L, self.X, self.Q
+        G = len(horizons)
+        hs = [int(h) for h in horizons]
+        hmax, hmin = max(hs), min(hs)
+        with torch.cuda.device(dev):
+            surf = surf.to(dev, torch.float32)
+            B, T = surf.shape[:2]
+            assert T - hmax >= 1
+            surf_r = surf.reshape(B, T, 25).repeat(G, 1, 1)
+            ex_r = ex.to(dev, torch.float32).repeat(G, 1, 1) if X > 0 else None
+            Cc = T - hmin
+            key = (tuple(hs), B, T)
+            cache = self.__dict__.setdefault("_mh_masks", {})
+            mask = cache.get(key)
+            if mask is None:
+                m = np.zeros((G, B, Cc, 1), dtype=np.float32)
+                for g, h in enumerate(hs):
+                    m[g, :, : T - h] = 1.0
+                mask = cache[key] = torch.from_numpy(m.reshape(G * B, Cc, 1)).to(dev)
+            eps_r = None
+            if eps is not None:
+                eps_r = torch.cat([e.to(dev, torch.float32).reshape(B, T, L) for e in eps], dim=0)
+            c = self.forward_saved(surf_r, ex_r, hmax, eps_r, seed, dropout_p, dropout_seed, ctx_len=Cc, ctx_mask=mask)
+            o = c.outputs
+            s_out, e_out, zm, zl = o["surf"], o["ex"], o["z_mean"], o["z_log_var"]
+            st = self._stream()
+            BG = G * B
+            d_pred, d_zm, d_zl = self._e(BG, hmax, Q * 25), self._e(BG, T, L), self._e(BG, T, L)
+            d_ex = self._e(BG, hmax, X) if X > 0 else None
+            sums = torch.zeros((G, 3), dtype=torch.float64, device=dev)
+            qw = np.asarray(loss_cfg["quantile_weights"], dtype=np.float64)
+            klw = float(loss_cfg["kl_weight"])
+            for g, h in enumerate(hs):
+                r0 = g * B
+                la = _lib.VsvLoss()
+                la.pred, la.target = s_out[r0:].data_ptr(), c.surf[r0:].data_ptr()
+                la.B, la.H, la.T, la.Q, la.Hs = B, h, T, Q, hmax
+                la.grad_scale = float(weights[g])
+                for i in range(Q):
+                    la.q[i] = float(loss_cfg["quantiles"][i])
+                    la.qw[i] = float(qw[i] / qw.sum())
+                if X > 0:
+                    la.ex_pred, la.ex_target, la.d_ex = e_out[r0:].data_ptr(), c.ex[r0:].data_ptr(), d_ex[r0:].data_ptr()
+                    la.X, la.ex_n, la.ex_l2 = X, int(loss_cfg["ex_n"]), int(loss_cfg["ex_l2"])
+                la.ex_weight, la.kl_weight = float(loss_cfg["ex_weight"]), klw
+                la.zm, la.zl, la.L = zm[r0:].data_ptr(), zl[r0:].data_ptr(), L
+                la.d_pred, la.d_zm, la.d_zl = d_pred[r0:].data_ptr(), d_zm[r0:].data_ptr(), d_zl[r0:].data_ptr()
+                la.sums = sums[g:].data_ptr()
+                _lib.check(lib.vsv_loss_grad(C.byref(la), st), "vsv_loss_grad")
+            w = torch.tensor([float(x) for x in weights], dtype=torch.float64, device=dev)
+            recon = sums[:, 0] + float(loss_cfg["ex_weight"]) * sums[:, 1] if X > 0 else sums[:, 0]
+            hl = recon + klw * sums[:, 2]
+            losses = {"loss": (w * hl).sum(), "reconstruction_loss": (w * recon).sum(),
+                      "kl_loss": (w * sums[:, 2]).sum(), "horizon_losses": hl}
+            if not want_grads:
+                return losses, None
+            gp = self.backward_saved(c, d_pred, d_ex, d_zm, d_zl)
+        return losses, gp
 
     def param_grads(self, gp: torch.Tensor) -> List[torch.Tensor]:
         """gradient w.r.t. the packed blob -> gradients of the parameters (spec order)."""

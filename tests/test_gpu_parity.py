@@ -778,3 +778,25 @@ def test_single_channel_output_equals_channel_of_full_output(L, X, D, S, C, H, m
         assert torch.equal(r["surf"], s_all[:, :, 25 * c:25 * c + 25])
     with pytest.raises(ValueError):
         eng.decode(D * S, H, 0, out_mode=eng.OUT_CHANNEL(3), **kw)
+
+
+@pytest.mark.parametrize("L,X,D,S,C,H,mem", [(5, 3, 3, 200, 4, 6, "lstm"), (12, 0, 2, 1500, 3, 3, "lstm"), (5, 3, 2, 64, 3, 4, "gru")])
+def test_reducing_rollout_equals_percentiles_of_stored_rollouts(L, X, D, S, C, H, mem):
+    """ar_generate(reduce_qs=...) -- every step decoded sample-minor (p50 channel alone when that is the reduced
+    one), reduced on the side stream, samples never stored -- against np.percentile of the rollouts it replaces;
+    the rollouts themselves are bit-identical (same feedback values), so the quantiles agree to rounding of the
+    interpolation."""
+    from vsv import paths
+    cfg = vo.make_config(L, X, mem_type=mem)
+    eng, _ = _engine(cfg, 13, 2.0)
+    rng = np.random.default_rng(3)
+    surf = _t(0.2 + 0.1 * rng.standard_normal((D, C, 5, 5)))
+    ex = _t(0.01 * rng.standard_normal((D, C, X))) if X else None
+    raw, _ = paths.ar_generate(eng, surf, ex, H, S, seed=4, day0=2)              # (D*S, H, 3, 5, 5)
+    want = np.percentile(_n(raw).reshape(D, S, H, 3, 5, 5), [5, 50, 95], axis=1).transpose(1, 2, 0, 3, 4, 5)
+    for ch in (1, None, 2):
+        q, none = paths.ar_generate(eng, surf, ex, H, S, seed=4, day0=2, reduce_qs=(5, 50, 95), reduce_channel=ch)
+        assert none is None
+        w = want if ch is None else want[:, :, :, ch]
+        assert q.shape == w.shape
+        assert err(_n(q), w) <= 1e-6

@@ -279,7 +279,8 @@ def ar_offset_windows(eng: Engine, vol: torch.Tensor, ex: Optional[torch.Tensor]
 
 def ar_generate(eng: Engine, surf_ctx: torch.Tensor, ex_ctx: Optional[torch.Tensor], horizon: int,
                 n_samples: int = 1, eps: Optional[torch.Tensor] = None, seed: int = 0, day0: int = 0,
-                share_prefix: Optional[bool] = None):
+                share_prefix: Optional[bool] = None, reduce_qs: Optional[Sequence[float]] = None,
+                reduce_channel: Optional[int] = 1):
     """generate_autoregressive_sequence (cvae_with_mem_randomized.py:717-807) for D
     context windows x S samples: every row rolls its OWN window -- each step is a
     one-day prior generation (:776), whose p50 channel (:786/:794) and predicted
@@ -291,7 +292,11 @@ def ar_generate(eng: Engine, surf_ctx: torch.Tensor, ex_ctx: Optional[torch.Tens
     them once per day and the rows continue from those states over their own k generated days
     (the same products in the same order: results do not change).
     eps: (D*S, horizon, L) injected future latents, or None -> Philox keyed by
-    (seed; sample, day0 + day, step).  Returns (D*S, horizon, Q, 5, 5)[, (D*S, horizon, X)]."""
+    (seed; sample, day0 + day, step).  Returns (D*S, horizon, Q, 5, 5)[, (D*S, horizon, X)].
+    reduce_qs: the Monte-Carlo product instead of the samples -- every step's decode writes its surfaces
+    sample-minor (one decoder channel, or all with reduce_channel None), the step's percentiles over the S
+    rollouts of a day are taken on the side stream while the next step's encoders run, and the samples are
+    never stored: returns (D, horizon, nq, 5, 5) or (D, horizon, nq, Q, 5, 5), and None."""
     D, C = surf_ctx.shape[:2]
     S, R, L, X, Q = n_samples, D * n_samples, eng.L, eng.X, eng.Q
     dev = eng.device
@@ -305,8 +310,16 @@ def ar_generate(eng: Engine, surf_ctx: torch.Tensor, ex_ctx: Optional[torch.Tens
     if X > 0:
         exb = torch.empty((R, TT, X), dtype=torch.float32, device=dev)
         exb[:, :C] = ex0.reshape(D, 1, C, X).expand(D, S, C, X).reshape(R, C, X)
-    out_s = torch.empty((R, horizon, Q, 5, 5), dtype=torch.float32, device=dev)
-    out_e = torch.empty((R, horizon, X), dtype=torch.float32, device=dev) if X > 0 else None
+    reducing = reduce_qs is not None
+    om = 0
+    if reducing:
+        # the fed-back p50 channel is needed in any case: decoded alone when it is also the reduced one
+        om = eng.OUT_CHANNEL(1) if reduce_channel == 1 else 1
+        out_q = []
+        out_s = out_e = None
+    else:
+        out_s = torch.empty((R, horizon, Q, 5, 5), dtype=torch.float32, device=dev)
+        out_e = torch.empty((R, horizon, X), dtype=torch.float32, device=dev) if X > 0 else None
     if eps is not None:
         eps = eps.to(dev, torch.float32).contiguous()
         assert eps.shape == (R, horizon, L)
@@ -322,7 +335,7 @@ def ar_generate(eng: Engine, surf_ctx: torch.Tensor, ex_ctx: Optional[torch.Tens
             enc = eng.encode_from_pre(0, ptab[0][k - C:], R, C)
             ctx = eng.encode_from_pre(1, ptab[1][k - C:], R, C)
             r = eng.decode(R, C + 1, C, ctx=ctx, zb=enc[..., :L].contiguous(), eps=ek, eps_t0=C,
-                           seed=seed, S=S, day0=day0, step0=k)
+                           seed=seed, S=S, day0=day0, step0=k, out_mode=om)
         elif share and k < C:
             ns = C - k                                         # days of the original context still in the window
             enc_s, st_e = eng.encode_state(0, ctx0[:, k:], C * 25, 25, ex0[:, k:] if X > 0 else None, C * X, X,
@@ -332,29 +345,46 @@ def ar_generate(eng: Engine, surf_ctx: torch.Tensor, ex_ctx: Optional[torch.Tens
             pre = eng.decode(D, ns, ns, ctx=ctx_s, zb=enc_s[..., :L].contiguous(), want_state=True, want_gates=k == 0)
             if k == 0:
                 r = eng.decode(R, 1, 0, state_in=pre["state"], state_div=S, gate_in=pre["gates"],
-                               eps=ek, eps_t0=0, seed=seed, S=S, day0=day0, step0=0)
+                               eps=ek, eps_t0=0, seed=seed, S=S, day0=day0, step0=0, out_mode=om)
             else:
                 # the rows' own generated days 0..k-1, from their tables
                 enc_r = eng.encode_from_pre(0, ptab[0], R, k, state_in=st_e, state_div=S)
                 ctx_r = eng.encode_from_pre(1, ptab[1], R, k, state_in=st_c, state_div=S)
                 r = eng.decode(R, k + 1, k, ctx=ctx_r, zb=enc_r[..., :L].contiguous(),
                                state_in=pre["state"], state_div=S,
-                               eps=ek, eps_t0=k, seed=seed, S=S, day0=day0, step0=k)
+                               eps=ek, eps_t0=k, seed=seed, S=S, day0=day0, step0=k, out_mode=om)
         else:
             win = buf[:, k:]
             wex = exb[:, k:] if X > 0 else None
             enc, ctx = eng.encode_both_strided(win, TT * 25, 25, wex, TT * X, X, R, C)
             zm = enc[..., :L].contiguous()
             r = eng.decode(R, C + 1, C, ctx=ctx, zb=zm, eps=ek, eps_t0=C,
-                           seed=seed, S=S, day0=day0, step0=k)
-        out_s[:, k] = r["surf"][:, 0]
-        buf[:, C + k] = r["surf"][:, 0, 1].reshape(R, 25)
-        if X > 0:
-            out_e[:, k] = r["ex"][:, 0]
-            exb[:, C + k] = r["ex"][:, 0]
+                           seed=seed, S=S, day0=day0, step0=k, out_mode=om)
+        if reducing:
+            smp = r["surf"]                                    # (D, 1, Q*25 | 25, S), sample-minor
+            p50 = smp[:, 0] if reduce_channel == 1 else smp[:, 0, 25:50]
+            buf[:, C + k] = p50.permute(0, 2, 1).reshape(R, 25)
+            nq = len(reduce_qs)
+            if reduce_channel is None:
+                out_q.append(eng.reduce_async(smp, reduce_qs, Q * 25, None, 1).view(D, 1, nq, Q, 5, 5))
+            elif reduce_channel == 1:
+                out_q.append(eng.reduce_async(smp, reduce_qs, 25, None, 1).view(D, 1, nq, 5, 5))
+            else:
+                out_q.append(eng.reduce_async(smp, reduce_qs, 25, reduce_channel, Q).view(D, 1, nq, 5, 5))
+            if X > 0:
+                exb[:, C + k] = r["ex"][:, 0]
+        else:
+            out_s[:, k] = r["surf"][:, 0]
+            buf[:, C + k] = r["surf"][:, 0, 1].reshape(R, 25)
+            if X > 0:
+                out_e[:, k] = r["ex"][:, 0]
+                exb[:, C + k] = r["ex"][:, 0]
         if ptab is not None and k < horizon - 1:
             for which in (0, 1):
                 eng.encode_pre(which, buf[:, C + k], TT * 25, exb[:, C + k] if X > 0 else None, TT * X, R, ptab[which][k])
+    if reducing:
+        eng.join_side()
+        return torch.cat(out_q, dim=1), None
     return out_s, out_e
 
 
@@ -429,14 +459,8 @@ def ar_mc_windows(eng: Engine, vol: torch.Tensor, ex: Optional[torch.Tensor], fi
         w0 = first_day + d0 - ctx_len
         win = vol[w0:w0 + nd + ctx_len - 1].reshape(-1, 25).unfold(0, ctx_len, 1).permute(0, 2, 1)   # (nd, C, 25)
         wex = ex[w0:w0 + nd + ctx_len - 1].unfold(0, ctx_len, 1).permute(0, 2, 1) if eng.X > 0 else None
-        s, _ = ar_generate(eng, win.reshape(nd, ctx_len, 5, 5), wex, horizon, S, seed=seed, day0=day_index0 + d0)
-        smp = s.view(nd, S, horizon, Q, 25)
-        if channel is None:
-            sm = smp.permute(0, 2, 3, 4, 1).contiguous()                       # (nd, H, Q, 25, S)
-            q = eng.percentile(sm, qs, inner=Q * 25).view(nd, horizon, len(qs), Q, 5, 5)
-        else:
-            sm = smp[:, :, :, channel].permute(0, 2, 3, 1).contiguous()        # (nd, H, 25, S)
-            q = eng.percentile(sm, qs, inner=25).view(nd, horizon, len(qs), 5, 5)
+        q, _ = ar_generate(eng, win.reshape(nd, ctx_len, 5, 5), wex, horizon, S, seed=seed, day0=day_index0 + d0,
+                           reduce_qs=qs, reduce_channel=channel)
         outs.append(q)
     return torch.cat(outs, dim=0)
 

@@ -410,6 +410,7 @@ typedef struct vsv_loss {
     float *d_pred, *d_ex, *d_zm, *d_zl;
     double *sums;
     int Hs;  float grad_scale;
+    int surf_l2;                            /* 1: re_surface = F.mse_loss (legacy one-channel CVAEMem, cvae_with_mem.py:681; Q must be 1) */
 } vsv_loss;
 int vsv_loss_grad(const vsv_loss *d, void *stream);
 

@@ -672,6 +672,94 @@ def main_round2():
     case_gmm("g12_gmm_noex12_C20_H7_K5", vo.make_config(12, 0), 44, 2.0, 4, 20, 7, 5)
 
 
+class UniformQueue:
+    """Patches torch.rand_like (the legacy encoder's uniform reparameterisation noise, cvae_with_mem.py:157)."""
+
+    def __init__(self, arr):
+        self.arr = arr
+
+    def __enter__(self):
+        self._rand_like = torch.rand_like
+
+        def rand_like(t, **kw):
+            assert tuple(t.shape) == tuple(self.arr.shape)
+            return torch.from_numpy(np.ascontiguousarray(self.arr)).to(t.dtype)
+
+        torch.rand_like = rand_like
+        return self
+
+    def __exit__(self, *a):
+        torch.rand_like = self._rand_like
+
+
+def case_legacy(name, cfg, seed, scale, B, seq_len, ctx_len, full=True):
+    """G14: the legacy fixed-length CVAEMem (vae/cvae_with_mem.py:466-738): forward with injected UNIFORM
+    noise, test_step's MSE / ex / KL losses, their gradients w.r.t. every parameter (float64), and
+    get_surface_given_conditions with a given z (context positions NOT replaced by the posterior mean)."""
+    from vae.cvae_with_mem import CVAEMem
+    np_dtype = np.float64
+    torch.set_default_dtype(torch.float64)
+    cfg = dict(cfg, seq_len=seq_len, ctx_len=ctx_len, quantiles=[0.5])
+    model = CVAEMem(dict(cfg))
+    W = vo.init_weights(cfg, seed, scale, np_dtype)
+    sd = model.state_dict()
+    assert set(sd) == set(W), (set(sd) ^ set(W))
+    for k, v in W.items():
+        assert tuple(sd[k].shape) == v.shape, k
+        sd[k] = torch.from_numpy(v.copy())
+    model.load_state_dict(sd, strict=True)
+    model.train()
+    rng = np.random.Generator(np.random.PCG64(9000 + seed))
+    X, L = cfg["ex_feats_dim"], cfg["latent_dim"]
+    surf, ex = synth(rng, B, seq_len, X, np_dtype)
+    eps = rng.random((B, seq_len, L)).astype(np_dtype)
+    x = {"surface": torch.from_numpy(surf)}
+    if X:
+        x["ex_feats"] = torch.from_numpy(ex)
+    with UniformQueue(eps):
+        out = model.forward(x)
+    model.zero_grad()
+    with UniformQueue(eps):
+        losses = model.test_step(x)
+    losses["loss"].backward()
+    d = dict(surface=surf, eps=eps, seq_len=seq_len, ctx_len=ctx_len, seed=seed, scale=scale,
+             recon=t2n(out[0]), z_mean=t2n(out[-3]), z_log_var=t2n(out[-2]), z=t2n(out[-1]))
+    if X:
+        d["ex_feats"] = ex
+        d["ex_recon"] = t2n(out[1])
+    for k, v in losses.items():
+        d["loss_" + k] = np.float64(t2n(v).reshape(-1)[0])
+    grads = {n: t2n(p.grad).copy() for n, p in model.named_parameters()}
+    d["grad_total_norm"] = np.float64(np.sqrt(sum(float((g ** 2).sum()) for g in grads.values())))
+    for n, g in grads.items():
+        d["gnorm/" + n] = np.float64(np.sqrt((g ** 2).sum()))
+        if full:
+            d["grad/" + n] = g.astype(np.float32)
+        else:
+            flat = g.ravel()
+            idx = np.linspace(0, flat.size - 1, num=min(flat.size, 64)).astype(np.int64)
+            d["gidx/" + n] = idx
+            d["gval/" + n] = flat[idx]
+    zg = rng.standard_normal((B, seq_len, L)).astype(np_dtype)
+    c = {"surface": torch.from_numpy(surf[:, :ctx_len])}
+    if X:
+        c["ex_feats"] = torch.from_numpy(ex[:, :ctx_len])
+    model.eval()
+    with torch.no_grad():
+        g = model.get_surface_given_conditions(c, z=torch.from_numpy(zg.copy()))
+    d["z_given"] = zg
+    if X:
+        d["surf_out"], d["ex_out"] = t2n(g[0]), t2n(g[1])
+    else:
+        d["surf_out"] = t2n(g)
+    save(name, cfg, d)
+
+
+def main_legacy():
+    case_legacy("g14_legacy_ex5_T8_C5", vo.make_config(5, 3), 50, 2.0, 6, 8, 5, full=False)
+    case_legacy("g14_legacy_noex_T6_C5", vo.make_config(5, 0), 51, 2.0, 5, 6, 5, full=False)
+
+
 if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "training":
         os.makedirs(OUT, exist_ok=True)
@@ -688,6 +776,9 @@ if __name__ == "__main__":
     elif len(sys.argv) > 1 and sys.argv[1] == "round2":
         os.makedirs(OUT, exist_ok=True)
         main_round2()
+    elif len(sys.argv) > 1 and sys.argv[1] == "legacy":
+        os.makedirs(OUT, exist_ok=True)
+        main_legacy()
     elif len(sys.argv) > 1 and sys.argv[1] == "cprior":
         os.makedirs(OUT, exist_ok=True)
         main_cprior()

@@ -254,3 +254,40 @@ def test_fitted_gmm_prior_vs_reference(name, tmp_path):
     s = model.get_surface_given_conditions(c, horizon=H, prior_mode="fitted")
     s = s[0] if isinstance(s, tuple) else s
     assert s.shape == (B, H, 3, 5, 5) and bool(torch.isfinite(s).all())
+
+
+def test_legacy_model_monte_carlo_product_vs_cpu_oracle():
+    """eval_utils.generate_surfaces_multiday with model_type = the legacy CVAEMem: the original
+    (days, num_vaes, 5, 5) Monte-Carlo product, z drawn at EVERY position (cvae_with_mem.py:547), against the
+    CPU oracle fed the same Philox draws."""
+    from eval_scripts import eval_utils as eu
+    from vae.cvae_with_mem import CVAEMem
+    from vae.utils import set_seeds
+    from vsv import paths
+    L, X, C, N, S = 5, 3, 5, 7, 24
+    cfg = vo.make_config(L, X, device="cuda:0", seq_len=C + 1, ctx_len=C)
+    model = CVAEMem(dict(cfg))
+    W = vo.init_weights(dict(cfg, quantiles=[0.5]), 6, 2.0, np.float32)
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in W.items()}, strict=True)
+    model.eval()
+    vol, ex = _calendar(30, X)
+    set_seeds(1)
+    s, e = eu.generate_surfaces_multiday(model, ex, vol, C + 2, N, S, model_type=CVAEMem, check_ex_feats=True, ctx_len=C)
+    assert s.shape == (N, S, 5, 5) and e.shape == (N, S, X)
+    set_seeds(1)
+    seed = model._draw_seed()
+    eng = model._engine()
+    W64 = {k: v.astype(np.float64) for k, v in W.items()}
+    ocfg = dict(cfg, quantiles=[0.5])
+    for d in (0, N - 1):
+        day = C + 2 + d
+        z = _n(eng.philox_normal(seed, day, 1, S, 0, C + 1))                       # (S, C+1, L): every position
+        win = np.broadcast_to(vol[day - C:day][None].astype(np.float64), (S, C, 5, 5))
+        wex = np.broadcast_to(ex[day - C:day][None].astype(np.float64), (S, C, X))
+        ctx_pad = np.zeros((S, C + 1, L))
+        ctx_pad[:, :C] = vo.ctx_encoder_forward(W64, ocfg, win, wex)
+        ws, we, _ = vo.decoder_forward(W64, ocfg, np.concatenate([ctx_pad, z], axis=-1))
+        assert _err(s[d], ws[:, C, 0]) <= TOL and _err(e[d], we[:, C]) <= TOL
+    # the same call on a CVAEMemRand keeps that class's semantics (posterior mean at the context positions)
+    raw, _ = paths.legacy_prior_windows(eng, _t(vol), _t(ex), C + 2, 2, C, 1, 3, seed=seed)
+    assert raw.shape == (2, 3, 1, 1, 5, 5)

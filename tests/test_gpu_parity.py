@@ -800,3 +800,59 @@ def test_reducing_rollout_equals_percentiles_of_stored_rollouts(L, X, D, S, C, H
         w = want if ch is None else want[:, :, :, ch]
         assert q.shape == w.shape
         assert err(_n(q), w) <= 1e-6
+
+
+@pytest.mark.parametrize("name", golden_names("g14_legacy"))
+def test_legacy_one_channel_mse_model_vs_reference(name):
+    """vae.cvae_with_mem.CVAEMem -- the legacy fixed-length model: one decoder channel, MSE surface loss, uniform
+    reparameterisation noise, generation from z at every position -- against the reference's own class (goldens
+    g14): forward, test_step losses, every parameter's gradient through train_step (SGD lr 0; the legacy step
+    does not clip), get_surface_given_conditions."""
+    from vae.cvae_with_mem import CVAEMem
+    g = load_golden(name)
+    X = int(g["cfg_ex_feats_dim"])
+    T, C = int(g["seq_len"]), int(g["ctx_len"])
+    cfg = vo.make_config(int(g["cfg_latent_dim"]), X, device="cuda:0", seq_len=T, ctx_len=C)
+    for k in ("ex_feats_loss_type", "kl_weight", "re_feat_weight"):
+        v = g["cfg_" + k]
+        cfg[k] = v.item() if v.dtype.kind != "U" else str(v)
+    model = CVAEMem(dict(cfg))
+    W = vo.init_weights(dict(cfg, quantiles=[0.5]), int(g["seed"]), float(g["scale"]), np.float32)
+    assert {k: tuple(v.shape) for k, v in model.state_dict().items()} == {k: v.shape for k, v in W.items()}
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in W.items()}, strict=True)
+    x = {"surface": _t(g["surface"])}
+    if X:
+        x["ex_feats"] = _t(g["ex_feats"])
+    eps = _t(g["eps"])
+    model.eval()
+    with torch.no_grad():
+        out = model.forward(x, _eps=eps)
+    assert out[0].shape == g["recon"].shape == (g["surface"].shape[0], T - C, 5, 5)
+    assert err(_n(out[0]), g["recon"]) <= TOL
+    assert err(_n(out[-3]), g["z_mean"]) <= TOL and err(_n(out[-1]), g["z"]) <= TOL
+    if X:
+        assert err(_n(out[1]), g["ex_recon"]) <= TOL
+    losses = model.test_step(x, _eps=eps)
+    for k in ("loss", "re_surface", "re_ex_feats", "reconstruction_loss", "kl_loss"):
+        want = float(g["loss_" + k])
+        assert abs(float(losses[k]) - want) <= 1e-3 * abs(want) + 1e-9, (k, float(losses[k]), want)
+    model.train()
+    opt = torch.optim.SGD(model.parameters(), lr=0.0)
+    tl = model.train_step(x, opt, _eps=eps)
+    assert abs(float(tl["loss"]) - float(g["loss_loss"])) <= 1e-3 * abs(float(g["loss_loss"]))
+    _check_grads(g, [n for n, _ in model.named_parameters()], [p.grad for _, p in model.named_parameters()])
+    # generation: the caller's z at every position
+    c = {"surface": x["surface"][:, :C]}
+    if X:
+        c["ex_feats"] = x["ex_feats"][:, :C]
+    model.eval()
+    gen = model.get_surface_given_conditions(c, z=_t(g["z_given"]))
+    s = gen[0] if X else gen
+    assert s.shape == g["surf_out"].shape and err(_n(s), g["surf_out"]) <= TOL
+    if X:
+        assert err(_n(gen[1]), g["ex_out"]) <= TOL
+    # and the prior draw runs, with the legacy shapes
+    s2 = model.get_surface_given_conditions(c)
+    assert (s2[0] if X else s2).shape == g["surf_out"].shape
+    with pytest.raises(ValueError):
+        model.forward({"surface": x["surface"][:, :T - 1]})

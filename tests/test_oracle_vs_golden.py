@@ -290,3 +290,33 @@ def test_fitted_gmm_prior(name):
     assert np.max(np.abs(s - g["surf_out"])) <= 1e-9
     if e is not None:
         assert np.max(np.abs(e - g["ex_out"])) <= 1e-9
+
+
+@pytest.mark.parametrize("name", golden_names("g14_legacy"))
+def test_oracle_matches_legacy_one_channel_model(name):
+    """The legacy fixed-length CVAEMem (reference vae/cvae_with_mem.py) is the same network with one decoder
+    channel: the oracle with quantiles=[0.5] reproduces its forward (uniform noise injected), its MSE / ex / KL
+    losses, and its literal generation from a given z (context latents NOT replaced by the posterior mean)."""
+    g = load_golden(name)
+    X = int(g["cfg_ex_feats_dim"])
+    cfg = vo.make_config(int(g["cfg_latent_dim"]), X, quantiles=[0.5])
+    W = vo.init_weights(cfg, int(g["seed"]), float(g["scale"]), np.float64)
+    T, C = int(g["seq_len"]), int(g["ctx_len"])
+    ex = g["ex_feats"] if X else None
+    out = vo.forward(W, cfg, g["surface"], ex, g["eps"], T - C)
+    assert np.max(np.abs(out[0][:, :, 0] - g["recon"])) <= 1e-9
+    assert np.max(np.abs(out[2] - g["z_mean"])) <= 1e-9 and np.max(np.abs(out[4] - g["z"])) <= 1e-9
+    mse = float(np.mean((out[0][:, :, 0] - g["surface"][:, C:]) ** 2))
+    assert abs(mse - float(g["loss_re_surface"])) <= 1e-12
+    kl = float(np.mean(np.sum(-0.5 * (1 + out[3] - np.exp(out[3]) - out[2] ** 2), axis=-1)))
+    assert abs(kl - float(g["loss_kl_loss"])) <= 1e-9 * max(1.0, abs(kl))
+    if X:
+        assert np.max(np.abs(out[1] - g["ex_recon"])) <= 1e-9
+    # literal generation: decoder over all T positions on cat([padded context embedding, z])
+    B, L = g["surface"].shape[0], cfg["latent_dim"]
+    ctx_pad = np.zeros((B, T, L))
+    ctx_pad[:, :C] = vo.ctx_encoder_forward(W, cfg, g["surface"][:, :C], None if ex is None else ex[:, :C])
+    s, e, _ = vo.decoder_forward(W, cfg, np.concatenate([ctx_pad, g["z_given"]], axis=-1))
+    assert np.max(np.abs(s[:, C:, 0] - g["surf_out"])) <= 1e-9
+    if X:
+        assert np.max(np.abs(e[:, C:] - g["ex_out"])) <= 1e-9

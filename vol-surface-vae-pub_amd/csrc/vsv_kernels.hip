@@ -1772,6 +1772,12 @@ __global__ void __launch_bounds__(256) loss_grad_kernel(const LossArgs a) {
         if (h < 0) { a.d_pred[i] = 0.0f; continue; }
         const float tg = a.target[((size_t)b * a.T + (a.T - a.H + h)) * 25 + p];
         const float e = tg - a.pred[i];
+        if (a.surf_l2) {
+            // F.mse_loss of the one-channel legacy decoder (cvae_with_mem.py:681): mean over B*H*25 (Q = 1)
+            s0 += (double)e * e * inv_s;
+            a.d_pred[i] = (float)(-2.0 * e * inv_s * gs);
+            continue;
+        }
         const float qq = a.q[qi];
         const float lo = (qq - 1.0f) * e, hi = qq * e;
         s0 += (double)a.qw[qi] * (double)fmaxf(lo, hi) * inv_s;
@@ -3101,6 +3107,7 @@ extern "C" int vsv_loss_grad(const vsv_loss* d, void* stream) {
     }
     if (d->B < 1 || d->H < 1 || d->T < d->H || d->Q < 1 || d->Q > 8 || d->L < 1) { set_error("vsv_loss_grad: bad sizes"); return -1; }
     if (d->Hs != 0 && d->Hs < d->H) { set_error("vsv_loss_grad: Hs < H"); return -1; }
+    if (d->surf_l2 && d->Q != 1) { set_error("vsv_loss_grad: the MSE surface loss is the one-channel decoder's (Q = 1)"); return -1; }
     if (d->ex_pred && (!d->ex_target || !d->d_ex || d->X < 1 || d->ex_n < 1 || d->ex_n > d->X)) { set_error("vsv_loss_grad: bad ex arguments"); return -1; }
     hipLaunchKernelGGL(loss_grad_kernel, dim3(64), dim3(256), 0, (hipStream_t)stream, *d);
     return launch_check("loss_grad_kernel");

@@ -205,8 +205,12 @@ def mc_generate_surfaces_multiday(model_data, ex_data, vol_surface_data, start_d
     eng, vol, ex = _arrays(model, vol_surface_data, ex_data)
     seed = _shared_seed(model)
 
+    from vae.cvae_with_mem import CVAEMem
+    legacy = isinstance(model, CVAEMem)                  # z drawn at every position, seq_len - ctx_len = 1 day ahead
+
     def fn(lo, hi):
-        s, e = paths.prior_windows(eng, vol, ex, start_day + lo, hi - lo, ctx_len, 1, num_vaes, seed=seed)
+        gen = paths.legacy_prior_windows if legacy else paths.prior_windows
+        s, e = gen(eng, vol, ex, start_day + lo, hi - lo, ctx_len, 1, num_vaes, seed=seed)
         return s[:, :, 0], (None if e is None else e[:, :, 0])
     s, e = _sharded_pair(fn, days_to_generate)
     s = s.double().cpu().numpy()

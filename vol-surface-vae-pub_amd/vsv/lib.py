@@ -126,7 +126,7 @@ class VsvLoss(C.Structure):
                 ("ex_weight", C.c_float), ("kl_weight", C.c_float),
                 ("zm", C.c_void_p), ("zl", C.c_void_p), ("L", C.c_int),
                 ("d_pred", C.c_void_p), ("d_ex", C.c_void_p), ("d_zm", C.c_void_p), ("d_zl", C.c_void_p),
-                ("sums", C.c_void_p), ("Hs", C.c_int), ("grad_scale", C.c_float)]
+                ("sums", C.c_void_p), ("Hs", C.c_int), ("grad_scale", C.c_float), ("surf_l2", C.c_int)]
 
 
 # name -> (restype, argtypes); the full list of symbols include/vsv_hip.h declares

@@ -218,6 +218,39 @@ def prior_windows(eng: Engine, vol: torch.Tensor, ex: Optional[torch.Tensor], fi
     return out_s, out_e
 
 
+def legacy_prior_windows(eng: Engine, vol: torch.Tensor, ex: Optional[torch.Tensor], first_day: int, n_days: int,
+                         ctx_len: int, horizon: int, n_samples: int = 1, seed: int = 0,
+                         day_index0: Optional[int] = None, chunk_rows: int = 1 << 16, mu: float = 0.0, std: float = 1.0):
+    """The Monte-Carlo loop of eval_scripts/eval_utils.py:8-70 for the LEGACY model (CVAEMem.get_surface_given_conditions,
+    cvae_with_mem.py:520-562): z ~ N(mu, std) at EVERY one of the C + H positions -- the context latents are not the
+    posterior mean -- so a day's samples share the context embedding only and each decodes all C + H steps.
+    Raw samples (n_days, n_samples, horizon, Q, 5, 5)[, (n_days, n_samples, horizon, X)]; Philox keyed by the
+    global day index."""
+    T = ctx_len + horizon
+    assert first_day >= ctx_len and first_day + n_days <= vol.shape[0]
+    vol = vol.to(device=eng.device, dtype=torch.float32).contiguous()
+    if eng.X > 0:
+        ex = ex.to(device=eng.device, dtype=torch.float32).contiguous()
+    if day_index0 is None:
+        day_index0 = first_day
+    Q, X, S = eng.Q, eng.X, n_samples
+    if n_days == 0:
+        return _empty_samples(eng, (0, S, horizon))
+    w0 = first_day - ctx_len
+    ctx = eng.encode_windows(1, vol[w0:], ex[w0:] if X > 0 else None, n_days, ctx_len)
+    out_s = torch.empty((n_days, S, horizon, Q, 5, 5), dtype=torch.float32, device=eng.device)
+    out_e = torch.empty((n_days, S, horizon, X), dtype=torch.float32, device=eng.device) if X > 0 else None
+    chunk_days = max(1, chunk_rows // max(1, S))
+    for d0 in range(0, n_days, chunk_days):
+        nd = min(chunk_days, n_days - d0)
+        r = eng.decode(nd * S, T, ctx_len, ctx=ctx[d0:d0 + nd], ctx_div=S, seed=seed, S=S, day0=day_index0 + d0,
+                       out_mode=0, mu0=float(mu), std0=float(std))
+        out_s[d0:d0 + nd] = r["surf"].view(nd, S, horizon, Q, 5, 5)
+        if X > 0:
+            out_e[d0:d0 + nd] = r["ex"].view(nd, S, horizon, X)
+    return out_s, out_e
+
+
 def oracle_windows(eng: Engine, vol: torch.Tensor, ex: Optional[torch.Tensor], first_day: int, n_days: int,
                    ctx_len: int, horizon: int, n_samples: int = 1, seed: int = 0,
                    day_index0: Optional[int] = None, chunk_rows: int = 1 << 16):

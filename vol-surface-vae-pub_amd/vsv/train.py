@@ -573,6 +573,7 @@ class TrainEngine:
                 d_ex = self._e(B, horizon, X)
                 la.ex_pred, la.ex_target, la.d_ex = e_out.data_ptr(), ex.data_ptr(), d_ex.data_ptr()
                 la.X, la.ex_n, la.ex_l2 = X, int(loss_cfg["ex_n"]), int(loss_cfg["ex_l2"])
+            la.surf_l2 = int(bool(loss_cfg.get("surf_l2", False)))
             la.ex_weight, la.kl_weight = float(loss_cfg["ex_weight"]), (0.0 if kl_fn is not None else klw)
             la.zm, la.zl, la.L = zm.data_ptr(), zl.data_ptr(), L
             la.d_pred, la.d_zm, la.d_zl = d_pred.data_ptr(), d_zm.data_ptr(), d_zl.data_ptr()

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define VSV_ABI_VERSION 15
+#define VSV_ABI_VERSION 16
 #define VSV_MAX_CONV 4
 #define VSV_MAX_CHAIN 8
 #define VSV_MAX_INTERACT 3
@@ -156,6 +156,49 @@ int vsv_encode_windows(const vsv_dims *dims, const float *packed, int which, con
 int vsv_encode_windows_state(const vsv_dims *dims, const float *packed, int which, const float *vol, const float *ex,
                              long n_windows, int T, const float *state_in, float *state_out,
                              float *out, void *ws, size_t ws_bytes, void *stream);
+
+/* The date-range prefix as a pipeline of LAYER stages (two-layer memories; -4 otherwise).  The same computation as
+ * vsv_encode_windows_state, resp. as a prefix-only vsv_decode (t_out0 = T) on (ctx_t, z_mean_t), split at the
+ * layer boundary -- still the forwards of cvae_with_mem_randomized.py:162-197 / :314-344 / :482-490 inside the
+ * date loops of generate_surfaces.py:60-102 --, bit-equal results:
+ *   *_layer0: [conv embedding and layer-0 table per calendar day,] layer 0's recurrence; leaves h0 of every
+ *             step in ws and writes layer 0's slot of state_out [and of in->gate_out];
+ *   *_layer1: b + W_ih(1) . h0 for all steps at once, layer 1's recurrence [, the latent / compression head
+ *             into out]; writes layer 1's slot of state_out [and of in->gate_out].
+ * A recurrent launch holds one CU per 32-row tile for its T sequential steps; with the two calls of a time
+ * segment on DIFFERENT streams (layer1 ordered after layer0 by an event, same ws) layer 1 of segment i runs
+ * beside layer 0 of segment i+1, so the critical path is one layer's steps plus a segment of the other.
+ * state_in / state_out: as for vsv_encode_windows_state / vsv_decode (all layers per row; each call touches its
+ * own layer's slot).  vsv_decode_prefix_layer0 reads in->ctx / zb (ctx_T = z_T = T, lv = NULL) and
+ * in->state_in; _layer1 reads in->state_in and in->gate_out only. */
+size_t vsv_encode_windows_split_ws_bytes(const vsv_dims *dims, long n_windows, int T);
+int vsv_encode_windows_layer0(const vsv_dims *dims, const float *packed, int which, const float *vol, const float *ex,
+                              long n_windows, int T, const float *state_in, float *state_out,
+                              void *ws, size_t ws_bytes, void *stream);
+int vsv_encode_windows_layer1(const vsv_dims *dims, const float *packed, int which, long n_windows, int T,
+                              const float *state_in, float *state_out, float *out,
+                              void *ws, size_t ws_bytes, void *stream);
+size_t vsv_decode_prefix_split_ws_bytes(const vsv_dims *dims, long n_rows, int T);
+struct vsv_decode_in;
+int vsv_decode_prefix_layer0(const vsv_dims *dims, const float *packed, const struct vsv_decode_in *in, long n_rows,
+                             int T, float *state_out, void *ws, size_t ws_bytes, void *stream);
+int vsv_decode_prefix_layer1(const vsv_dims *dims, const float *packed, const struct vsv_decode_in *in, long n_rows,
+                             int T, float *state_out, void *ws, size_t ws_bytes, void *stream);
+
+/* The whole date-range prefix in one call: for the windows vol[d : d + ctx_len] (d < n_days) the decoder state
+ * after the context steps (state_out, (n_days, vsv_state_floats)) and the first future step's shared gates
+ * (gate_out, (n_days, vsv_gate_floats)) -- posterior mean and context embedding from the two encoders, decoder
+ * over (ctx_t, z_mean_t): the context half of get_surface_given_conditions (:695-715) for every day of the loops
+ * of generate_surfaces.py:60-102.  The ctx_len steps are cut into n_seg time segments and every stack into its
+ * two layers (the *_layer0 / *_layer1 stages above); all stage launches are issued here onto `streams`
+ * (n_streams = 6: one per stage; 4: the two encoders' same-layer stages share a stream -- HIP's default number of
+ * hardware queues) and ordered by HIP events; the work is forked from `stream` and joined back into it.
+ * Creates and destroys HIP events (host objects); no device memory is allocated.  Results are bit-equal to the
+ * fused launches for any n_seg.  Two-layer memories, at most 8192 days per call. */
+size_t vsv_context_prefix_ws_bytes(const vsv_dims *dims, long n_days, int ctx_len, int n_seg);
+int vsv_context_prefix(const vsv_dims *dims, const float *packed, const float *vol, const float *ex, long n_days,
+                       int ctx_len, int n_seg, void *const *streams, int n_streams,
+                       float *state_out, float *gate_out, void *ws, size_t ws_bytes, void *stream);
 
 /* The one entry point that allocates nothing and needs no caller workspace.  NO COUNTERPART IN THE REFERENCE:
  * it exists for callers that cannot allocate device memory -- code under HIP graph capture, tight serving

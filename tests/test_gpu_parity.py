@@ -1,6 +1,8 @@
 """GPU parity tests: the HIP path (through the C ABI of libvsv_hip.so) against
 the reference's own outputs (tests/golden) and against the CPU oracle on seeded
 inputs.  Tolerances are the north-star's: max abs err <= 1e-4 on vols."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -647,10 +649,17 @@ def test_segmented_context_prefix_equals_single_launches():
         vol = _t((0.2 + 0.1 * rng.standard_normal((N + C - 1, 5, 5))).astype(np.float32))
         ex = _t((0.01 * rng.standard_normal((N + C - 1, X))).astype(np.float32)) if X else None
         s1, g1 = paths._context_prefix(eng, vol, ex, N, C, n_seg=1)
-        for n_seg in (2, 3):
-            s2, g2 = paths._context_prefix(eng, vol, ex, N, C, n_seg=n_seg)
-            torch.cuda.synchronize()
-            assert float((s1 - s2).abs().max()) <= 1e-6 and float((g1 - g2).abs().max()) <= 1e-6, (mem, n_seg)
+        for layers in ("0", "py", "1"):
+            # "py" / "1": every stack also split into its two layers (vsv_*_layer0 / _layer1 stages driven from
+            # Python, resp. all issued by the one native call vsv_context_prefix)
+            os.environ["VSV_PREFIX_LAYERS"] = layers
+            try:
+                for n_seg in (2, 3):
+                    s2, g2 = paths._context_prefix(eng, vol, ex, N, C, n_seg=n_seg)
+                    torch.cuda.synchronize()
+                    assert torch.equal(s1, s2) and torch.equal(g1, g2), (mem, n_seg, layers)
+            finally:
+                os.environ.pop("VSV_PREFIX_LAYERS", None)
 
 
 @pytest.mark.parametrize("Hm,sh,X,mem", [(64, (3, 3, 3), 0, "lstm"), (48, (5, 4, 4), 3, "lstm"), (80, (4, 4), 0, "gru"),

@@ -605,6 +605,13 @@ struct LstmSeqArgs {
     // rollouts the table is [generated day][gate value][row] and pre_tstride = one day's table.
     const float* pre_t;
     long pre_stride, pre_tstride;
+    // XMODE 0, inference, one launch per layer (NL = 1; the date-range prefix as a pipeline of layer stages):
+    // the gate pre-activations b + W_ih . x of every step, [inst][16*NT][64] as lstm_pre_kernel writes them
+    // (inst = rowtile*T + t); the launch keeps only the recurrent product on its time loop
+    const float* pre_g;
+    // the state arrays (state_in / state_out / gate_out) hold st_nl layers per row and this launch's layer 0
+    // is layer st_l0 of them (0: NL layers, this launch's own)
+    int st_nl, st_l0;
 };
 
 // per-thread constants of the decoder input assembly
@@ -663,8 +670,10 @@ __device__ __forceinline__ void lstm_cell(f32x16 (&acc)[OWN], float (&c)[OWN][4]
             for (int jj = 0; jj < 4; ++jj) {
                 const float r = fast_sigmoid(acc[i][4 * jj + 0]);
                 const float z = fast_sigmoid(acc[i][4 * jj + 1]);
-                const float n = fast_tanh(acc[i][4 * jj + 2] + r * acc[i][4 * jj + 3]);
-                const float h = n + z * (c[i][jj] - n);
+                // (explicit fused multiply-adds: left to -ffp-contract the template instances of a kernel may
+                // fuse these differently, and launches that should agree bit for bit differ in the last place)
+                const float n = fast_tanh(__builtin_fmaf(r, acc[i][4 * jj + 3], acc[i][4 * jj + 2]));
+                const float h = __builtin_fmaf(z, c[i][jj] - n, n);
                 c[i][jj] = h;
                 hn[i][jj] = h;
                 if (KEEP) {
@@ -682,7 +691,7 @@ __device__ __forceinline__ void lstm_cell(f32x16 (&acc)[OWN], float (&c)[OWN][4]
             const float fg = fast_sigmoid(acc[i][4 * jj + 1]);
             const float gg = fast_tanh(acc[i][4 * jj + 2]);
             const float og = fast_sigmoid(acc[i][4 * jj + 3]);
-            const float cn = fg * c[i][jj] + ig * gg;
+            const float cn = __builtin_fmaf(fg, c[i][jj], ig * gg);
             c[i][jj] = cn;
             hn[i][jj] = og * fast_tanh(cn);
             if (KEEP) {
@@ -816,6 +825,7 @@ lstm_kernel(const LstmSeqArgs a) {
     const int SL = (SAVE && a.sv_nl > 0) ? a.sv_nl : NL;          // layers per instance in the saved arrays
     const int L0 = (SAVE && a.sv_nl > 0) ? a.sv_l0 : 0;           // the model's layer that is l = 0 here
     const bool rec = SAVE && a.rec != 0;                          // wave-uniform
+    const int SNL = a.st_nl > 0 ? a.st_nl : NL;                   // layers per row in the state arrays
     const bool dropping = SAVE && SL > 1 && a.drop.p > 0.0f;      // wave-uniform; the dropped h lives at ha0
     const DropArgs drop = (SAVE && dropping) ? resolve_drop(a.drop) : a.drop;
 
@@ -872,6 +882,14 @@ lstm_kernel(const LstmSeqArgs a) {
                 for (int r = 0; r < 16; ++r) acc[i][r] = p[(size_t)(2 * ((toff[i] >> 2) + r)) * a.pre_stride];
             return;
         }
+        if (XMODE == 0 && !SAVE && l == 0 && a.pre_g) {
+            const float* p = a.pre_g + (size_t)(rowtile * a.T + t) * (16 * NT) * 64 + lv;
+#pragma unroll
+            for (int i = 0; i < OWN; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][r] = p[((toff[i] >> 2) + r) * 64];
+            return;
+        }
         if (SAVE && rec) {
             const float* p = a.sv_gates + ((size_t)(rowtile * a.T + t) * SL + L0 + l) * (16 * NT) * 64 + lv;
 #pragma unroll
@@ -904,7 +922,7 @@ lstm_kernel(const LstmSeqArgs a) {
         qxn = ((2 * a.L + 7) >> 3) - qx0;
     }
     // (with a pre-activation table layer 0 streams its recurrent quads only)
-    const size_t w0_skip = (XMODE == 0 && !SAVE && a.pre_t) ? (size_t)(kx >> 2) * NT * 64 : 0;
+    const size_t w0_skip = (XMODE == 0 && !SAVE && (a.pre_t || a.pre_g)) ? (size_t)(kx >> 2) * NT * 64 : 0;
     if (OWN == 4) wload<OWN>(a0, (const float4*)a.w[0] + w0_skip + (size_t)qx0 * NT * 64, wo, 0u);
 
     // state: (h | c) per layer, each HP floats in lane order (position 8*tile + 4*hh + jj holds unit
@@ -912,7 +930,7 @@ lstm_kernel(const LstmSeqArgs a) {
     float c[NL][OWN][4];
     {
         const bool has_state = a.din.state_in != nullptr;                  // wave-uniform
-        const float* st = has_state ? a.din.state_in + (size_t)state_row * NL * 2 * HP : nullptr;
+        const float* st = has_state ? a.din.state_in + ((size_t)state_row * SNL + a.st_l0) * 2 * HP : nullptr;
         float4 hv[NL][OWN], cv[NL][OWN];
 #pragma unroll
         for (int l = 0; l < NL; ++l)
@@ -1029,7 +1047,7 @@ lstm_kernel(const LstmSeqArgs a) {
                 const float* bin;
                 if (l == 0) bin = (XMODE == 0) ? a.x_tileb + ((size_t)(rowtile * a.T + t) * kx) * 64 + lv : xs;
                 else bin = (SAVE && dropping) ? ha0 + lv : hb + (size_t)(l - 1) * HPK * 64;
-                if (!(SAVE && rec) && !(XMODE == 0 && !SAVE && l == 0 && a.pre_t))
+                if (!(SAVE && rec) && !(XMODE == 0 && !SAVE && l == 0 && (a.pre_t || a.pre_g)))
                     gemm_seg<OWN>(acc, w, lv, toff, NT * 64, bin, nq_in);
                 if (!shared) gemm_seg<OWN>(acc, w + (size_t)nq_in * NT * 64, lv, toff, NT * 64, hl, NT);
             }
@@ -1143,7 +1161,7 @@ lstm_kernel(const LstmSeqArgs a) {
     if (a.state_out && rowe_ok) {
 #pragma unroll
         for (int l = 0; l < NL; ++l) {
-            float* st = a.state_out + ((size_t)rowe * NL + l) * 2 * HP;
+            float* st = a.state_out + ((size_t)rowe * SNL + a.st_l0 + l) * 2 * HP;
 #pragma unroll
             for (int i = 0; i < OWN; ++i) {
                 if (tval[i]) {
@@ -1155,7 +1173,7 @@ lstm_kernel(const LstmSeqArgs a) {
             }
         }
     }
-    if (XMODE == 1 && a.din.gate_out) {
+    if (a.din.gate_out) {
         // bias + W_hh . h_final of every layer: the part of the NEXT step's gates that all rows
         // continuing from this state share (consumed through gate_in)
 #pragma unroll
@@ -1169,7 +1187,7 @@ lstm_kernel(const LstmSeqArgs a) {
 #pragma unroll
                 for (int i = 0; i < OWN; ++i) {
                     if (tval[i]) {
-                        float4* p = (float4*)(a.din.gate_out + (((size_t)rowe * NL + l) * NT + (toff[i] >> 6)) * 32 + hhe * 16);
+                        float4* p = (float4*)(a.din.gate_out + (((size_t)rowe * SNL + a.st_l0 + l) * NT + (toff[i] >> 6)) * 32 + hhe * 16);
 #pragma unroll
                         for (int v = 0; v < 4; ++v)
                             p[v] = make_float4(acc[i][4 * v + 0], acc[i][4 * v + 1], acc[i][4 * v + 2], acc[i][4 * v + 3]);
@@ -2299,6 +2317,360 @@ static int encode_windows_impl(const vsv_dims* dims, const float* packed, int wh
     h.out_mode = 1; h.out = out; h.out_f = e.nh; h.S = 1;
     h.aux_layer = -1;
     return launch_dense_chain(h, st);
+}
+
+// ---- the date-range prefix as a pipeline of LAYER stages (two-layer memories) ---------------------------------
+// A recurrent launch holds one CU per 32-row tile for its T sequential steps, and a fused two-layer step costs
+// that CU the matrix time of both layers.  Split at the layer boundary -- layer 0's recurrence; layer 1's input
+// product b + W_ih . h0 for all steps at once (lstm_pre_kernel, off the time loop); layer 1's recurrence -- the
+// two recurrences of consecutive TIME SEGMENTS run on different CUs at the same time (the caller puts the two
+// calls on different streams): the prefix's critical path is one layer's steps plus a segment of the other.
+// Same products in the same order as the fused launches: results are bit-equal.
+static size_t enc_split_bytes(const Layout& lay, long n_windows, int T, size_t off[5]) {
+    const long rt = (n_windows + 31) / 32, ct = (n_windows + T - 1 + 31) / 32;
+    const int kx = lay.enc[0].kx > lay.enc[1].kx ? lay.enc[0].kx : lay.enc[1].kx;
+    size_t cur = 0;
+    off[0] = cur; cur += align256((size_t)ct * kx * 64 * sizeof(float));                      // embeddings per day
+    off[1] = cur; cur += align256((size_t)32 * lay.NTm * ct * 32 * sizeof(float));            // layer-0 table
+    off[2] = cur; cur += align256((size_t)rt * T * 4 * lay.NTm * 64 * sizeof(float));         // h0 of every step
+    off[3] = cur; cur += align256((size_t)rt * T * 16 * lay.NTm * 64 * sizeof(float));        // layer-1 pre-activations
+    off[4] = cur; cur += align256((size_t)rt * T * 4 * lay.NTm * 64 * sizeof(float));         // h1 of every step
+    return cur + 256;
+}
+
+extern "C" size_t vsv_encode_windows_split_ws_bytes(const vsv_dims* dims, long n_windows, int T) {
+    Layout lay;
+    const char* msg = nullptr;
+    size_t off[5];
+    if (!dims || make_layout(*dims, lay, &msg) != 0 || n_windows < 0 || T < 0) return 0;
+    return enc_split_bytes(lay, n_windows, T, off);
+}
+
+extern "C" int vsv_encode_windows_layer0(const vsv_dims* dims, const float* packed, int which, const float* vol,
+                                         const float* ex, long n_windows, int T, const float* state_in,
+                                         float* state_out, void* ws, size_t ws_bytes, void* stream) {
+    VSV_LAYOUT_OR_FAIL("vsv_encode_windows_layer0")
+    if (which < 0 || which > 1) { set_error("vsv_encode_windows_layer0: which must be 0 or 1"); return -1; }
+    if (lay.NL != 2) { set_error("vsv_encode_windows_layer0: the layer split is for two-layer memories"); return -4; }
+    if (n_windows < 0 || T < 0) { set_error("vsv_encode_windows_layer0: negative size"); return -1; }
+    if (n_windows == 0 || T == 0) return 0;
+    if (!packed || !vol || !ws) { set_error("vsv_encode_windows_layer0: null pointer"); return -1; }
+    if (lay.X > 0 && !ex) { set_error("vsv_encode_windows_layer0: ex_feats_dim > 0 but ex is null"); return -1; }
+    const long rt = (n_windows + 31) / 32;
+    if (rt > kWideMaxRowtiles) { set_error("vsv_encode_windows_layer0: at most %ld windows per call", kWideMaxRowtiles * 32); return -5; }
+    size_t off[5];
+    if (ws_bytes < enc_split_bytes(lay, n_windows, T, off)) { set_error("vsv_encode_windows_layer0: workspace too small"); return -1; }
+    hipStream_t st = (hipStream_t)stream;
+    const EncLayout& e = lay.enc[which];
+    const int NT = lay.NTm;
+    const long n_cal = n_windows + T - 1, ct = (n_cal + 31) / 32;
+    char* base = (char*)(((uintptr_t)ws + 255) & ~(uintptr_t)255);
+    float* xe = (float*)(base + off[0]);
+    float* pre = (float*)(base + off[1]);
+    float* h0 = (float*)(base + off[2]);
+
+    DenseChainArgs a = {};
+    a.n_layers = e.n_chain;
+    for (int i = 0; i < e.n_chain; ++i) fill_dense(a, i, packed, e.conv[i]);
+    a.inj_layer = e.n_conv - 1;
+    a.n_rows = n_cal; a.n_rowtiles = ct; a.T = 1;
+    a.in_mode = 0; a.in = vol; a.in_rs = 25; a.in_ts = 0; a.in_f = 25;
+    a.in_ks = 4 * e.conv[0].nq;
+    if (lay.X > 0) { a.inj = ex; a.inj_rs = lay.X; a.inj_ts = 0; a.inj_f0 = e.ex_f0; a.inj_n = lay.X; }
+    a.out_mode = 0; a.out = xe; a.out_f = e.E; a.S = 1;
+    a.aux_layer = -1;
+    int rc = launch_dense_chain(a, st);
+    if (rc) return rc;
+    const float* w0 = packed + e.lstm[0].w_off;
+    const float* b0 = packed + e.lstm[0].b_off;
+    if (NT == 13) hipLaunchKernelGGL(lstm_pre_t_kernel<13>, dim3((unsigned)ct), dim3(64 * 13), 0, st, w0, b0, e.kx >> 2, xe, pre, ct * 32);
+    else if (NT == 16) hipLaunchKernelGGL(lstm_pre_t_kernel<16>, dim3((unsigned)ct), dim3(64 * 16), 0, st, w0, b0, e.kx >> 2, xe, pre, ct * 32);
+    else { set_error("unsupported LSTM hidden size: %d tiles of 8 units", NT); return -4; }
+    rc = launch_check("lstm_pre_t_kernel");
+    if (rc) return rc;
+    LstmSeqArgs l = {};
+    l.gru = lay.gru;
+    l.w[0] = w0; l.b[0] = b0;
+    l.kx = e.kx; l.n_rows = n_windows; l.n_rowtiles = rt; l.T = T;
+    l.pre_t = pre; l.pre_stride = ct * 32; l.pre_tstride = 1; l.L = lay.L;
+    l.hout = h0; l.t_out0 = 0;
+    l.din.state_in = state_in; l.din.state_div = 1;
+    l.state_out = state_out;
+    l.st_nl = 2; l.st_l0 = 0;
+    return launch_lstm<0>(l, NT, 1, false, st);
+}
+
+static int encode_windows_layer1_impl(const vsv_dims* dims, const float* packed, int which, long n_windows, int T,
+                                      const float* state_in, float* state_out, float* out, int out_f, void* ws,
+                                      size_t ws_bytes, void* stream);
+
+extern "C" int vsv_encode_windows_layer1(const vsv_dims* dims, const float* packed, int which, long n_windows, int T,
+                                         const float* state_in, float* state_out, float* out, void* ws,
+                                         size_t ws_bytes, void* stream) {
+    return encode_windows_layer1_impl(dims, packed, which, n_windows, T, state_in, state_out, out, 0, ws, ws_bytes, stream);
+}
+
+// out_f: head outputs written per (window, step), 0 = all (the prefix pipeline wants z_mean only: L of 2L)
+static int encode_windows_layer1_impl(const vsv_dims* dims, const float* packed, int which, long n_windows, int T,
+                                      const float* state_in, float* state_out, float* out, int out_f, void* ws,
+                                      size_t ws_bytes, void* stream) {
+    VSV_LAYOUT_OR_FAIL("vsv_encode_windows_layer1")
+    if (which < 0 || which > 1) { set_error("vsv_encode_windows_layer1: which must be 0 or 1"); return -1; }
+    if (lay.NL != 2) { set_error("vsv_encode_windows_layer1: the layer split is for two-layer memories"); return -4; }
+    if (n_windows < 0 || T < 0) { set_error("vsv_encode_windows_layer1: negative size"); return -1; }
+    if (n_windows == 0 || T == 0) return 0;
+    if (!packed || !out || !ws) { set_error("vsv_encode_windows_layer1: null pointer"); return -1; }
+    const long rt = (n_windows + 31) / 32;
+    if (rt > kWideMaxRowtiles) { set_error("vsv_encode_windows_layer1: at most %ld windows per call", kWideMaxRowtiles * 32); return -5; }
+    size_t off[5];
+    if (ws_bytes < enc_split_bytes(lay, n_windows, T, off)) { set_error("vsv_encode_windows_layer1: workspace too small"); return -1; }
+    hipStream_t st = (hipStream_t)stream;
+    const EncLayout& e = lay.enc[which];
+    const int NT = lay.NTm;
+    char* base = (char*)(((uintptr_t)ws + 255) & ~(uintptr_t)255);
+    const float* h0 = (const float*)(base + off[2]);
+    float* g1 = (float*)(base + off[3]);
+    float* h1 = (float*)(base + off[4]);
+    const float* w1 = packed + e.lstm[1].w_off;
+    const float* b1 = packed + e.lstm[1].b_off;
+    int rc = launch_lstm_pre(NT, w1, b1, NT, h0, (long)4 * NT * 64, g1, (long)16 * NT * 64, rt * T, st);
+    if (rc) return rc;
+    LstmSeqArgs l = {};
+    l.gru = lay.gru;
+    l.w[0] = w1; l.b[0] = b1;
+    l.kx = 4 * NT; l.n_rows = n_windows; l.n_rowtiles = rt; l.T = T;
+    l.pre_g = g1; l.L = lay.L;
+    l.hout = h1; l.t_out0 = 0;
+    l.din.state_in = state_in; l.din.state_div = 1;
+    l.state_out = state_out;
+    l.st_nl = 2; l.st_l0 = 1;
+    rc = launch_lstm<0>(l, NT, 1, false, st);
+    if (rc) return rc;
+    DenseChainArgs h = {};
+    h.n_layers = 1;
+    fill_dense(h, 0, packed, e.head);
+    h.n_rows = n_windows; h.n_rowtiles = rt; h.T = T;
+    h.in_mode = 1; h.in = h1; h.in_ks = 4 * NT;
+    h.out_mode = 1; h.out = out; h.out_f = (out_f > 0 && out_f < e.nh) ? out_f : e.nh; h.S = 1;
+    h.aux_layer = -1;
+    return launch_dense_chain(h, st);
+}
+
+static size_t dec_split_bytes(const Layout& lay, long n_rows, int T, size_t off[2]) {
+    const long rt = (n_rows + 31) / 32;
+    off[0] = 0;
+    off[1] = align256((size_t)rt * T * 4 * lay.NTd * 64 * sizeof(float));                      // h0 | layer-1 pre-activations
+    return off[1] + align256((size_t)rt * T * 16 * lay.NTd * 64 * sizeof(float)) + 256;
+}
+
+extern "C" size_t vsv_decode_prefix_split_ws_bytes(const vsv_dims* dims, long n_rows, int T) {
+    Layout lay;
+    const char* msg = nullptr;
+    size_t off[2];
+    if (!dims || make_layout(*dims, lay, &msg) != 0 || n_rows < 0 || T < 0) return 0;
+    return dec_split_bytes(lay, n_rows, T, off);
+}
+
+static int decode_prefix_check(const char* who, const Layout& lay, const float* packed, const vsv_decode_in* in, long n_rows,
+                               int T, void* ws, size_t ws_bytes, size_t off[2]) {
+    if (lay.NL != 2) { set_error("%s: the layer split is for two-layer memories", who); return -4; }
+    if (!packed || !in || !ws) { set_error("%s: null pointer", who); return -1; }
+    if (n_rows < 1 || n_rows > 0x7fffffffL || T < 1) { set_error("%s: bad sizes", who); return -1; }
+    if ((n_rows + 31) / 32 > kWideMaxRowtiles) { set_error("%s: at most %ld rows per call", who, kWideMaxRowtiles * 32); return -5; }
+    if (ws_bytes < dec_split_bytes(lay, n_rows, T, off)) { set_error("%s: workspace too small", who); return -1; }
+    if (in->gate_in) { set_error("%s: gate_in is for the Monte-Carlo draw, not the prefix", who); return -1; }
+    if (in->state_in && in->state_div != 1) { set_error("%s: state_div must be 1", who); return -1; }
+    return 0;
+}
+
+extern "C" int vsv_decode_prefix_layer0(const vsv_dims* dims, const float* packed, const vsv_decode_in* in, long n_rows,
+                                        int T, float* state_out, void* ws, size_t ws_bytes, void* stream) {
+    VSV_LAYOUT_OR_FAIL("vsv_decode_prefix_layer0")
+    size_t off[2];
+    if (int rc = decode_prefix_check("vsv_decode_prefix_layer0", lay, packed, in, n_rows, T, ws, ws_bytes, off)) return rc;
+    if (in->ctx_T != T || in->z_T != T || !in->ctx || !in->zb || in->lv) {
+        set_error("vsv_decode_prefix_layer0: the prefix runs on (ctx_t, z_mean_t) for all T steps"); return -1;
+    }
+    const DecLayout& dc = lay.dec;
+    char* base = (char*)(((uintptr_t)ws + 255) & ~(uintptr_t)255);
+    LstmSeqArgs l = {};
+    l.gru = lay.gru;
+    l.w[0] = packed + dc.lstm[0].w_off; l.b[0] = packed + dc.lstm[0].b_off;
+    l.kx = dc.kx; l.n_rows = n_rows; l.n_rowtiles = (n_rows + 31) / 32; l.T = T;
+    l.L = lay.L; l.din = *in;
+    if (l.din.ctx_div < 1) l.din.ctx_div = 1;
+    if (l.din.z_div < 1) l.din.z_div = 1;
+    if (l.din.S < 1) l.din.S = 1;
+    l.din.state_div = 1;
+    l.state_out = state_out;
+    l.hout = (float*)(base + off[0]); l.t_out0 = 0;
+    l.st_nl = 2; l.st_l0 = 0;
+    return launch_lstm<1>(l, lay.NTd, 1, false, (hipStream_t)stream);
+}
+
+extern "C" int vsv_decode_prefix_layer1(const vsv_dims* dims, const float* packed, const vsv_decode_in* in, long n_rows,
+                                        int T, float* state_out, void* ws, size_t ws_bytes, void* stream) {
+    VSV_LAYOUT_OR_FAIL("vsv_decode_prefix_layer1")
+    size_t off[2];
+    if (int rc = decode_prefix_check("vsv_decode_prefix_layer1", lay, packed, in, n_rows, T, ws, ws_bytes, off)) return rc;
+    hipStream_t st = (hipStream_t)stream;
+    const DecLayout& dc = lay.dec;
+    const int NT = lay.NTd;
+    const long rt = (n_rows + 31) / 32;
+    char* base = (char*)(((uintptr_t)ws + 255) & ~(uintptr_t)255);
+    const float* h0 = (const float*)(base + off[0]);
+    float* g1 = (float*)(base + off[1]);
+    const float* w1 = packed + dc.lstm[1].w_off;
+    const float* b1 = packed + dc.lstm[1].b_off;
+    int rc = launch_lstm_pre(NT, w1, b1, NT, h0, (long)4 * NT * 64, g1, (long)16 * NT * 64, rt * T, st);
+    if (rc) return rc;
+    LstmSeqArgs l = {};
+    l.gru = lay.gru;
+    l.w[0] = w1; l.b[0] = b1;
+    l.kx = 4 * NT; l.n_rows = n_rows; l.n_rowtiles = rt; l.T = T;
+    l.pre_g = g1; l.L = lay.L;
+    l.din.state_in = in->state_in; l.din.state_div = 1;
+    l.din.gate_out = in->gate_out;
+    l.state_out = state_out;
+    l.t_out0 = T;
+    l.st_nl = 2; l.st_l0 = 1;
+    return launch_lstm<0>(l, NT, 1, false, st);
+}
+
+// ---- the whole date-range prefix as ONE call: every stage launch of every time segment, issued from native code
+// (the Python loop over the same entry points spends ~0.15 ms of host time per segment, more than a segment's
+// stages take on the GPU) onto the caller's worker streams, ordered by HIP events.
+struct PrefixPlan {
+    int n_seg;
+    size_t seg_off[65];          // per segment: start of its block
+    size_t o_wse, o_wsc, o_wsd, o_zm, o_ctx, o_ste, o_stc, o_std;   // offsets inside a segment's block
+    size_t wse_bytes, wsd_bytes;
+    size_t total;
+};
+
+static int prefix_plan(const Layout& lay, long n_days, int C, int n_seg, PrefixPlan& p) {
+    if (n_seg < 1 || n_seg > 64 || C < n_seg) return -1;
+    p.n_seg = n_seg;
+    size_t cur = 0;
+    const size_t nse = (size_t)lay.NL * 2 * 8 * lay.NTm, nsd = (size_t)lay.NL * 2 * 8 * lay.NTd;
+    for (int i = 0; i < n_seg; ++i) {
+        const int T = ((i + 1) * C) / n_seg - (i * C) / n_seg;
+        size_t off5[5], off2[2];
+        p.seg_off[i] = cur;
+        // (the largest segment's sizes serve all: blocks are laid out with the first segment's T or larger)
+        const size_t wse = enc_split_bytes(lay, n_days, T, off5), wsd = dec_split_bytes(lay, n_days, T, off2);
+        size_t b = 0;
+        b += align256(wse);                                    // posterior encoder workspace
+        b += align256(wse);                                    // context encoder workspace
+        b += align256(wsd);                                    // decoder workspace
+        b += 2 * align256((size_t)n_days * T * lay.L * sizeof(float));      // z_mean, ctx embedding
+        b += 2 * align256((size_t)n_days * nse * sizeof(float));            // encoder states
+        b += align256((size_t)n_days * nsd * sizeof(float));                // decoder state
+        cur += b;
+    }
+    p.seg_off[n_seg] = cur;
+    p.total = cur + 256;
+    return 0;
+}
+
+extern "C" size_t vsv_context_prefix_ws_bytes(const vsv_dims* dims, long n_days, int ctx_len, int n_seg) {
+    Layout lay;
+    const char* msg = nullptr;
+    PrefixPlan p;
+    if (!dims || make_layout(*dims, lay, &msg) != 0 || n_days < 0 || prefix_plan(lay, n_days, ctx_len, n_seg, p) != 0) return 0;
+    return p.total;
+}
+
+extern "C" int vsv_context_prefix(const vsv_dims* dims, const float* packed, const float* vol, const float* ex, long n_days,
+                                  int ctx_len, int n_seg, void* const* streams, int n_streams, float* state_out,
+                                  float* gate_out, void* ws, size_t ws_bytes, void* stream) {
+    VSV_LAYOUT_OR_FAIL("vsv_context_prefix")
+    if (lay.NL != 2) { set_error("vsv_context_prefix: the layer split is for two-layer memories"); return -4; }
+    if (!packed || !vol || !streams || !state_out || !gate_out || !ws) { set_error("vsv_context_prefix: null pointer"); return -1; }
+    if (lay.X > 0 && !ex) { set_error("vsv_context_prefix: ex_feats_dim > 0 but ex is null"); return -1; }
+    if (n_days < 1 || (n_days + 31) / 32 > kWideMaxRowtiles) { set_error("vsv_context_prefix: 1..%ld days per call", kWideMaxRowtiles * 32); return -5; }
+    if (n_streams != 3 && n_streams != 4 && n_streams != 6) { set_error("vsv_context_prefix: 3, 4 or 6 worker streams"); return -1; }
+    PrefixPlan pl;
+    if (prefix_plan(lay, n_days, ctx_len, n_seg, pl) != 0) { set_error("vsv_context_prefix: 1 <= n_seg <= min(64, ctx_len)"); return -1; }
+    if (ws_bytes < pl.total) { set_error("vsv_context_prefix: workspace too small"); return -1; }
+    hipStream_t main = (hipStream_t)stream;
+    // stage -> stream: (encoder L0, encoder L1, context L0, context L1, decoder L0, decoder L1); with four
+    // streams (HIP's default number of hardware queues) the two encoders' same-layer stages share one
+    hipStream_t sq[6];
+    for (int k = 0; k < 6; ++k) {
+        static const int map4[6] = {0, 0, 1, 1, 2, 3}, map3[6] = {0, 0, 1, 1, 2, 2};
+        sq[k] = (hipStream_t)streams[n_streams == 6 ? k : (n_streams == 4 ? map4[k] : map3[k])];
+    }
+    auto ev_new = [](hipEvent_t& e) { return hipEventCreateWithFlags(&e, hipEventDisableTiming) == hipSuccess; };
+    auto fail_hip = [](const char* what) { set_error("vsv_context_prefix: %s: %s", what, hipGetErrorString(hipGetLastError())); return -3; };
+    hipEvent_t fork;
+    if (!ev_new(fork)) return fail_hip("hipEventCreate");
+    (void)hipEventRecord(fork, main);
+    for (int k = 0; k < n_streams; ++k) (void)hipStreamWaitEvent((hipStream_t)streams[k], fork, 0);
+    (void)hipEventDestroy(fork);
+
+    char* base = (char*)(((uintptr_t)ws + 255) & ~(uintptr_t)255);
+    const size_t nse = (size_t)lay.NL * 2 * 8 * lay.NTm;
+    const float *st_e = nullptr, *st_c = nullptr, *st_d = nullptr;
+    int rc = 0;
+    for (int i = 0; i < n_seg && rc == 0; ++i) {
+        const int t0 = (i * ctx_len) / n_seg, T = ((i + 1) * ctx_len) / n_seg - t0;
+        const bool last = i == n_seg - 1;
+        size_t off5[5], off2[2];
+        const size_t wse = enc_split_bytes(lay, n_days, T, off5), wsd = dec_split_bytes(lay, n_days, T, off2);
+        char* b = base + pl.seg_off[i];
+        void* ws_e = b; b += align256(wse);
+        void* ws_c = b; b += align256(wse);
+        void* ws_d = b; b += align256(wsd);
+        float* zm = (float*)b; b += align256((size_t)n_days * T * lay.L * sizeof(float));
+        float* cx = (float*)b; b += align256((size_t)n_days * T * lay.L * sizeof(float));
+        float* ne = (float*)b; b += align256((size_t)n_days * nse * sizeof(float));
+        float* nc = (float*)b; b += align256((size_t)n_days * nse * sizeof(float));
+        float* nd = last ? state_out : (float*)b;
+        const float* v = vol + (size_t)25 * t0;
+        const float* e = lay.X > 0 ? ex + (size_t)lay.X * t0 : nullptr;
+        hipEvent_t evs[5];
+        for (auto& q : evs) if (!ev_new(q)) return fail_hip("hipEventCreate");
+        // encoders: layer 0, then (other stream) layer 1 + head; the final states of the last segment are not needed
+        for (int which = 0; which < 2 && rc == 0; ++which) {
+            hipStream_t s0 = sq[2 * which], s1 = sq[2 * which + 1];
+            float* so = last ? nullptr : (which ? nc : ne);
+            const float* si = which ? st_c : st_e;
+            void* w = which ? ws_c : ws_e;
+            rc = vsv_encode_windows_layer0(dims, packed, which, v, e, n_days, T, si, so, w, wse, s0);
+            if (rc) break;
+            (void)hipEventRecord(evs[which], s0);
+            (void)hipStreamWaitEvent(s1, evs[which], 0);
+            rc = encode_windows_layer1_impl(dims, packed, which, n_days, T, si, so, which ? cx : zm, lay.L, w, wse, s1);
+            if (rc) break;
+            (void)hipEventRecord(evs[2 + which], s1);
+            (void)hipStreamWaitEvent(sq[4], evs[2 + which], 0);
+        }
+        if (rc == 0) {
+            vsv_decode_in din = {};
+            din.ctx = cx; din.ctx_rs = (long)T * lay.L; din.ctx_T = T; din.ctx_div = 1;
+            din.zb = zm; din.z_rs = (long)T * lay.L; din.z_T = T; din.z_div = 1;
+            din.S = 1; din.state_in = st_d; din.state_div = 1;
+            din.gate_out = last ? gate_out : nullptr;
+            rc = vsv_decode_prefix_layer0(dims, packed, &din, n_days, T, nd, ws_d, wsd, sq[4]);
+            if (rc == 0) {
+                (void)hipEventRecord(evs[4], sq[4]);
+                (void)hipStreamWaitEvent(sq[5], evs[4], 0);
+                rc = vsv_decode_prefix_layer1(dims, packed, &din, n_days, T, nd, ws_d, wsd, sq[5]);
+            }
+        }
+        for (auto& q : evs) (void)hipEventDestroy(q);
+        st_e = ne; st_c = nc; st_d = nd;
+    }
+    // join: the caller's stream continues when every worker stream has drained
+    for (int k = 0; k < n_streams; ++k) {
+        hipEvent_t j;
+        if (!ev_new(j)) return fail_hip("hipEventCreate");
+        (void)hipEventRecord(j, (hipStream_t)streams[k]);
+        (void)hipStreamWaitEvent(main, j, 0);
+        (void)hipEventDestroy(j);
+    }
+    return rc;
 }
 
 // ---- the one entry point that allocates nothing, for callers that cannot call hipMalloc (code under HIP graph

@@ -361,6 +361,71 @@ class Engine:
         _lib.check(rc, "vsv_encode_windows")
         return (out, st_out) if want_state else out
 
+    # -- the date-range prefix as layer stages (vsv_*_layer0 / _layer1) ------------------------------
+    def enc_state_floats(self) -> int:
+        return int(self.lib.vsv_enc_state_floats(C.byref(self.dims)))
+
+    def encode_windows_layer0(self, which, vol, ex, n_windows, T, state_in, state_out, ws=None):
+        """Layer 0 of encoder `which` over the windows (on the current stream); h0 of every step stays in the
+        returned workspace, which the matching encode_windows_layer1 call takes."""
+        if ws is None:
+            ws = self._ws(self.lib.vsv_encode_windows_split_ws_bytes(C.byref(self.dims), n_windows, T))
+        with torch.cuda.device(self.device):
+            rc = self.lib.vsv_encode_windows_layer0(C.byref(self.dims), _ptr(self.packed), which, _ptr(vol), _ptr(ex),
+                                                    n_windows, T, _ptr(state_in), _ptr(state_out),
+                                                    _ptr(ws), ws.numel(), self._stream())
+        _lib.check(rc, "vsv_encode_windows_layer0")
+        return ws
+
+    def encode_windows_layer1(self, which, n_windows, T, state_in, state_out, ws):
+        nh = self.L if which else 2 * self.L
+        out = torch.empty((n_windows, T, nh), dtype=torch.float32, device=self.device)
+        with torch.cuda.device(self.device):
+            rc = self.lib.vsv_encode_windows_layer1(C.byref(self.dims), _ptr(self.packed), which, n_windows, T,
+                                                    _ptr(state_in), _ptr(state_out), _ptr(out),
+                                                    _ptr(ws), ws.numel(), self._stream())
+        _lib.check(rc, "vsv_encode_windows_layer1")
+        return out
+
+    def decode_prefix_layer(self, layer: int, n_rows: int, T: int, ctx, zb, state_in, state_out, gates, ws=None):
+        """Layer `layer` of the decoder's context prefix over (ctx_t, z_mean_t) (ctx, zb: (n_rows, T, L))."""
+        din = _lib.VsvDecodeIn()
+        if layer == 0:
+            din.ctx, din.ctx_rs, din.ctx_T, din.ctx_div = ctx.data_ptr(), T * self.L, T, 1
+            din.zb, din.z_rs, din.z_T, din.z_div = zb.data_ptr(), T * self.L, T, 1
+        din.S, din.state_div = 1, 1
+        if state_in is not None:
+            din.state_in = state_in.data_ptr()
+        if gates is not None:
+            din.gate_out = gates.data_ptr()
+        if ws is None:
+            ws = self._ws(self.lib.vsv_decode_prefix_split_ws_bytes(C.byref(self.dims), n_rows, T))
+        fn = self.lib.vsv_decode_prefix_layer0 if layer == 0 else self.lib.vsv_decode_prefix_layer1
+        with torch.cuda.device(self.device):
+            rc = fn(C.byref(self.dims), _ptr(self.packed), C.byref(din), n_rows, T, _ptr(state_out),
+                    _ptr(ws), ws.numel(), self._stream())
+        _lib.check(rc, f"vsv_decode_prefix_layer{layer}")
+        return ws
+
+    def context_prefix(self, vol, ex, n_days: int, ctx_len: int, n_seg: int, n_streams: int = 4):
+        """vsv_context_prefix: decoder state after the context steps + first-step shared gates for the windows
+        vol[d : d + ctx_len], as a pipeline of layer stages over time segments on the engine's worker streams."""
+        pool = getattr(self, "_stage_streams", None)
+        if pool is None or len(pool) < n_streams:
+            pool = self._stage_streams = [torch.cuda.Stream(self.device) for _ in range(6)]
+        arr = (C.c_void_p * n_streams)(*[s.cuda_stream for s in pool[:n_streams]])
+        state = torch.empty((n_days, self.state_floats), dtype=torch.float32, device=self.device)
+        gates = torch.empty((n_days, self.gate_floats), dtype=torch.float32, device=self.device)
+        ws = self._ws(self.lib.vsv_context_prefix_ws_bytes(C.byref(self.dims), n_days, ctx_len, n_seg))
+        with torch.cuda.device(self.device):
+            rc = self.lib.vsv_context_prefix(C.byref(self.dims), _ptr(self.packed), _ptr(vol), _ptr(ex), n_days, ctx_len,
+                                             n_seg, arr, n_streams, _ptr(state), _ptr(gates),
+                                             _ptr(ws), ws.numel(), self._stream())
+        _lib.check(rc, "vsv_context_prefix")
+        # (ws is used on the worker streams, which the call joined back into the current stream: freeing it to
+        # the current stream's pool after this point is ordered behind that join)
+        return state, gates
+
     def encode_both_windows(self, vol, ex, n_windows, T, T_ctx=None):
         """Both encoders over overlapping windows (posterior encoder T steps, context encoder T_ctx), on two
         HIP streams (see encode_both_strided); falls back to the strided entry point beyond MAX_WINDOWS."""

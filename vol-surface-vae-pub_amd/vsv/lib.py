@@ -152,6 +152,22 @@ SIGNATURES = {
     "vsv_encode_windows_state": (C.c_int, [C.POINTER(VsvDims), C.c_void_p, C.c_int, C.c_void_p, C.c_void_p,
                                            C.c_long, C.c_int, C.c_void_p, C.c_void_p,
                                            C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "vsv_encode_windows_split_ws_bytes": (C.c_size_t, [C.POINTER(VsvDims), C.c_long, C.c_int]),
+    "vsv_encode_windows_layer0": (C.c_int, [C.POINTER(VsvDims), C.c_void_p, C.c_int, C.c_void_p, C.c_void_p,
+                                            C.c_long, C.c_int, C.c_void_p, C.c_void_p,
+                                            C.c_void_p, C.c_size_t, C.c_void_p]),
+    "vsv_encode_windows_layer1": (C.c_int, [C.POINTER(VsvDims), C.c_void_p, C.c_int, C.c_long, C.c_int,
+                                            C.c_void_p, C.c_void_p, C.c_void_p,
+                                            C.c_void_p, C.c_size_t, C.c_void_p]),
+    "vsv_decode_prefix_split_ws_bytes": (C.c_size_t, [C.POINTER(VsvDims), C.c_long, C.c_int]),
+    "vsv_decode_prefix_layer0": (C.c_int, [C.POINTER(VsvDims), C.c_void_p, C.POINTER(VsvDecodeIn), C.c_long, C.c_int,
+                                           C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "vsv_decode_prefix_layer1": (C.c_int, [C.POINTER(VsvDims), C.c_void_p, C.POINTER(VsvDecodeIn), C.c_long, C.c_int,
+                                           C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "vsv_context_prefix_ws_bytes": (C.c_size_t, [C.POINTER(VsvDims), C.c_long, C.c_int, C.c_int]),
+    "vsv_context_prefix": (C.c_int, [C.POINTER(VsvDims), C.c_void_p, C.c_void_p, C.c_void_p, C.c_long, C.c_int, C.c_int,
+                                     C.POINTER(C.c_void_p), C.c_int, C.c_void_p, C.c_void_p,
+                                     C.c_void_p, C.c_size_t, C.c_void_p]),
     "vsv_encode_pre_ws_bytes": (C.c_size_t, [C.POINTER(VsvDims), C.c_long]),
     "vsv_encode_pre": (C.c_int, [C.POINTER(VsvDims), C.c_void_p, C.c_int, C.c_void_p, C.c_long, C.c_void_p, C.c_long,
                                  C.c_long, C.c_void_p, C.c_long, C.c_void_p, C.c_size_t, C.c_void_p]),
@@ -210,7 +226,7 @@ def load() -> C.CDLL:
             fn = getattr(lib, name)
             fn.restype = res
             fn.argtypes = args
-        if lib.vsv_abi_version() != 15:
+        if lib.vsv_abi_version() != 16:
             raise RuntimeError("libvsv_hip.so ABI version mismatch")
         _lib = lib
     return _lib

@@ -60,13 +60,24 @@ def _context_prefix(eng: Engine, sv: torch.Tensor, se: Optional[torch.Tensor], n
                     n_seg: Optional[int] = None):
     """Decoder state after the C context steps of the windows sv[d : d + C] (d < n_days), and the first
     future step's shared gates: posterior mean and context embedding from the two encoders, then the
-    decoder over (ctx_t, z_mean_t).  The three launches are each bound by one CU per 32-day tile stepping
-    through time, and the decoder's step t needs the encoders' step t only -- so the C steps are cut into
-    n_seg segments and the decoder's segment i runs (third stream) beside the encoders' segment i+1, the
-    memory states handed from segment to segment (VSV_PREFIX_SEGMENTS overrides; 1 = one launch each)."""
+    decoder over (ctx_t, z_mean_t).
+    Every recurrent launch is bound by one CU per 32-day tile stepping through time, so the C steps are cut
+    into time segments whose stages overlap on several streams, the memory states handed from segment to
+    segment.  Two schedules (same products in the same order, bit-equal results):
+      * fused stacks, three streams (posterior encoder, context encoder, decoder), three segments;
+      * up to 2048 days (two-layer memories): every stack also split into its two layers -- layer 1's input
+        product b + W_ih . h0 leaves the time loop for one launch over all steps -- with the decoder's two
+        layers on streams of their own (four worker streams = HIP's default number of hardware queues), all
+        launches issued by the native vsv_context_prefix.  Measured prefix latency, context 60: 2.11 / 2.21 /
+        2.47 ms at 500 / 1000 / 2000 days against 2.40 / 2.56 / 2.59 ms fused; beyond that the CUs are
+        saturated and the extra launches cost more than the overlap gains (4000 days: 3.4 vs 3.06 ms).
+    VSV_PREFIX_SEGMENTS overrides the segment count (1 = one fused launch per stack); VSV_PREFIX_LAYERS = 0 /
+    1 / py forces the fused / split / split-driven-from-Python schedule, VSV_PREFIX_STREAMS = 3 / 4 / 6."""
     L = eng.L
+    mode = os.environ.get("VSV_PREFIX_LAYERS", "")
+    split = eng.dims.mem_layers == 2 and (mode in ("1", "py") or (mode == "" and n_days <= 2048))
     if n_seg is None:
-        n_seg = int(os.environ.get("VSV_PREFIX_SEGMENTS", "3"))
+        n_seg = int(os.environ.get("VSV_PREFIX_SEGMENTS", "0")) or (4 if split else 3)
     if n_seg <= 1 or n_days > eng.MAX_WINDOWS or ctx_len < 4 * n_seg:
         enc, ctx = eng.encode_both_windows(sv, se, n_days, ctx_len)
         zm = enc[..., :L].contiguous()
@@ -74,6 +85,10 @@ def _context_prefix(eng: Engine, sv: torch.Tensor, se: Optional[torch.Tensor], n
         return pre["state"], pre["gates"]
     dev = eng.device
     main = torch.cuda.current_stream(dev)
+    if split and mode == "py":
+        return _context_prefix_layers(eng, sv, se, n_days, ctx_len, n_seg, main)
+    if split:
+        return eng.context_prefix(sv, se, n_days, ctx_len, n_seg, int(os.environ.get("VSV_PREFIX_STREAMS", "4")))
     if eng._side is None:
         eng._side = torch.cuda.Stream(dev)
     if getattr(eng, "_third", None) is None:
@@ -108,6 +123,53 @@ def _context_prefix(eng: Engine, sv: torch.Tensor, se: Optional[torch.Tensor], n
     pre["state"].record_stream(main)
     pre["gates"].record_stream(main)
     return pre["state"], pre["gates"]
+
+
+def _context_prefix_layers(eng: Engine, sv, se, n_days: int, ctx_len: int, n_seg: int, main):
+    """_context_prefix with every stack split into its two layers (see there)."""
+    L, dev = eng.L, eng.device
+    pool = getattr(eng, "_stage_streams", None)
+    if pool is None:
+        pool = eng._stage_streams = [torch.cuda.Stream(dev) for _ in range(6)]
+    e0, e1, c0, c1, d0, d1 = pool
+    for s in pool:
+        s.wait_stream(main)
+    f32 = dict(dtype=torch.float32, device=dev)
+    keep = []                                                  # every buffer stays referenced until the streams have joined
+    nse, nsd = eng.enc_state_floats(), eng.state_floats
+    st_e = st_c = st_d = None
+    gates = torch.empty((n_days, eng.gate_floats), **f32)
+    for i in range(n_seg):
+        t0, t1 = (i * ctx_len) // n_seg, ((i + 1) * ctx_len) // n_seg
+        Ts, last = t1 - t0, i == n_seg - 1
+        v, e = sv[t0:], (se[t0:] if se is not None else None)
+        ne = None if last else torch.empty((n_days, nse), **f32)      # the encoders' final states are not needed
+        nc = None if last else torch.empty((n_days, nse), **f32)
+        nd = torch.empty((n_days, nsd), **f32)
+        outs = {}
+        for which, s0, s1, st_in, st_out in ((0, e0, e1, st_e, ne), (1, c0, c1, st_c, nc)):
+            with torch.cuda.stream(s0):
+                ws = eng.encode_windows_layer0(which, v, e, n_days, Ts, st_in, st_out)
+                ev = s0.record_event()
+            s1.wait_event(ev)
+            with torch.cuda.stream(s1):
+                o = eng.encode_windows_layer1(which, n_days, Ts, st_in, st_out, ws)
+                outs[which] = o[..., :L].contiguous() if which == 0 else o
+                evo = s1.record_event()
+            d0.wait_event(evo)
+            keep += [ws, o]
+        with torch.cuda.stream(d0):
+            wsd = eng.decode_prefix_layer(0, n_days, Ts, outs[1], outs[0], st_d, nd, gates if last else None)
+            ev = d0.record_event()
+        d1.wait_event(ev)
+        with torch.cuda.stream(d1):
+            eng.decode_prefix_layer(1, n_days, Ts, None, None, st_d, nd, gates if last else None, ws=wsd)
+        keep += [wsd, outs[0], outs[1], st_e, st_c, st_d]
+        st_e, st_c, st_d = ne, nc, nd
+    for s in pool:
+        main.wait_stream(s)
+    del keep
+    return st_d, gates
 
 
 def _empty_quantiles(eng: Engine, horizon: int, nq: int, channel: Optional[int]) -> torch.Tensor:

@@ -457,6 +457,16 @@ typedef struct vsv_loss {
 } vsv_loss;
 int vsv_loss_grad(const vsv_loss *d, void *stream);
 
+/* Backward of the reparameterisation z = mu + exp(0.5 logvar) * eps (:199) and of the decoder-input cat (:1066),
+ * the autograd steps between the decoder's and the encoders' backward passes: from dx (B, T, 2L) = gradient
+ * w.r.t. [ctx_pad | z],
+ *   d_enc (B, T, 2L) = [ dz + d_zm | dz * 0.5 * (z - mu) + d_zl ]  with dz = dx[.., L:] (+ d_z),
+ *   d_ctx (B, Tc, L) = dx[:, :Tc, :L] (* ctx_mask (B, Tc), the per-row context lengths of multi-horizon training).
+ * d_zm / d_zl (the KL term's gradients), d_z and ctx_mask may be NULL. */
+int vsv_reparam_backward(const float *dx, const float *z, const float *zm, const float *d_zm, const float *d_zl,
+                         const float *d_z, const float *ctx_mask, long B, int T, int Tc, int L,
+                         float *d_enc, float *d_ctx, void *stream);
+
 /* The dropout factors (0 or 1/(1-p)) the training kernels apply to layer `layer`'s output of
  * LSTM `id`: out (n_rows, T, hidden).  Test / debugging aid: the reference draws its masks from
  * torch's generator (inside nn.LSTM), so parity is checked with this mask injected into the

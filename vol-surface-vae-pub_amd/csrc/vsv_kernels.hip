@@ -1578,6 +1578,17 @@ __global__ void __launch_bounds__(256, 1) lstm_bwd_kernel(const LstmBwdArgs a) {
     const int t_outs = a.T - a.t_out0;
     // layers of the saved arrays / first of them handled here (one launch per layer: NL = 1, sv_nl = 2)
     const int SL = a.sv_nl > 0 ? a.sv_nl : NL, L0 = a.sv_nl > 0 ? a.sv_l0 : 0;
+    // One layer per launch (the training schedule): this wave's W_hh^T fragments -- its 32 hidden units against
+    // all 4H gate rows, 4*NT quads -- stay in REGISTERS for the whole time loop (the kernel runs one wave per
+    // SIMD, 512 VGPRs each), so a step streams nothing from L2 and starts its products as soon as dgates(t+1)
+    // is in LDS; the dependent chain of 16*NT products runs as two interleaved chains.
+    constexpr bool WREG = (NL == 1);
+    float4 wreg[WREG ? 4 * NT : 1];
+    if constexpr (WREG) {
+        const float4* wT = (const float4*)a.wT_hh[0] + lane + wave * 64;
+#pragma unroll
+        for (int q = 0; q < 4 * NT; ++q) wreg[q] = wT[(size_t)q * 4 * 64];
+    }
     __syncthreads();
 
     for (int t = a.T - 1; t >= 0; --t) {
@@ -1634,8 +1645,32 @@ __global__ void __launch_bounds__(256, 1) lstm_bwd_kernel(const LstmBwdArgs a) {
                     }
                 }
             }
-            if (t + 1 < a.T)
-                gemm_seg<1>(acc, (const float4*)a.wT_hh[l], lane, toff1, 4 * 64, dg + (size_t)l * GK * 64, 4 * NT);
+            if (t + 1 < a.T) {
+                if constexpr (WREG) {
+                    f32x16 acc2;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc2[r] = 0.0f;
+                    const float* b = dg;
+#pragma unroll
+                    for (int q = 0; q < 4 * NT; q += 2) {
+                        const float b0 = b[(4 * q + 0) * 64], b1 = b[(4 * q + 1) * 64], b2 = b[(4 * q + 2) * 64],
+                                    b3 = b[(4 * q + 3) * 64], b4 = b[(4 * q + 4) * 64], b5 = b[(4 * q + 5) * 64],
+                                    b6 = b[(4 * q + 6) * 64], b7 = b[(4 * q + 7) * 64];
+                        acc[0] = mfma32(wreg[q].x, b0, acc[0]);
+                        acc2 = mfma32(wreg[q + 1].x, b4, acc2);
+                        acc[0] = mfma32(wreg[q].y, b1, acc[0]);
+                        acc2 = mfma32(wreg[q + 1].y, b5, acc2);
+                        acc[0] = mfma32(wreg[q].z, b2, acc[0]);
+                        acc2 = mfma32(wreg[q + 1].z, b6, acc2);
+                        acc[0] = mfma32(wreg[q].w, b3, acc[0]);
+                        acc2 = mfma32(wreg[q + 1].w, b7, acc2);
+                    }
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[0][r] += acc2[r];
+                } else {
+                    gemm_seg<1>(acc, (const float4*)a.wT_hh[l], lane, toff1, 4 * 64, dg + (size_t)l * GK * 64, 4 * NT);
+                }
+            }
             // cell backward for the 16 units of this lane
             float dgv[16][4];
 #pragma unroll
@@ -3471,6 +3506,45 @@ extern "C" int vsv_tileb_gemm_launch(const vsv_tileb_gemm* d, void* stream) {
     if (insts > 0x7fffffffL) { set_error("vsv_tileb_gemm_launch: too many instances"); return -2; }
     hipLaunchKernelGGL(tileb_gemm_kernel, dim3((unsigned)insts), dim3(256), 0, (hipStream_t)stream, *d);
     return launch_check("tileb_gemm_kernel");
+}
+
+// Backward of the reparameterisation z = mu + exp(0.5 logvar) * eps (:199) and of the decoder-input cat (:1066):
+// from dx (B, T, 2L) = d loss / d [ctx_pad | z]
+//   d_enc (B, T, 2L) = [ dz + d_zm | dz * 0.5 * (z - mu) + d_zl ]   (d_zm / d_zl: the KL term's gradients; dz = dx[.., L:] + d_z)
+//   d_ctx (B, Tc, L) = dx[:, :Tc, :L] [* ctx_mask (B, Tc)]
+__global__ void __launch_bounds__(256) reparam_bwd_kernel(const float* __restrict__ dx, const float* __restrict__ z,
+                                                          const float* __restrict__ zm, const float* __restrict__ d_zm,
+                                                          const float* __restrict__ d_zl, const float* __restrict__ d_z,
+                                                          const float* __restrict__ ctx_mask, long B, int T, int Tc, int L,
+                                                          float* __restrict__ d_enc, float* __restrict__ d_ctx) {
+    const long n = B * T * L;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+        const int f = (int)(i % L);
+        const long bt = i / L;
+        const int t = (int)(bt % T);
+        const long b = bt / T;
+        float dz = dx[bt * 2 * L + L + f];
+        if (d_z) dz += d_z[i];
+        d_enc[bt * 2 * L + f] = d_zm ? dz + d_zm[i] : dz;
+        const float dl = dz * 0.5f * (z[i] - zm[i]);
+        d_enc[bt * 2 * L + L + f] = d_zl ? dl + d_zl[i] : dl;
+        if (t < Tc) {
+            const float g = dx[bt * 2 * L + f];
+            d_ctx[(b * Tc + t) * L + f] = ctx_mask ? g * ctx_mask[b * Tc + t] : g;
+        }
+    }
+}
+
+extern "C" int vsv_reparam_backward(const float* dx, const float* z, const float* zm, const float* d_zm, const float* d_zl,
+                                    const float* d_z, const float* ctx_mask, long B, int T, int Tc, int L,
+                                    float* d_enc, float* d_ctx, void* stream) {
+    if (!dx || !z || !zm || !d_enc || !d_ctx) { set_error("vsv_reparam_backward: null pointer"); return -1; }
+    if (B < 1 || T < 1 || Tc < 0 || Tc > T || L < 1) { set_error("vsv_reparam_backward: bad sizes"); return -1; }
+    const long n = B * T * L;
+    const unsigned blocks = (unsigned)((n + 255) / 256 > 1024 ? 1024 : (n + 255) / 256);
+    hipLaunchKernelGGL(reparam_bwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, dx, z, zm, d_zm, d_zl, d_z,
+                       ctx_mask, B, T, Tc, L, d_enc, d_ctx);
+    return launch_check("reparam_bwd_kernel");
 }
 
 extern "C" int vsv_loss_grad(const vsv_loss* d, void* stream) {

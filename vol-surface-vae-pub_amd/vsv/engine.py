@@ -217,6 +217,7 @@ class Engine:
         """Host packing through vsv_pack_weights (numpy state_dict)."""
         blob = pack_state_dict(self.dims, state_dict)
         self.packed = torch.from_numpy(blob).to(self.device)
+        self._fold_stale = False                               # (the host packer writes the folded section itself)
 
     def set_weights_from_params(self, named_params) -> torch.Tensor:
         """Device-side packing of live nn.Parameters: two gathers through the index
@@ -235,14 +236,23 @@ class Engine:
             fm = build_fold_maps(self.dims)
             self._fold = {k: torch.from_numpy(np.ascontiguousarray(v).astype(np.int64)).to(self.device)
                           for k, v in fm.items() if k not in ("fold_w", "fold_b")}
+        # (computed when a generation call first needs it -- Engine.decode --, not on every re-pack: a training
+        # step re-packs after each optimizer step and never reads the folded section)
+        self.packed = packed.detach()
+        self._fold_stale = True
+        return packed
+
+    def _ensure_fold(self) -> None:
+        """The folded (first ConvT) . (Linear) section of a blob packed from live parameters, on demand."""
+        if not getattr(self, "_fold_stale", False):
+            return
         f = self._fold
         with torch.no_grad():
+            packed = self.packed
             A, Bm = packed[f["a_w"]], packed[f["b_w"]]
-            packed = packed.clone()
             packed.index_copy_(0, f["f_w"].reshape(-1), (A @ Bm).reshape(-1))
             packed.index_copy_(0, f["f_b"], A @ packed[f["b_b"]] + packed[f["a_b"]])
-        self.packed = packed.detach()
-        return packed
+        self._fold_stale = False
 
     # -- helpers ---------------------------------------------------------
     def _stream(self):
@@ -463,6 +473,7 @@ class Engine:
         eps (n_rows,eps_T,L).  out_mode 0: surf (n_rows, T', Q, 5, 5); 1: (n_rows/S, T', Q*25, S);
         OUT_CHANNEL(c) = 2 + c: (n_rows/S, T', 25, S), decoder channel c only (the others are not computed).
         Returns dict(surf, ex, state, z, gates)."""
+        self._ensure_fold()
         din = _lib.VsvDecodeIn()
         if ctx is not None:
             ctx = _f32c(ctx, self.device)

@@ -72,6 +72,7 @@ class GraphedLossGrads:
             self.ex.copy_(ex, non_blocking=True)
         self.graph.replay()
         self.eng.packed = self.packed            # what the blob now holds: the parameters as of this replay
+        self.eng._fold_stale = True              # (generation's folded head section is rebuilt on demand)
         v = self.loss_vec.clone()
         losses = {"loss": v[0], "re_surface": v[1], "re_ex_feats": v[2], "reconstruction_loss": v[3], "kl_loss": v[4]}
         self.te.last_flat = self.flat

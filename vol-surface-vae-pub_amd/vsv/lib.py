@@ -184,6 +184,8 @@ SIGNATURES = {
     "vsv_percentile": (C.c_int, [C.c_void_p, C.c_long, C.c_int, C.POINTER(C.c_double), C.c_int,
                                  C.c_int, C.c_long, C.c_void_p, C.c_void_p]),
     "vsv_profile_next_decode": (None, [C.c_void_p, C.c_void_p]),
+    "vsv_reparam_backward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                       C.c_long, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
     "vsv_dropout_mask": (C.c_int, [C.c_float, C.c_uint64, C.c_int, C.c_int, C.c_long, C.c_int, C.c_int,
                                    C.c_void_p, C.c_void_p]),
     "vsv_train_encode": (C.c_int, [C.POINTER(VsvDims), C.c_void_p, C.c_int,

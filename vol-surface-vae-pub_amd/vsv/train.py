@@ -513,17 +513,14 @@ class TrainEngine:
             dx = self._e(B, T, 2 * L)
             dg = self._lstm_bwd(c, "d", lay["Hd"], NTd, sv_d, T, c.Cn, dh_top, 1, 2, dx_rows=dx, dx_f=2 * L)
             self._lstm_wgrads(c, gp, d["lstm"], sv_d, dg, T, NTd, sv_d["xe"])
-            # reparameterisation (:199) and the context embedding
-            dz = dx[..., L:]
-            if d_z is not None:
-                dz = dz + d_z.to(dev, torch.float32)
-            dzm_t = dz if d_zm is None else dz + d_zm
-            dzl_t = dz * 0.5 * (z - zm)
-            if d_zl is not None:
-                dzl_t = dzl_t + d_zl
-            d_ctx = dx[:, :Cn, :L].contiguous() if c.ctx_mask is None else dx[:, :Cn, :L] * c.ctx_mask
-
-            d_enc = torch.cat([dzm_t, dzl_t], dim=-1).contiguous()
+            # reparameterisation (:199) and the context embedding: one launch (vsv_reparam_backward)
+            d_enc, d_ctx = self._e(B, T, 2 * L), self._e(B, Cn, L)
+            f32 = lambda t: None if t is None else t.to(dev, torch.float32).contiguous()
+            d_zm, d_zl, d_z = f32(d_zm), f32(d_zl), f32(d_z)
+            mask = None if c.ctx_mask is None else c.ctx_mask.reshape(B, Cn).contiguous()
+            _lib.check(self.lib.vsv_reparam_backward(dx.data_ptr(), z.data_ptr(), zm.data_ptr(), _ptr(d_zm), _ptr(d_zl),
+                                                     _ptr(d_z), _ptr(mask), B, T, Cn, L, d_enc.data_ptr(),
+                                                     d_ctx.data_ptr(), self._stream()), "vsv_reparam_backward")
             side.wait_stream(main)
             with torch.cuda.stream(side):
                 ds_c = self._enc_bwd(c, gp, 1, c.sv_c, Cn, d_ctx, want_input_grad)
@@ -580,7 +577,7 @@ class TrainEngine:
             sums = torch.zeros(3, dtype=torch.float64, device=dev)
             la.sums = sums.data_ptr()
             _lib.check(lib.vsv_loss_grad(C.byref(la), st), "vsv_loss_grad")
-            re_s, re_e, kl = sums[0], sums[1], sums[2]
+            kl = sums[2]
             if extra_d_pred is not None:
                 d_pred = d_pred + extra_d_pred.to(dev, torch.float32).reshape(B, horizon, Q * 25)
             if kl_fn is not None:
@@ -588,9 +585,17 @@ class TrainEngine:
                 kl = kl.to(torch.float64)
                 d_zm = d_zm + g_zm
                 d_zl = d_zl + g_zl
-            recon = re_s + loss_cfg["ex_weight"] * re_e if X > 0 else re_s
-            losses = {"loss": recon + klw * kl, "re_surface": re_s, "re_ex_feats": re_e,
-                      "reconstruction_loss": recon, "kl_loss": kl}
+            # loss = re_surface + ex_weight * re_ex_feats + kl_weight * kl etc. as ONE small matrix-vector product
+            exw = float(loss_cfg["ex_weight"]) if X > 0 else 0.0
+            key = (exw, klw)
+            M = self.__dict__.setdefault("_loss_mix", {}).get(key)
+            if M is None:
+                M = self._loss_mix[key] = torch.tensor([[1.0, exw, klw], [1.0, 0.0, 0.0], [0.0, 1.0, 0.0],
+                                                        [1.0, exw, 0.0], [0.0, 0.0, 1.0]], dtype=torch.float64, device=dev)
+            if kl_fn is not None:
+                sums = torch.stack([sums[0], sums[1], kl])
+            v = torch.mv(M, sums)
+            losses = {"loss": v[0], "re_surface": v[1], "re_ex_feats": v[2], "reconstruction_loss": v[3], "kl_loss": v[4]}
             if not want_grads:
                 return losses, None, outputs
             gp = self.backward_saved(c, d_pred, d_ex, d_zm, d_zl, None, want_input_grad)

@@ -118,7 +118,13 @@ def train_bench(dev, steps: int, cpu_steps: int):
     batches = [{"surface": torch.from_numpy((0.2 + 0.1 * rng.standard_normal((B, int(T), 5, 5))).astype(np.float32)).to(dev),
                 "ex_feats": torch.from_numpy((0.01 * rng.standard_normal((B, int(T), 3))).astype(np.float32)).to(dev)}
                for T in lens]
-    for b in batches[:3]:
+    # default path: forward + loss + backward + scatter replayed as one HIP graph per sequence length
+    # (vsv/graphed.py).  Untimed first: one step per length, so every graph is captured.
+    warm = {int(b["surface"].shape[1]): b for b in batches}
+    for T in range(2, 22):
+        if T not in warm:
+            warm[T] = {"surface": torch.full((B, T, 5, 5), 0.2, device=dev), "ex_feats": torch.zeros((B, T, 3), device=dev)}
+    for b in list(warm.values()) + batches[:3]:
         model.train_step(b, opt)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -128,27 +134,23 @@ def train_bench(dev, steps: int, cpu_steps: int):
     dt = time.perf_counter() - t0
     out = {"metric": "train samples/s", "value": B * steps / dt, "unit": "samples/s", "ms_per_step": dt / steps * 1e3,
            "config": {"workload": "BASELINE configs[1]: CVAEMemRand ex_loss train_step, batch 64, T ~ U[2,21], "
-                                  "horizon 1, AdamW(1e-5), clip 1.0, dropout 0", "steps": steps}}
-    # the same steps with forward+loss+backward replayed as one HIP graph per sequence length (opt-in,
-    # config hip_graphs; vsv/graphed.py).  Untimed first: one step per length, so every graph is captured.
+                                  "horizon 1, AdamW(1e-5), clip 1.0, dropout 0", "steps": steps,
+                      "hip_graphs": bool(model._use_graphs())}}
+    # the same steps launched eagerly (config hip_graphs = False)
     try:
-        model.config["hip_graphs"] = True
-        warm = {int(b["surface"].shape[1]): b for b in batches}
-        for T in range(2, 22):
-            if T not in warm:
-                warm[T] = {"surface": torch.full((B, T, 5, 5), 0.2, device=dev), "ex_feats": torch.zeros((B, T, 3), device=dev)}
-        for b in list(warm.values()) + batches[:3]:
+        model.config["hip_graphs"] = False
+        for b in batches[:3]:
             model.train_step(b, opt)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for b in batches[3:]:
             model.train_step(b, opt)
         torch.cuda.synchronize()
-        out["ms_per_step_hip_graph"] = (time.perf_counter() - t0) / steps * 1e3
-    except Exception as exc:                       # the opt-in leg must not cost the bench line
-        out["ms_per_step_hip_graph"] = None
-        out["hip_graph_error"] = repr(exc)[:200]
-    model.config["hip_graphs"] = False
+        out["ms_per_step_eager"] = (time.perf_counter() - t0) / steps * 1e3
+    except Exception as exc:                       # the comparison leg must not cost the bench line
+        out["ms_per_step_eager"] = None
+        out["eager_error"] = repr(exc)[:200]
+    model.config["hip_graphs"] = True
     # BASELINE configs[2]: multi-horizon [1, 7, 14, 30] quantile training, context 20 (sequence 50), batch 64:
     # four forward/backward passes and one optimizer step per call (train_step_multihorizon)
     try:

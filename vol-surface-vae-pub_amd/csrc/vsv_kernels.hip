@@ -1198,6 +1198,157 @@ lstm_kernel(const LstmSeqArgs a) {
     }
 }
 
+// ---------------------------------------------------------------------------
+// lstm_rec_kernel: ONE memory layer whose gate pre-activations b + W_ih . x are given for every step (per-calendar-
+// day table pre_t, per-instance pre_g, or -- training, SAVE -- the layer's slots of sv_gates), for few row tiles
+// (<= 256): one wave per gate tile, NT waves per 32-row workgroup.  Only W_hh . h is on the time loop, and the
+// wave's W_hh fragments (NT quads = 4*NT registers) stay in REGISTERS for all T steps: a step streams nothing from
+// L2 and is bound by the CU's matrix pipe (NT*NT quads of four products over four SIMDs) plus one barrier -- h is
+// double-buffered in LDS, so a step's writers need not wait for the previous step's readers.
+// Same products in the same order as lstm_kernel's per-layer launches: results are bit-equal.
+// ---------------------------------------------------------------------------
+template <int NT, bool SAVE>
+__global__ void __launch_bounds__(64 * NT, (NT + 3) / 4) lstm_rec_kernel(const LstmSeqArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    constexpr int HPK = 4 * NT, HP = 8 * NT;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const long rowtile = (long)blockIdx.x;
+    const int hh = lane >> 5, m = lane & 31;
+    const long row_raw = rowtile * 32 + m;
+    const bool row_ok = row_raw < a.n_rows;
+    const long row = row_ok ? row_raw : a.n_rows - 1;
+    const uint32_t row32 = (uint32_t)row;
+    const int SL = (SAVE && a.sv_nl > 0) ? a.sv_nl : 1;           // layers per instance in the saved arrays
+    const int L0 = (SAVE && a.sv_nl > 0) ? a.sv_l0 : 0;           // the model's layer this launch runs
+    const int SNL = a.st_nl > 0 ? a.st_nl : 1;                    // layers per row in the state arrays
+    const bool dropping = SAVE && L0 + 1 < SL && a.drop.p > 0.0f;
+    const DropArgs drop = dropping ? resolve_drop(a.drop) : a.drop;
+    // (offsets into smem, not an array of two pointers: selecting a pointer at run time loses the LDS address
+    // space and every h read becomes a flat load with full waits)
+    float* const hbase = smem + lane;
+    const int nq_in = a.kx >> 2;
+
+    // recurrent fragments of this wave's gate tile
+    float4 wreg[NT];
+    {
+        const float4* w = (const float4*)a.w[0] + (size_t)nq_in * NT * 64 + wave * 64 + lane;
+#pragma unroll
+        for (int q = 0; q < NT; ++q) wreg[q] = w[(size_t)q * NT * 64];
+    }
+    auto load_pre = [&](f32x16& acc, int t) {
+        if (!SAVE && a.pre_t) {
+            // (a running pointer: sixteen 64-bit addresses at once do not fit beside the resident weights)
+            const float* p = a.pre_t + ((size_t)hh + (size_t)(32 * wave)) * a.pre_stride + row32 + (size_t)t * a.pre_tstride;
+            const size_t step = 2 * (size_t)a.pre_stride;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                acc[r] = *p;
+                p += step;
+                asm volatile("" : "+v"(p));
+            }
+        } else {
+            const float* p = SAVE ? a.sv_gates + ((size_t)(rowtile * a.T + t) * SL + L0) * (16 * NT) * 64 + lane
+                                  : a.pre_g + (size_t)(rowtile * a.T + t) * (16 * NT) * 64 + lane;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] = p[(16 * wave + r) * 64];
+        }
+    };
+    f32x16 acc[1];
+    load_pre(acc[0], 0);
+
+    // state: (h | c), position 8*tile + 4*hh + jj holds unit 8*tile + 2*jj + hh
+    float c[1][4];
+    const bool has_state = a.din.state_in != nullptr;              // wave-uniform
+    {
+        float4 hv = make_float4(0.0f, 0.0f, 0.0f, 0.0f), cv = hv;
+        if (has_state) {
+            const uint32_t srow = a.din.state_div == 1 ? row32 : row32 / (uint32_t)a.din.state_div;
+            const float* ps = a.din.state_in + ((size_t)srow * SNL + a.st_l0) * 2 * HP + 8 * wave + 4 * hh;
+            hv = *(const float4*)ps;
+            cv = *(const float4*)(ps + HP);
+        }
+        const float hq[4] = {hv.x, hv.y, hv.z, hv.w};
+        const float cq[4] = {cv.x, cv.y, cv.z, cv.w};
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) {
+            hbase[(4 * wave + jj) * 64] = hq[jj];
+            c[0][jj] = cq[jj];
+        }
+    }
+    __syncthreads();
+    const int t_outs = a.T - a.t_out0;
+    for (int t = 0; t < a.T; ++t) {
+        const float* hr = hbase + (t & 1) * (HPK * 64);
+        float* hw = hbase + ((t + 1) & 1) * (HPK * 64);
+        if (t > 0 || has_state) {                                  // (h = 0 at the first step of a fresh sequence)
+#pragma unroll
+            for (int q = 0; q < NT; ++q) {
+                const float b0 = hr[(4 * q + 0) * 64], b1 = hr[(4 * q + 1) * 64], b2 = hr[(4 * q + 2) * 64],
+                            b3 = hr[(4 * q + 3) * 64];
+                acc[0] = mfma32(wreg[q].x, b0, acc[0]);
+                acc[0] = mfma32(wreg[q].y, b1, acc[0]);
+                acc[0] = mfma32(wreg[q].z, b2, acc[0]);
+                acc[0] = mfma32(wreg[q].w, b3, acc[0]);
+            }
+        }
+        float hn[1][4];
+        lstm_cell<SAVE, 1>(acc, c, hn, a.gru != 0);
+        if (SAVE) {
+            const size_t il = (size_t)(rowtile * a.T + t) * SL + L0;
+            float* sg = a.sv_gates + il * (16 * NT) * 64 + lane;
+            float* sc = a.sv_c + il * HPK * 64 + lane;
+            float* sh = a.sv_h + il * HPK * 64 + lane;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) sg[(16 * wave + r) * 64] = acc[0][r];
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) {
+                sc[(4 * wave + jj) * 64] = c[0][jj];
+                sh[(4 * wave + jj) * 64] = hn[0][jj];
+            }
+            if (dropping) {
+                float fct[4];
+                dropout_factors(drop, row32, (uint32_t)t, wave, hh, L0, fct);
+                float* sd = a.sv_hd + (size_t)(rowtile * a.T + t) * HPK * 64 + lane;
+#pragma unroll
+                for (int jj = 0; jj < 4; ++jj) sd[(4 * wave + jj) * 64] = hn[0][jj] * fct[jj];
+            }
+        }
+        if (a.hout && t >= a.t_out0) {
+            float* ho = a.hout + ((size_t)(rowtile * t_outs + (t - a.t_out0)) * HPK) * 64 + lane;
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) ho[(4 * wave + jj) * 64] = hn[0][jj];
+        }
+        if (t + 1 < a.T) load_pre(acc[0], t + 1);                  // lands while the waves meet
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) hw[(4 * wave + jj) * 64] = hn[0][jj];
+        __syncthreads();                                           // h(t) published (the other buffer is free again)
+    }
+    const float* hf = hbase + (a.T & 1) * (HPK * 64);
+    if (a.state_out && row_ok) {
+        float* st = a.state_out + ((size_t)row_raw * SNL + a.st_l0) * 2 * HP + 8 * wave + 4 * hh;
+        *(float4*)st = make_float4(hf[(4 * wave + 0) * 64], hf[(4 * wave + 1) * 64], hf[(4 * wave + 2) * 64], hf[(4 * wave + 3) * 64]);
+        *(float4*)(st + HP) = make_float4(c[0][0], c[0][1], c[0][2], c[0][3]);
+    }
+    if (a.din.gate_out) {
+        // bias + W_hh . h_final: the part of the next step's gates shared by all rows continuing from this state
+        const int toff1[1] = {wave * 64};
+        f32x16 g[1];
+        load_bias<1>(g, a.b[0], toff1, hh);
+#pragma unroll
+        for (int q = 0; q < NT; ++q) {
+            g[0] = mfma32(wreg[q].x, hf[(4 * q + 0) * 64], g[0]);
+            g[0] = mfma32(wreg[q].y, hf[(4 * q + 1) * 64], g[0]);
+            g[0] = mfma32(wreg[q].z, hf[(4 * q + 2) * 64], g[0]);
+            g[0] = mfma32(wreg[q].w, hf[(4 * q + 3) * 64], g[0]);
+        }
+        if (row_ok) {
+            float4* p = (float4*)(a.din.gate_out + (((size_t)row_raw * SNL + a.st_l0) * NT + wave) * 32 + hh * 16);
+#pragma unroll
+            for (int v = 0; v < 4; ++v) p[v] = make_float4(g[0][4 * v + 0], g[0][4 * v + 1], g[0][4 * v + 2], g[0][4 * v + 3]);
+        }
+    }
+}
+
 // layer[li] of the decoder head (LstmSeqArgs::head, part of the by-value kernel argument) for a run-time li,
 // read from the kernarg segment by scalar loads: indexing the by-value copy itself would put it in scratch.
 // The struct is the kernel's only explicit argument, so it sits at offset 0 of the segment.
@@ -2150,9 +2301,33 @@ static int launch_lstm_nt(const LstmSeqArgs& a, int NL, bool head, hipStream_t s
     return NL == 2 ? launch_lstm_t<NT, 2, XMODE, false>(a, st) : launch_lstm_t<NT, 1, XMODE, false>(a, st);
 }
 
+template <int NT, bool SAVE>
+static int launch_lstm_rec(const LstmSeqArgs& a, hipStream_t st) {
+    const size_t lds = (size_t)2 * 4 * NT * 64 * sizeof(float);
+    int rc = set_lds(lstm_rec_kernel<NT, SAVE>, lds);
+    if (rc) return rc;
+    hipLaunchKernelGGL((lstm_rec_kernel<NT, SAVE>), dim3((unsigned)a.n_rowtiles), dim3(64 * NT), lds, st, a);
+    return launch_check("lstm_rec_kernel");
+}
+
+// the recurrent-only single-layer launches (pre-activations given) of few row tiles: weights in registers
+static bool lstm_rec_applies(const LstmSeqArgs& a, int NL) {
+    static const bool off = [] { const char* e = getenv("VSV_LSTM_REC"); return e && e[0] == '0'; }();
+    if (off || NL != 1 || a.n_rowtiles > kWideMaxRowtiles || a.din.gate_in) return false;
+    if (a.sv_gates) return a.rec != 0 && (a.st_nl == 0);
+    // inference (pre_t / pre_g): measured slower than lstm_kernel's per-layer launch on the date-range prefix
+    // (2.8 vs 2.1 ms at 500 days), so it is opt-in there (VSV_LSTM_REC=2)
+    static const bool infer = [] { const char* e = getenv("VSV_LSTM_REC"); return e && e[0] == '2'; }();
+    return infer && (a.pre_t != nullptr || a.pre_g != nullptr);
+}
+
 template <int XMODE>
 static int launch_lstm(const LstmSeqArgs& a, int NT, int NL, bool head, hipStream_t st) {
     if (a.n_rowtiles <= 0 || a.T <= 0) return 0;
+    if (XMODE == 0 && !head && lstm_rec_applies(a, NL)) {
+        if (NT == 13) return a.sv_gates ? launch_lstm_rec<13, true>(a, st) : launch_lstm_rec<13, false>(a, st);
+        if (NT == 16) return a.sv_gates ? launch_lstm_rec<16, true>(a, st) : launch_lstm_rec<16, false>(a, st);
+    }
     switch (NT) {
         case 13: return launch_lstm_nt<13, XMODE>(a, NL, head, st);
         case 16: return launch_lstm_nt<16, XMODE>(a, NL, head, st);

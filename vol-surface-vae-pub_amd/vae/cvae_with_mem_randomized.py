@@ -593,13 +593,17 @@ class CVAEMemRand(BaseVAE):
         return losses, gp
 
     def _use_graphs(self) -> bool:
-        """HIP-graph replay of the training step: opt-in (config["hip_graphs"] = True or VSV_GRAPHS=1).  A step
-        is bound by the GPU (the recurrent launches on two CUs), not by the host's launch rate: on the MI355X
-        box eager launches and graph replay measure the same within 1 % (bench.py "train":
-        ms_per_step vs ms_per_step_hip_graph), so eager is the default and the graph is for hosts that cannot
-        keep up."""
+        """HIP-graph replay of the training step (vsv/graphed.py: weight packing, noise, forward, loss, backward
+        and the gradient scatter as ONE graph per input shape): on by default, config["hip_graphs"] = False or
+        VSV_GRAPHS=0 runs the same launches eagerly.  Eager, a step costs the host 1.65 ms of launch path whatever
+        the sequence length, more than the kernels take below T = 10; replayed, the step is bound by the GPU alone
+        (bench.py "train": ms_per_step vs ms_per_step_eager).  A new (batch, length) shape is captured on first
+        use (tens of ms)."""
         import os
-        return bool(self.config.get("hip_graphs", False)) or os.environ.get("VSV_GRAPHS", "0") == "1"
+        env = os.environ.get("VSV_GRAPHS")
+        if env is not None:
+            return env == "1"
+        return bool(self.config.get("hip_graphs", True))
 
     def _accumulate_grads(self, gp, weight=1.0, alias=False):
         """Add weight * gradient to .grad of the parameters.  gp: gradient w.r.t. the packed blob (eager path)

@@ -65,17 +65,21 @@ def _context_prefix(eng: Engine, sv: torch.Tensor, se: Optional[torch.Tensor], n
     into time segments whose stages overlap on several streams, the memory states handed from segment to
     segment.  Two schedules (same products in the same order, bit-equal results):
       * fused stacks, three streams (posterior encoder, context encoder, decoder), three segments;
-      * up to 2048 days (two-layer memories): every stack also split into its two layers -- layer 1's input
+      * opt-in, VSV_PREFIX_LAYERS=1 (two-layer memories): every stack also split into its two layers -- layer 1's input
         product b + W_ih . h0 leaves the time loop for one launch over all steps -- with the decoder's two
         layers on streams of their own (four worker streams = HIP's default number of hardware queues), all
         launches issued by the native vsv_context_prefix.  Measured prefix latency, context 60: 2.11 / 2.21 /
-        2.47 ms at 500 / 1000 / 2000 days against 2.40 / 2.56 / 2.59 ms fused; beyond that the CUs are
-        saturated and the extra launches cost more than the overlap gains (4000 days: 3.4 vs 3.06 ms).
+        2.47 ms at 500 / 1000 / 2000 days against 2.40 / 2.56 / 2.59 ms fused when no two busy streams share a
+        hardware queue, 3.2 ms at 500 days when they do; beyond 2000 days the CUs are saturated and the extra
+        launches cost more than the overlap gains (4000 days: 3.4 vs 3.06 ms).
     VSV_PREFIX_SEGMENTS overrides the segment count (1 = one fused launch per stack); VSV_PREFIX_LAYERS = 0 /
     1 / py forces the fused / split / split-driven-from-Python schedule, VSV_PREFIX_STREAMS = 3 / 4 / 6."""
     L = eng.L
     mode = os.environ.get("VSV_PREFIX_LAYERS", "")
-    split = eng.dims.mem_layers == 2 and (mode in ("1", "py") or (mode == "" and n_days <= 2048))
+    # (opt-in: with HIP's default of four hardware queues the worker streams may share a queue with each other
+    # or with the caller's stream, and the pipeline then serialises -- 2.1 or 3.2 ms at 500 days from one
+    # process to the next; the fused three-stream schedule measures 2.5 ms every time)
+    split = eng.dims.mem_layers == 2 and mode in ("1", "py")
     if n_seg is None:
         n_seg = int(os.environ.get("VSV_PREFIX_SEGMENTS", "0")) or (4 if split else 3)
     if n_seg <= 1 or n_days > eng.MAX_WINDOWS or ctx_len < 4 * n_seg:

@@ -1696,6 +1696,77 @@ __global__ void __launch_bounds__(256, 2) dense_bwd_kernel(const DenseBwdArgs a)
     }
 }
 
+// dense_bwd_wg_kernel: the same chain with one WORKGROUP per instance, for few instances (a training batch of 64
+// at horizon 1 is two instances of the decoder head: one wave each walked five layers alone, 128 us).  The column
+// is shared in LDS; wave w handles slots 16w .. 16w+15 in the element-wise phase and output tile w of W^T . g.
+// The per-tile product chains are those of dense_bwd_kernel: results are bit-equal.
+__global__ void __launch_bounds__(256) dense_bwd_wg_kernel(const DenseBwdArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const long inst = (long)blockIdx.x;
+    const long rowtile = inst / a.T;
+    const int t = (int)(inst % a.T);
+    const int hh = lane >> 5, m = lane & 31;
+    long row = rowtile * 32 + m;
+    const bool row_ok = row < a.n_rows;
+    if (!row_ok) row = a.n_rows - 1;
+    float* col = smem + lane;
+    const int s_lo = 16 * wave;
+    if (a.in_mode == 0) {
+        const float* src = a.in + ((size_t)row * a.T + t) * a.in_f;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            const int f = feat_of(wave, k, hh);
+            col[(s_lo + k) * 64] = (row_ok && f < a.in_f) ? src[f] : 0.0f;
+        }
+    } else {
+        const float* src = a.in + (size_t)inst * kDenseSlots * 64 + lane;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) col[(s_lo + k) * 64] = row_ok ? src[(s_lo + k) * 64] : 0.0f;
+    }
+#pragma unroll 1
+    for (int li = 0; li < a.n_layers; ++li) {
+        const DenseBwdLayer& ly = a.layer[li];
+        const float* act = ly.act_out ? ly.act_out + (size_t)inst * kDenseSlots * 64 + lane : nullptr;
+        const float* add = (ly.add && row_ok) ? ly.add + ((size_t)row * a.T + t) * ly.add_n - ly.add_f0 : nullptr;
+        float* go = ly.g_out ? ly.g_out + (size_t)inst * kDenseSlots * 64 + lane : nullptr;
+        {
+            // this wave's sixteen slots (it wrote them itself: no barrier needed before)
+            float av[16];
+#pragma unroll
+            for (int k = 0; k < 16; ++k) av[k] = act ? act[(s_lo + k) * 64] : 1.0f;
+#pragma unroll
+            for (int k = 0; k < 16; ++k) {
+                const int s = s_lo + k;
+                const int f = feat_of(wave, k, hh);
+                float g = col[s * 64];
+                if (add && f >= ly.add_f0 && f < ly.add_f0 + ly.add_n) g += add[f];
+                if (act && f < ly.n_relu && !(av[k] > 0.0f)) g = 0.0f;
+                col[s * 64] = g;
+                if (go) go[s * 64] = g;
+            }
+        }
+        if (ly.ntT > 0) {                                          // (block-uniform)
+            __syncthreads();                                       // g complete
+            f32x16 acc[1];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[0][r] = 0.0f;
+            if (wave < ly.ntT) {
+                const int toff1[1] = {wave * 64};
+                gemm_seg_deep<1>(acc, (const float4*)ly.wT, lane, toff1, ly.ntT * 64, col, ly.nqT);
+            }
+            __syncthreads();                                       // every wave has read g
+#pragma unroll
+            for (int r = 0; r < 16; ++r) col[(s_lo + r) * 64] = acc[0][r];        // (tiles >= ntT: zeros)
+        }
+    }
+    if (a.dx_out) {
+        float* o = a.dx_out + (size_t)inst * kDenseSlots * 64 + lane;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) o[(s_lo + k) * 64] = col[(s_lo + k) * 64];
+    }
+}
+
 // ---------------------------------------------------------------------------
 // lstm_bwd_kernel: BPTT of a 1- or 2-layer LSTM for a tile of 32 rows per
 // workgroup (4 waves).  Wave w owns the hidden units of gate tiles w, w+4, ...,
@@ -3471,6 +3542,13 @@ extern "C" int vsv_dense_backward(const vsv_dense_bwd* d, void* stream) {
     const long insts = d->n_rowtiles * d->T;
     const long blocks = (insts + 3) / 4;
     if (blocks > 0x7fffffffL) { set_error("vsv_dense_backward: too many tiles"); return -2; }
+    static const bool wg_off = [] { const char* e = getenv("VSV_DENSE_BWD_WG"); return e && e[0] == '0'; }();
+    if (insts <= 1024 && !wg_off) {
+        // few instances: a workgroup per instance, its four waves splitting slots and output tiles
+        const size_t lds1 = (size_t)kDenseSlots * 64 * sizeof(float);
+        hipLaunchKernelGGL(dense_bwd_wg_kernel, dim3((unsigned)insts), dim3(256), lds1, (hipStream_t)stream, *d);
+        return launch_check("dense_bwd_wg_kernel");
+    }
     const size_t lds = (size_t)4 * kDenseSlots * 64 * sizeof(float);
     hipLaunchKernelGGL(dense_bwd_kernel, dim3((unsigned)blocks), dim3(256), lds, (hipStream_t)stream, *d);
     return launch_check("dense_bwd_kernel");

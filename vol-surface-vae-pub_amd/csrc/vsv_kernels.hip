@@ -559,6 +559,91 @@ __global__ void __launch_bounds__(256, 2) dense_chain_kernel(const DenseChainArg
     }
 }
 
+// dense_chain_wg_kernel: the same chain with one WORKGROUP per instance, for few instances (the decoder head of a
+// training batch of 64 at horizon 1 is two instances; the latent heads and small date ranges likewise): wave w
+// computes output tile w of every layer from the column shared in LDS.  Per-tile product chains as in
+// dense_chain_kernel: results are bit-equal.
+__global__ void __launch_bounds__(256) dense_chain_wg_kernel(const DenseChainArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const long inst = (long)blockIdx.x;
+    const long rowtile = inst / a.T;
+    const int t = (int)(inst % a.T);
+    const int hh = lane >> 5, m = lane & 31;
+    long row = rowtile * 32 + m;
+    const bool row_ok = row < a.n_rows;
+    if (!row_ok) row = a.n_rows - 1;
+    float* col = smem + lane;
+    const int s_lo = 16 * wave;
+    if (a.in_mode == 0) {
+        const float* src = a.in + row * a.in_rs + (long)t * a.in_ts;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            const int sl = s_lo + k, f = 2 * sl + hh;
+            col[sl * 64] = (sl < a.in_ks && f < a.in_f) ? src[f] : 0.0f;
+        }
+    } else {
+        const float* src = a.in + (size_t)inst * a.in_ks * 64 + lane;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) col[(s_lo + k) * 64] = (s_lo + k < a.in_ks) ? src[(s_lo + k) * 64] : 0.0f;
+    }
+    __syncthreads();
+#pragma unroll 1
+    for (int li = 0; li < a.n_layers; ++li) {
+        if (a.save) {
+            float* sv = a.save + ((size_t)li * (a.n_rowtiles * a.T) + inst) * kDenseSlots * 64 + lane;
+#pragma unroll
+            for (int k = 0; k < 16; ++k) sv[(s_lo + k) * 64] = col[(s_lo + k) * 64];
+        }
+        const DenseLayerArg ly = chain_layer_of_kernarg(li);
+        const bool last = (li == a.n_layers - 1);
+        const bool mine = wave < ly.nt;
+        f32x16 acc[1];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[0][r] = 0.0f;
+        if (mine) {
+            const int toff1[1] = {wave * 64};
+            load_bias<1>(acc, ly.b, toff1, hh);
+            gemm_seg<1>(acc, (const float4*)ly.w, lane, toff1, ly.nt * 64, col, ly.nq);
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                acc[0][r] = (feat_of(wave, r, hh) < ly.n_relu) ? fmaxf(acc[0][r], 0.0f) : acc[0][r];
+            // injection / aux features live in the layer's LAST tile
+            RowIo io = {nullptr, 1, nullptr, nullptr};
+            if ((last && a.out_mode != 0) || (li == a.inj_layer && a.inj != nullptr) || li == a.aux_layer)
+                io = make_rowio(a, row, row_ok, t);
+            const bool do_inj = (li == a.inj_layer) && io.inj != nullptr, do_aux = (li == a.aux_layer) && io.aux != nullptr;
+            if ((do_inj || do_aux) && wave == ly.nt - 1) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int f = feat_of(wave, r, hh);
+                    if (do_inj && f >= a.inj_f0 && f < a.inj_f0 + a.inj_n) acc[0][r] = io.inj[f];
+                    if (do_aux && f >= a.aux_f0 && f < a.aux_f0 + a.aux_n) io.aux[f] = acc[0][r];
+                }
+            }
+            if (last) {
+                if (a.out_mode == 0) {
+                    float* o = a.out + ((size_t)inst * (16 * ly.nt)) * 64 + lane;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) o[(s_lo + r) * 64] = acc[0][r];
+                } else if (io.out) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int f = feat_of(wave, r, hh);
+                        if (f < a.out_f) io.out[(size_t)f * io.fstride] = acc[0][r];
+                    }
+                }
+            }
+        }
+        if (!last) {
+            __syncthreads();                                       // every wave has read this layer's input
+#pragma unroll
+            for (int r = 0; r < 16; ++r) col[(s_lo + r) * 64] = acc[0][r];        // (tiles >= nt: zeros)
+            __syncthreads();
+        }
+    }
+}
+
 // ---------------------------------------------------------------------------
 // lstm_kernel: a 1- or 2-layer LSTM walked over T steps for a tile of 32 rows
 // per workgroup, with (XMODE 0) the x part read from a tile-B tensor written by
@@ -2338,6 +2423,13 @@ static int launch_dense_chain(const DenseChainArgs& a, hipStream_t st) {
     const size_t lds = (size_t)4 * kDenseSlots * 64 * sizeof(float);
     const long blocks = (insts + 3) / 4;
     if (blocks > 0x7fffffffL) { set_error("dense_chain: too many tiles"); return -2; }
+    static const bool wg_off = [] { const char* e = getenv("VSV_DENSE_WG"); return e && e[0] == '0'; }();
+    if (insts <= 512 && !wg_off) {
+        // few instances: a workgroup per instance, its four waves splitting the output tiles
+        const size_t lds1 = (size_t)kDenseSlots * 64 * sizeof(float);
+        hipLaunchKernelGGL(dense_chain_wg_kernel, dim3((unsigned)insts), dim3(256), lds1, st, a);
+        return launch_check("dense_chain_wg_kernel");
+    }
     hipLaunchKernelGGL(dense_chain_kernel, dim3((unsigned)blocks), dim3(256), lds, st, a);
     return launch_check("dense_chain_kernel");
 }

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define VSV_ABI_VERSION 16
+#define VSV_ABI_VERSION 17
 #define VSV_MAX_CONV 4
 #define VSV_MAX_CHAIN 8
 #define VSV_MAX_INTERACT 3
@@ -52,6 +52,10 @@ typedef struct vsv_dims {
     int n_quantiles;                   /* Q = len(config["quantiles"])       */
     int interaction_layers;            /* config["interaction_layers"] or 0: n Linear+ReLU + 1 Linear, width kept */
     int mem_type;                      /* config["mem_type"]: 0 "lstm" (nn.LSTM), 1 "gru" (nn.GRU), :154-159 */
+    int compress_context;              /* config["compress_context"]: 1 = the context encoder ends in Linear(mem_hidden
+                                          -> latent_dim) (:363-366); 0 = its embedding is the memory's output itself
+                                          (mem_hidden wide: the class default, :1014-1015) and the decoder memory reads
+                                          [ctx (mem_hidden) | z (latent_dim)] */
 } vsv_dims;
 
 /* Raw parameters in PyTorch state_dict layout (HOST pointers, float32,
@@ -460,11 +464,12 @@ int vsv_loss_grad(const vsv_loss *d, void *stream);
 /* Backward of the reparameterisation z = mu + exp(0.5 logvar) * eps (:199) and of the decoder-input cat (:1066),
  * the autograd steps between the decoder's and the encoders' backward passes: from dx (B, T, 2L) = gradient
  * w.r.t. [ctx_pad | z],
- *   d_enc (B, T, 2L) = [ dz + d_zm | dz * 0.5 * (z - mu) + d_zl ]  with dz = dx[.., L:] (+ d_z),
- *   d_ctx (B, Tc, L) = dx[:, :Tc, :L] (* ctx_mask (B, Tc), the per-row context lengths of multi-horizon training).
+ *   d_enc (B, T, 2L) = [ dz + d_zm | dz * 0.5 * (z - mu) + d_zl ]  with dz = dx[.., Lc:] (+ d_z),
+ *   d_ctx (B, Tc, Lc) = dx[:, :Tc, :Lc] (* ctx_mask (B, Tc), the per-row context lengths of multi-horizon training).
+ * dx rows are [ctx part (Lc = context-embedding width) | z part (L)].
  * d_zm / d_zl (the KL term's gradients), d_z and ctx_mask may be NULL. */
 int vsv_reparam_backward(const float *dx, const float *z, const float *zm, const float *d_zm, const float *d_zl,
-                         const float *d_z, const float *ctx_mask, long B, int T, int Tc, int L,
+                         const float *d_z, const float *ctx_mask, long B, int T, int Tc, int L, int Lc,
                          float *d_enc, float *d_ctx, void *stream);
 
 /* The dropout factors (0 or 1/(1-p)) the training kernels apply to layer `layer`'s output of

@@ -476,6 +476,28 @@ def main_gru():
     case_cprior_train("g8_cprior_train_gru_ex5_B4_T24_h3", ex5, 80, 2.0, 4, 24, 3, [1, 7])
 
 
+def main_nocompress():
+    """compress_context=False, the class default (:1014-1015): the context encoder's final_compression is
+    nn.Identity() (:225-228), the decoder memory takes [context memory state (mem_hidden) | z] (:363-366) and the
+    prior network's heads read its memory state (conditional_prior_network.py:73-78)."""
+    f32, f64 = np.float32, np.float64
+    ex5 = vo.make_config(5, 3, compress_context=False)
+    noex = vo.make_config(5, 0, compress_context=False)
+    ex12 = vo.make_config(12, 3, compress_context=False, quantile_loss_weights=[5.0, 1.0, 5.0], kl_weight=1e-3)
+    gru = vo.make_config(5, 3, compress_context=False, mem_type="gru", interaction_layers=1)
+    case_forward("g1_fwd_nocomp_ex5_T21_h1_f32", ex5, 90, 2.0, f32, 4, 21, 1)
+    case_forward("g1_fwd_nocomp_noex_T9_h3_f64", noex, 91, 2.0, f64, 3, 9, 3)
+    case_forward("g1_fwd_nocomp_gru_int1_T12_h2_f32", gru, 92, 2.0, f32, 3, 12, 2)
+    case_prior("g2_prior_nocomp_ex12_C20_H7_f32", ex12, 93, 2.0, f32, 6, 20, 7)
+    case_prior("g2_prior_nocomp_noex_C5_H1_f64", noex, 94, 2.0, f64, 8, 5, 1)
+    case_grads("g4_grads_nocomp_ex5_B6_T21_h3", ex5, 95, 2.0, 6, 21, 3, full=False)
+    case_grads("g4_grads_nocomp_ex12_B4_T20_h7", ex12, 96, 2.0, 4, 20, 7, full=False)
+    case_grads("g4_grads_nocomp_gru_int1_B5_T9_h2", gru, 97, 2.0, 5, 9, 2, full=False)
+    case_ar("g6_ar_nocomp_ex5_C20_H30", ex5, 98, 2.0, 4, 20, 30)
+    case_cprior_gen("g8_cprior_gen_nocomp_ex5_C20_H7_f32", ex5, 99, 2.0, f32, 4, 20, 7, True, 0.3)
+    case_cprior_train("g8_cprior_train_nocomp_ex5_B4_T24_h3", ex5, 100, 2.0, 4, 24, 3, [1, 7])
+
+
 def main_cprior():
     f32, f64 = np.float32, np.float64
     ex5 = vo.make_config(5, 3)
@@ -515,6 +537,7 @@ def save(name, cfg, d):
     d["cfg_mem_layers"] = cfg["mem_layers"]
     d["cfg_interaction_layers"] = int(cfg.get("interaction_layers") or 0)
     d["cfg_mem_type"] = np.asarray(cfg.get("mem_type", "lstm"))
+    d["cfg_compress_context"] = np.asarray(bool(cfg.get("compress_context", False)))
     d["cfg_quantile_loss_weights"] = np.asarray(cfg.get("quantile_loss_weights") or [1.0, 1.0, 1.0])
     for k in ("ex_loss_on_ret_only", "ex_feats_loss_type", "kl_weight", "re_feat_weight"):
         d["cfg_" + k] = np.asarray(cfg[k])
@@ -776,6 +799,9 @@ if __name__ == "__main__":
     elif len(sys.argv) > 1 and sys.argv[1] == "round2":
         os.makedirs(OUT, exist_ok=True)
         main_round2()
+    elif len(sys.argv) > 1 and sys.argv[1] == "nocompress":
+        os.makedirs(OUT, exist_ok=True)
+        main_nocompress()
     elif len(sys.argv) > 1 and sys.argv[1] == "legacy":
         os.makedirs(OUT, exist_ok=True)
         main_legacy()

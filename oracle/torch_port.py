@@ -34,7 +34,8 @@ class TorchPort(nn.Module):
         self.p = nn.ParameterDict({k.replace(".", "/"): nn.Parameter(torch.tensor(v, dtype=dtype))
                                    for k, v in W.items() if ".mem." not in k})
         self.mems = nn.ModuleDict()
-        for name, inp, hid in (("encoder", E, Hm), ("ctx_encoder", E, Hm), ("decoder", 2 * self.L, self.Hd)):
+        Lc = self.L if cfg.get("compress_context", False) else Hm                         # :363-366
+        for name, inp, hid in (("encoder", E, Hm), ("ctx_encoder", E, Hm), ("decoder", Lc + self.L, self.Hd)):
             kind = nn.GRU if cfg.get("mem_type", "lstm") == "gru" else nn.LSTM            # :154-159
             m = kind(inp, hid, num_layers=self.nl, batch_first=True, dropout=dropout)     # :155, :307, :476
             m = m.to(dtype)
@@ -117,6 +118,8 @@ class TorchPort(nn.Module):
             e = torch.cat([e, ex], dim=-1)
         e = self._interact(e, "ctx_encoder", "ctx")
         h = self._mem("ctx_encoder", e)
+        if not self.cfg.get("compress_context", False):
+            return h                                                                  # nn.Identity(), :228
         return F.linear(h, self.w("ctx_encoder.final_compression.weight"),
                         self.w("ctx_encoder.final_compression.bias"))                # :343
 
@@ -146,7 +149,7 @@ class TorchPort(nn.Module):
         B, T = surf.shape[:2]
         C = T - horizon
         ctx = self.ctx_encoder(surf[:, :C], None if ex is None else ex[:, :C])
-        ctx_pad = torch.cat([ctx, torch.zeros(B, T - C, self.L, dtype=ctx.dtype)], dim=1)   # :1061-1062
+        ctx_pad = torch.cat([ctx, torch.zeros(B, T - C, ctx.shape[-1], dtype=ctx.dtype)], dim=1)   # :1061-1062
         zm, zl = self.encoder(surf, ex)
         z = zm + torch.exp(0.5 * zl) * eps                                            # :199
         s, e = self.decoder(torch.cat([ctx_pad, z], dim=-1))                          # :1066
@@ -160,7 +163,7 @@ class TorchPort(nn.Module):
             zm, _ = self.encoder(surf, ex)
             z[:, :C] = zm
             ctx = self.ctx_encoder(surf, ex)
-            ctx_pad = torch.cat([ctx, torch.zeros(B, T - C, self.L, dtype=ctx.dtype)], dim=1)
+            ctx_pad = torch.cat([ctx, torch.zeros(B, T - C, ctx.shape[-1], dtype=ctx.dtype)], dim=1)
             s, e = self.decoder(torch.cat([ctx_pad, z], dim=-1))
         return s[:, C:], (None if e is None else e[:, C:])
 

@@ -37,7 +37,8 @@ def prior_state_dict_spec(cfg: dict) -> List[Tuple[str, Tuple[int, ...]]]:
     """Parameter names and shapes of ConditionalPriorNetwork.state_dict() (keys carry the
     "prior_network." prefix they have inside CVAEMemRandConditionalPrior): the context-encoder stack
     under its own names, a compression Linear and the two prior heads
-    (/root/reference/vae/conditional_prior_network.py:62-82, 104-112, 159-166), compress_context=True."""
+    (/root/reference/vae/conditional_prior_network.py:62-82, 104-112, 159-166); without compress_context the
+    compression is nn.Identity() and the heads read the memory's hidden state (:73-78)."""
     L, X, Hm, nl = cfg["latent_dim"], cfg["ex_feats_dim"], cfg["mem_hidden"], cfg["mem_layers"]
     csh = list(cfg["ctx_surface_hidden"])
     E = csh[-1] * 25 + X
@@ -56,9 +57,12 @@ def prior_state_dict_spec(cfg: dict) -> List[Tuple[str, Tuple[int, ...]]]:
         i = E if l == 0 else Hm
         spec += [(f"prior_network.mem.weight_ih_l{l}", (ng * Hm, i)), (f"prior_network.mem.weight_hh_l{l}", (ng * Hm, Hm)),
                  (f"prior_network.mem.bias_ih_l{l}", (ng * Hm,)), (f"prior_network.mem.bias_hh_l{l}", (ng * Hm,))]
-    spec += [("prior_network.compression.weight", (L, Hm)), ("prior_network.compression.bias", (L,)),
-             ("prior_network.prior_mean_layer.weight", (L, L)), ("prior_network.prior_mean_layer.bias", (L,)),
-             ("prior_network.prior_logvar_layer.weight", (L, L)), ("prior_network.prior_logvar_layer.bias", (L,))]
+    hid = Hm
+    if cfg.get("compress_context", False):
+        spec += [("prior_network.compression.weight", (L, Hm)), ("prior_network.compression.bias", (L,))]
+        hid = L
+    spec += [("prior_network.prior_mean_layer.weight", (L, hid)), ("prior_network.prior_mean_layer.bias", (L,)),
+             ("prior_network.prior_logvar_layer.weight", (L, hid)), ("prior_network.prior_logvar_layer.bias", (L,))]
     return spec
 
 
@@ -236,7 +240,8 @@ def encoder_forward(W: Weights, cfg: dict, surface: np.ndarray,
 def ctx_encoder_forward(W: Weights, cfg: dict, surface: np.ndarray,
                         ex_feats: Optional[np.ndarray] = None) -> np.ndarray:
     """CVAECtxMemRandEncoder.forward (cvae_with_mem_randomized.py:314-344),
-    compress_context=True -> (B,C,L)."""
+    -> (B,C,Lc): Lc = latent_dim with compress_context, else the memory's hidden state itself
+    (final_compression is nn.Identity(), :225-228)."""
     n = len(cfg["ctx_surface_hidden"])
     emb = _embed(surface, W, "ctx_encoder.ctx_surface_embedding",
                  [f"ctx_enc_conv_{i}" for i in range(n)])
@@ -244,6 +249,8 @@ def ctx_encoder_forward(W: Weights, cfg: dict, surface: np.ndarray,
         emb = np.concatenate([emb, ex_feats], axis=-1)
     emb = _interact(emb, W, cfg, "ctx_encoder", "ctx")
     h, _ = lstm_forward(emb, W, "ctx_encoder.mem", cfg["mem_layers"])
+    if not cfg.get("compress_context", False):
+        return h
     return linear(h, W["ctx_encoder.final_compression.weight"],
                   W["ctx_encoder.final_compression.bias"])
 
@@ -257,7 +264,8 @@ def prior_network_forward(Wp: Weights, cfg: dict, surface: np.ndarray, ex_feats:
         emb = np.concatenate([emb, ex_feats], axis=-1)
     emb = _interact(emb, Wp, cfg, "prior_network", "prior")
     h, _ = lstm_forward(emb, Wp, "prior_network.mem", cfg["mem_layers"])
-    h = linear(h, Wp["prior_network.compression.weight"], Wp["prior_network.compression.bias"])
+    if cfg.get("compress_context", False):
+        h = linear(h, Wp["prior_network.compression.weight"], Wp["prior_network.compression.bias"])
     return (linear(h, Wp["prior_network.prior_mean_layer.weight"], Wp["prior_network.prior_mean_layer.bias"]),
             linear(h, Wp["prior_network.prior_logvar_layer.weight"], Wp["prior_network.prior_logvar_layer.bias"]))
 
@@ -285,7 +293,7 @@ def cond_prior_generate(W: Weights, Wp: Weights, cfg: dict, ctx_surface: np.ndar
     z[:, C:] = pm[:, -1:] + np.exp(0.5 * plv[:, -1:]) * eps_future
     z[:, :C] = zm if eps_ctx is None else zm + np.exp(0.5 * zl) * eps_ctx
     ctx = ctx_encoder_forward(W, cfg, ctx_surface, ctx_ex)
-    ctx_pad = np.zeros((B, C + H, L), dtype=ctx_surface.dtype)
+    ctx_pad = np.zeros((B, C + H, ctx.shape[-1]), dtype=ctx_surface.dtype)
     ctx_pad[:, :C] = ctx
     s, e, _ = decoder_forward(W, cfg, np.concatenate([ctx_pad, z], axis=-1))
     return s[:, C:], (None if e is None else e[:, C:])
@@ -346,7 +354,7 @@ def forward(W: Weights, cfg: dict, surface: np.ndarray, ex_feats: Optional[np.nd
         raise ValueError("Insufficient sequence length")             # :1043
     L = cfg["latent_dim"]
     ctx = ctx_encoder_forward(W, cfg, surface[:, :C], None if ex_feats is None else ex_feats[:, :C])
-    ctx_pad = np.zeros((B, T, L), dtype=surface.dtype)               # :1061-1062
+    ctx_pad = np.zeros((B, T, ctx.shape[-1]), dtype=surface.dtype)               # :1061-1062
     ctx_pad[:, :C] = ctx
     zm, zl = encoder_forward(W, cfg, surface, ex_feats)
     z = zm + np.exp(0.5 * zl) * eps                                   # :199
@@ -365,7 +373,7 @@ def get_surface_given_conditions(W: Weights, cfg: dict, ctx_surface: np.ndarray,
     zm, _ = encoder_forward(W, cfg, ctx_surface, ctx_ex)
     z[:, :C] = zm
     ctx = ctx_encoder_forward(W, cfg, ctx_surface, ctx_ex)
-    ctx_pad = np.zeros((B, T, L), dtype=ctx_surface.dtype)
+    ctx_pad = np.zeros((B, T, ctx.shape[-1]), dtype=ctx_surface.dtype)
     ctx_pad[:, :C] = ctx
     s, e, _ = decoder_forward(W, cfg, np.concatenate([ctx_pad, z.astype(ctx_surface.dtype)], axis=-1))
     return s[:, C:], (None if e is None else e[:, C:])
@@ -405,7 +413,7 @@ def prior_mc_shared_prefix(W: Weights, cfg: dict, ctx_surface: np.ndarray,
     ctx = ctx_encoder_forward(W, cfg, ctx_surface, ctx_ex)
     _, finals = lstm_forward(np.concatenate([ctx, zm], axis=-1), W, "decoder.mem", cfg["mem_layers"])
     state = [(np.repeat(h, S, axis=0), np.repeat(c, S, axis=0)) for h, c in finals]
-    dec_in = np.concatenate([np.zeros((D * S, H, L), dtype=ctx_surface.dtype),
+    dec_in = np.concatenate([np.zeros((D * S, H, ctx.shape[-1]), dtype=ctx_surface.dtype),
                              z_future.reshape(D * S, H, L).astype(ctx_surface.dtype)], axis=-1)
     s, e, _ = decoder_forward(W, cfg, dec_in, state)
     s = s.reshape(D, S, H, -1, 5, 5)

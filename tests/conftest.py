@@ -37,6 +37,8 @@ def cfg_of(g):
         cfg["interaction_layers"] = int(g["cfg_interaction_layers"])
     if "cfg_mem_type" in g:
         cfg["mem_type"] = str(g["cfg_mem_type"])
+    if "cfg_compress_context" in g:
+        cfg["compress_context"] = bool(g["cfg_compress_context"])
     for k in ("ex_loss_on_ret_only", "ex_feats_loss_type", "kl_weight", "re_feat_weight"):
         if "cfg_" + k in g:
             v = g["cfg_" + k]

@@ -865,3 +865,63 @@ def test_legacy_one_channel_mse_model_vs_reference(name):
     assert (s2[0] if X else s2).shape == g["surf_out"].shape
     with pytest.raises(ValueError):
         model.forward({"surface": x["surface"][:, :T - 1]})
+
+
+@pytest.mark.parametrize("mem,L,X", [("lstm", 5, 3), ("lstm", 12, 0), ("gru", 5, 3)])
+def test_uncompressed_context_mc_product_and_model_class(mem, L, X):
+    """compress_context=False (the class default, reference :1014-1015): the decoder reads the context memory's
+    hidden state (width mem_hidden) next to z.  The goldens named *_nocomp_* cover forward / generation / gradients
+    against the reference; here the Monte-Carlo product (shared prefix, fused decoder with Philox noise, percentile
+    reduction, the segmented prefix) against the oracle, and the drop-in class (device-side packing, training)."""
+    from vsv import paths
+    from vae.cvae_with_mem_randomized import CVAEMemRand
+    C, H, S, N = 6, 2, 1000, 40
+    cfg = vo.make_config(L, X, mem_type=mem, compress_context=False)
+    eng, W = _engine(cfg, 61, 2.0)
+    assert eng.Lc == cfg["mem_hidden"]
+    rng = np.random.default_rng(29)
+    vol = (0.2 + 0.1 * rng.standard_normal((N + C, 5, 5))).astype(np.float32)
+    ex = (0.01 * rng.standard_normal((N + C, X))).astype(np.float32) if X else None
+    q = paths.prior_mc_windows(eng, _t(vol), _t(ex), C, N, C, H, S, seed=7, chunk_days=16, channel=None)
+    eps = _n(eng.philox_normal(7, C, N, S, 0, H)).reshape(N, S, H, L)
+    win = np.stack([vol[d:d + C] for d in range(N)])
+    wex = np.stack([ex[d:d + C] for d in range(N)]) if X else None
+    smp, _ = vo.prior_mc_shared_prefix(W, cfg, win, wex, eps.astype(np.float32))
+    want = np.percentile(smp.astype(np.float64), [5, 50, 95], axis=1).transpose(1, 2, 0, 3, 4, 5)
+    assert err(_n(q), want) <= TOL
+    q1 = paths.prior_mc_windows(eng, _t(vol), _t(ex), C, N, C, H, S, seed=7, chunk_days=256, channel=1)
+    assert err(_n(q1), want[:, :, :, 1]) <= TOL
+    # the date-range prefix in time segments: same steps in the same order
+    s1, g1 = paths._context_prefix(eng, _t(vol), _t(ex), N, C, n_seg=1)
+    for layers in ("0", "1"):
+        os.environ["VSV_PREFIX_LAYERS"] = layers
+        try:
+            s2, g2 = paths._context_prefix(eng, _t(vol), _t(ex), N, C, n_seg=2)
+            torch.cuda.synchronize()
+            assert torch.equal(s1, s2) and torch.equal(g1, g2), layers
+        finally:
+            os.environ.pop("VSV_PREFIX_LAYERS", None)
+    # the class: parameters packed on the device from the nn.Module's tensors, training reduces the loss
+    torch.manual_seed(1)
+    model = CVAEMemRand(vo.make_config(L, X, mem_type=mem, compress_context=False, device="cuda:0"))
+    assert isinstance(model.ctx_encoder.final_compression, torch.nn.Identity)
+    assert model.decoder.mem.weight_ih_l0.shape[1] == cfg["mem_hidden"] + L
+    x = {"surface": torch.from_numpy(win[:16, :, :, :].copy())}
+    if X:
+        x["ex_feats"] = torch.from_numpy(wex[:16].copy())
+    sd = {k: v.detach().cpu().numpy().astype(np.float64) for k, v in model.state_dict().items()
+          if not k.startswith("quantile_loss_fn")}
+    e_in = rng.standard_normal((16, C, L))
+    want_f = vo.forward(sd, cfg, x["surface"].numpy().astype(np.float64),
+                        x["ex_feats"].numpy().astype(np.float64) if X else None, e_in, 1)
+    got = paths.forward(model._engine(), x["surface"].cuda(), x["ex_feats"].cuda() if X else None, 1, eps=_t(e_in))
+    assert err(_n(got[0]), want_f[0]) <= TOL
+    opt = torch.optim.AdamW(model.parameters(), lr=1e-3)
+    first = None
+    for _ in range(20):
+        losses = model.train_step(x, opt)
+        assert torch.isfinite(losses["loss"])
+        first = first if first is not None else float(losses["loss"])
+    assert float(losses["loss"]) < first
+    got2 = model.forward(x)
+    assert got2[0].shape == (16, 1, 3, 5, 5)

@@ -658,8 +658,8 @@ struct LstmSeqArgs {
     int T;
     // XMODE 0
     const float* x_tileb;   // [(rowtile*T + t)*kx + s][64]
-    // XMODE 1
-    int L;
+    // XMODE 1: decoder input [ctx (Lc features: L with compress_context, else the context memory's width) | z (L)]
+    int L, Lc;
     vsv_decode_in din;
     float* z_out;           // (n_rows, T, L) or null
     // state
@@ -710,9 +710,9 @@ struct DecIn {
 __device__ __forceinline__ float decoder_input(const LstmSeqArgs& a, const DecIn& di, long row, bool row_ok, bool writer,
                                                int t, int f) {
     const vsv_decode_in& d = a.din;
-    const int L = a.L;
-    if (f < L) return (t < d.ctx_T) ? di.ctx[(long)t * L + f] : 0.0f;
-    f -= L;
+    const int L = a.L, Lc = a.Lc;
+    if (f < Lc) return (t < d.ctx_T) ? di.ctx[(long)t * Lc + f] : 0.0f;
+    f -= Lc;
     if (f >= L) return 0.0f;
     float base, scale;
     if (t < d.z_T) {
@@ -1003,8 +1003,8 @@ lstm_kernel(const LstmSeqArgs a) {
     // are multiplied (L = 12: quads 1-2 of 4)
     int qx0 = 0, qxn = kx >> 2;
     if (XMODE == 1 && !SAVE && OWN == 4 && shared0 && a.din.ctx_T <= 0 && a.din.z_T <= 0 && !a.din.eps_in && !a.z_out) {
-        qx0 = a.L >> 3;
-        qxn = ((2 * a.L + 7) >> 3) - qx0;
+        qx0 = a.Lc >> 3;
+        qxn = ((a.Lc + a.L + 7) >> 3) - qx0;
     }
     // (with a pre-activation table layer 0 streams its recurrent quads only)
     const size_t w0_skip = (XMODE == 0 && !SAVE && (a.pre_t || a.pre_g)) ? (size_t)(kx >> 2) * NT * 64 : 0;
@@ -1056,7 +1056,7 @@ lstm_kernel(const LstmSeqArgs a) {
             // Monte-Carlo fast path (prior draw from a day's prefix state): the context half of the input
             // is the zero padding, the latent half mu0 + std0 * Philox
             for (int s = wave; s < kx; s += NW) {
-                const int f = 2 * s + hh - a.L;
+                const int f = 2 * s + hh - a.Lc;
                 float v = 0.0f;
                 if (f >= 0 && f < a.L) {
                     v = d.mu0;
@@ -1494,11 +1494,11 @@ __global__ void __launch_bounds__(256, 2) mc_decode1_kernel(const LstmSeqArgs a)
         state_row = (d.state_div == d.S) ? day_rel : row32 / (uint32_t)(d.state_div > 0x7fffffffL ? 0x7fffffffL : d.state_div);
         float* const col = col0 + lane;
         // x part of layer 0: [ctx (zero padding) | z | alignment padding]; k-step s, half hh <-> feature 2s + hh
-        for (int s = 0; s < kx; ++s) col[s * 64] = (2 * s + hh >= a.L && 2 * s + hh < 2 * a.L) ? d.mu0 : 0.0f;
+        for (int s = 0; s < kx; ++s) col[s * 64] = (2 * s + hh >= a.Lc && 2 * s + hh < a.Lc + a.L) ? d.mu0 : 0.0f;
         if (d.std0 != 0.0f) {
             // one Philox block gives the latents 4b .. 4b+3 (philox_normal_elem: word pair f & 2, cos / sin by f & 1);
             // this lane holds the two of them with its parity
-            const int par = (hh - a.L) & 1;
+            const int par = (hh - a.Lc) & 1;
             const uint32_t k0 = (uint32_t)d.seed, k1 = (uint32_t)(d.seed >> 32);
             for (int b = 0; 4 * b < a.L; ++b) {
                 uint32_t c0 = sample, c1 = day, c2 = (uint32_t)(d.step0 - d.eps_t0), c3 = (uint32_t)b;
@@ -1511,7 +1511,7 @@ __global__ void __launch_bounds__(256, 2) mc_decode1_kernel(const LstmSeqArgs a)
                     const float u2 = ((float)(xb >> 9) + 0.5f) * 1.1920928955078125e-07f;
                     const float r = __builtin_amdgcn_sqrtf(-1.3862943611198906f * __builtin_amdgcn_logf(u1));
                     const float e = r * (par ? __builtin_amdgcn_sinf(u2) : __builtin_amdgcn_cosf(u2));
-                    if (f < a.L) col[((f + a.L - hh) >> 1) * 64] = d.mu0 + d.std0 * e;
+                    if (f < a.L) col[((f + a.Lc - hh) >> 1) * 64] = d.mu0 + d.std0 * e;
                 }
             }
         }
@@ -1519,7 +1519,7 @@ __global__ void __launch_bounds__(256, 2) mc_decode1_kernel(const LstmSeqArgs a)
     const float* const gate_in = d.gate_in + (size_t)state_row * 2 * NT * 32;
     const float* const st = d.state_in + (size_t)state_row * 2 * 2 * HP;
     // of layer 0's input quads only those that hold z are multiplied (the context half is the zero padding)
-    const int qx0 = a.L >> 3, qxn = ((2 * a.L + 7) >> 3) - qx0;
+    const int qx0 = a.Lc >> 3, qxn = ((a.Lc + a.L + 7) >> 3) - qx0;
     MC1_STAMP(1);
 
     // ---- the two memory layers
@@ -2870,7 +2870,7 @@ extern "C" int vsv_decode_prefix_layer0(const vsv_dims* dims, const float* packe
     l.gru = lay.gru;
     l.w[0] = packed + dc.lstm[0].w_off; l.b[0] = packed + dc.lstm[0].b_off;
     l.kx = dc.kx; l.n_rows = n_rows; l.n_rowtiles = (n_rows + 31) / 32; l.T = T;
-    l.L = lay.L; l.din = *in;
+    l.L = lay.L; l.Lc = lay.Lc; l.din = *in;
     if (l.din.ctx_div < 1) l.din.ctx_div = 1;
     if (l.din.z_div < 1) l.din.z_div = 1;
     if (l.din.S < 1) l.din.S = 1;
@@ -2936,7 +2936,7 @@ static int prefix_plan(const Layout& lay, long n_days, int C, int n_seg, PrefixP
         b += align256(wse);                                    // posterior encoder workspace
         b += align256(wse);                                    // context encoder workspace
         b += align256(wsd);                                    // decoder workspace
-        b += 2 * align256((size_t)n_days * T * lay.L * sizeof(float));      // z_mean, ctx embedding
+        b += align256((size_t)n_days * T * lay.L * sizeof(float)) + align256((size_t)n_days * T * lay.Lc * sizeof(float));   // z_mean, ctx embedding
         b += 2 * align256((size_t)n_days * nse * sizeof(float));            // encoder states
         b += align256((size_t)n_days * nsd * sizeof(float));                // decoder state
         cur += b;
@@ -2996,7 +2996,7 @@ extern "C" int vsv_context_prefix(const vsv_dims* dims, const float* packed, con
         void* ws_c = b; b += align256(wse);
         void* ws_d = b; b += align256(wsd);
         float* zm = (float*)b; b += align256((size_t)n_days * T * lay.L * sizeof(float));
-        float* cx = (float*)b; b += align256((size_t)n_days * T * lay.L * sizeof(float));
+        float* cx = (float*)b; b += align256((size_t)n_days * T * lay.Lc * sizeof(float));
         float* ne = (float*)b; b += align256((size_t)n_days * nse * sizeof(float));
         float* nc = (float*)b; b += align256((size_t)n_days * nse * sizeof(float));
         float* nd = last ? state_out : (float*)b;
@@ -3014,14 +3014,14 @@ extern "C" int vsv_context_prefix(const vsv_dims* dims, const float* packed, con
             if (rc) break;
             (void)hipEventRecord(evs[which], s0);
             (void)hipStreamWaitEvent(s1, evs[which], 0);
-            rc = encode_windows_layer1_impl(dims, packed, which, n_days, T, si, so, which ? cx : zm, lay.L, w, wse, s1);
+            rc = encode_windows_layer1_impl(dims, packed, which, n_days, T, si, so, which ? cx : zm, which ? 0 : lay.L, w, wse, s1);
             if (rc) break;
             (void)hipEventRecord(evs[2 + which], s1);
             (void)hipStreamWaitEvent(sq[4], evs[2 + which], 0);
         }
         if (rc == 0) {
             vsv_decode_in din = {};
-            din.ctx = cx; din.ctx_rs = (long)T * lay.L; din.ctx_T = T; din.ctx_div = 1;
+            din.ctx = cx; din.ctx_rs = (long)T * lay.Lc; din.ctx_T = T; din.ctx_div = 1;
             din.zb = zm; din.z_rs = (long)T * lay.L; din.z_T = T; din.z_div = 1;
             din.S = 1; din.state_in = st_d; din.state_div = 1;
             din.gate_out = last ? gate_out : nullptr;
@@ -3332,7 +3332,7 @@ extern "C" int vsv_decode(const vsv_dims* dims, const float* packed, const vsv_d
     l.gru = lay.gru;
     for (int i = 0; i < lay.NL; ++i) { l.w[i] = packed + dc.lstm[i].w_off; l.b[i] = packed + dc.lstm[i].b_off; }
     l.kx = dc.kx; l.n_rows = n_rows; l.n_rowtiles = rt; l.T = T;
-    l.L = lay.L; l.din = *in; l.z_out = z_out;
+    l.L = lay.L; l.Lc = lay.Lc; l.din = *in; l.z_out = z_out;
     if (l.din.ctx_div < 1) l.din.ctx_div = 1;
     if (l.din.z_div < 1) l.din.z_div = 1;
     if (l.din.S < 1) l.din.S = 1;
@@ -3578,7 +3578,7 @@ extern "C" int vsv_train_decode(const vsv_dims* dims, const float* packed, const
     l.gru = lay.gru;
     for (int i = 0; i < lay.NL; ++i) { l.w[i] = packed + dc.lstm[i].w_off; l.b[i] = packed + dc.lstm[i].b_off; }
     l.kx = dc.kx; l.n_rows = n_rows; l.n_rowtiles = rt; l.T = T;
-    l.L = lay.L; l.din = *in; l.z_out = z_out;
+    l.L = lay.L; l.Lc = lay.Lc; l.din = *in; l.z_out = z_out;
     if (l.din.ctx_div < 1) l.din.ctx_div = 1;
     if (l.din.z_div < 1) l.din.z_div = 1;
     if (l.din.S < 1) l.din.S = 1;
@@ -3861,34 +3861,38 @@ __global__ void __launch_bounds__(256) reparam_bwd_kernel(const float* __restric
                                                           const float* __restrict__ zm, const float* __restrict__ d_zm,
                                                           const float* __restrict__ d_zl, const float* __restrict__ d_z,
                                                           const float* __restrict__ ctx_mask, long B, int T, int Tc, int L,
-                                                          float* __restrict__ d_enc, float* __restrict__ d_ctx) {
+                                                          int Lc, float* __restrict__ d_enc, float* __restrict__ d_ctx) {
+    const int W = Lc + L;                                          // dx row: [ctx part (Lc) | z part (L)]
     const long n = B * T * L;
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
         const int f = (int)(i % L);
         const long bt = i / L;
-        const int t = (int)(bt % T);
-        const long b = bt / T;
-        float dz = dx[bt * 2 * L + L + f];
+        float dz = dx[bt * W + Lc + f];
         if (d_z) dz += d_z[i];
         d_enc[bt * 2 * L + f] = d_zm ? dz + d_zm[i] : dz;
         const float dl = dz * 0.5f * (z[i] - zm[i]);
         d_enc[bt * 2 * L + L + f] = d_zl ? dl + d_zl[i] : dl;
-        if (t < Tc) {
-            const float g = dx[bt * 2 * L + f];
-            d_ctx[(b * Tc + t) * L + f] = ctx_mask ? g * ctx_mask[b * Tc + t] : g;
-        }
+    }
+    const long nc = B * Tc * Lc;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < nc; i += (long)gridDim.x * 256) {
+        const int f = (int)(i % Lc);
+        const long bt = i / Lc;
+        const int t = (int)(bt % Tc);
+        const long b = bt / Tc;
+        const float g = dx[(b * T + t) * W + f];
+        d_ctx[i] = ctx_mask ? g * ctx_mask[bt] : g;
     }
 }
 
 extern "C" int vsv_reparam_backward(const float* dx, const float* z, const float* zm, const float* d_zm, const float* d_zl,
-                                    const float* d_z, const float* ctx_mask, long B, int T, int Tc, int L,
+                                    const float* d_z, const float* ctx_mask, long B, int T, int Tc, int L, int Lc,
                                     float* d_enc, float* d_ctx, void* stream) {
     if (!dx || !z || !zm || !d_enc || !d_ctx) { set_error("vsv_reparam_backward: null pointer"); return -1; }
-    if (B < 1 || T < 1 || Tc < 0 || Tc > T || L < 1) { set_error("vsv_reparam_backward: bad sizes"); return -1; }
-    const long n = B * T * L;
+    if (B < 1 || T < 1 || Tc < 0 || Tc > T || L < 1 || Lc < 1) { set_error("vsv_reparam_backward: bad sizes"); return -1; }
+    const long n = B * T * (L > Lc ? L : Lc);
     const unsigned blocks = (unsigned)((n + 255) / 256 > 1024 ? 1024 : (n + 255) / 256);
     hipLaunchKernelGGL(reparam_bwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, dx, z, zm, d_zm, d_zl, d_z,
-                       ctx_mask, B, T, Tc, L, d_enc, d_ctx);
+                       ctx_mask, B, T, Tc, L, Lc, d_enc, d_ctx);
     return launch_check("reparam_bwd_kernel");
 }
 

@@ -44,8 +44,8 @@ struct EncLayout {
     int n_chain = 0;               // conv layers + interaction Linears: the dense chain in front of the LSTM
     Sec conv[kMaxDenseLayers];     // the chain; the ex-features are injected into the output of conv[n_conv-1]
     Sec lstm[2];                   // k-space: layer 0 = [x: kx | h0: 4*NTm], layer 1 = [h0 | h1]
-    Sec head;                      // [z_mean; z_log_var] (which=0) or final_compression (which=1)
-    int nh = 0;                    // head outputs: 2L or L
+    Sec head;                      // [z_mean; z_log_var] (which=0) or final_compression / identity (which=1)
+    int nh = 0;                    // head outputs: 2L or Lc
     int E = 0;                     // LSTM input features: c_last*25 + X
     int kx = 0;                    // k-steps of the LSTM x part (PERM32 order): 16 * tiles of the chain's last layer
     int ex_f0 = 0;                 // first ex-feature slot in the embedding (c_last*25)
@@ -53,7 +53,7 @@ struct EncLayout {
 
 struct DecLayout {
     Sec lstm[2];                   // k-space: layer 0 = [x: kx | h0: 4*NTd], layer 1 = [h0 | h1]
-    int kx = 0;                    // k-steps of [ctx | z] in natural order: ceil(2L/2) rounded up to 4
+    int kx = 0;                    // k-steps of [ctx | z] in natural order: ceil((Lc + L)/2) rounded up to 4
     int n_head = 0;
     Sec head[kMaxDenseLayers];     // [interaction Linears,] Linear, ConvT x n_conv, Conv
     // inference only: head[fold_at] (Linear) and head[fold_at + 1] (first ConvT [+ ex Linear]) have no
@@ -70,6 +70,7 @@ struct DecLayout {
 
 struct Layout {
     int L = 0, X = 0, Hm = 0, NL = 0, Q = 0;
+    int Lc = 0;                    // context-embedding width: L (compress_context) or Hm
     int NI = 0;                    // interaction Linears per module: 0, or interaction_layers + 1
     int gru = 0;                   // memory cell: 0 nn.LSTM, 1 nn.GRU (gate slots r, z, n_x, n_h)
     int Hd = 0;                    // decoder LSTM hidden = c_last*25 + X

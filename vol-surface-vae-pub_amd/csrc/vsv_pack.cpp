@@ -85,6 +85,7 @@ int make_layout(const vsv_dims& d, Layout& lay, const char** msg) {
     lay.NI = d.interaction_layers > 0 ? d.interaction_layers + 1 : 0;
     if (d.mem_type < 0 || d.mem_type > 1) return fail("mem_type must be 0 (lstm) or 1 (gru)");
     lay.gru = d.mem_type;
+    lay.Lc = d.compress_context ? lay.L : lay.Hm;
     if (d.n_conv < 1 || d.n_conv > VSV_MAX_CONV || d.n_ctx_conv < 1 || d.n_ctx_conv > VSV_MAX_CONV)
         return fail("1..4 conv layers supported");
     if (d.n_conv + lay.NI > kMaxDenseLayers || d.n_ctx_conv + lay.NI > kMaxDenseLayers || 2 + d.n_conv + lay.NI > kMaxDenseLayers)
@@ -138,11 +139,11 @@ int make_layout(const vsv_dims& d, Layout& lay, const char** msg) {
         e.kx = 16 * nt_prev;
         e.lstm[0] = alloc_sec(cur, e.kx / 4 + lay.NTm, lay.NTm, 4 * lay.Hm, 0);
         if (lay.NL == 2) e.lstm[1] = alloc_sec(cur, 2 * lay.NTm, lay.NTm, 4 * lay.Hm, 0);
-        e.nh = which ? lay.L : 2 * lay.L;
+        e.nh = which ? lay.Lc : 2 * lay.L;
         e.head = alloc_sec(cur, lay.NTm, cdiv(e.nh, 32), e.nh, 0);
     }
     DecLayout& dc = lay.dec;
-    dc.kx = 4 * cdiv(lay.L, 4);                       // 2L features, 2 per k-step, rounded up to a quad
+    dc.kx = 4 * cdiv(lay.Lc + lay.L, 8);              // Lc + L features, 2 per k-step, rounded up to a quad
     dc.lstm[0] = alloc_sec(cur, dc.kx / 4 + lay.NTd, lay.NTd, 4 * lay.Hd, 0);
     if (lay.NL == 2) dc.lstm[1] = alloc_sec(cur, 2 * lay.NTd, lay.NTd, 4 * lay.Hd, 0);
     // head: Linear(Hd -> c_last*25 [+X]) ; ConvT x n_conv ; Conv -> Q*25.
@@ -403,15 +404,24 @@ extern "C" int vsv_pack_weights(const vsv_dims* dims, const vsv_raw_weights* raw
             pack_sec(out, e.head, out_nat32(2 * L), in_nat(Hm), W, B);
         } else {
             const float *wc = raw->ctx_comp_w, *bc = raw->ctx_comp_b;
-            WFn W = [=](int r, int c) { return wc[(size_t)r * Hm + c]; };
-            BFn B = [=](int r) { return bc[r]; };
-            pack_sec(out, e.head, out_nat32(L), in_nat(Hm), W, B);
+            if (d.compress_context) {
+                if (!wc || !bc) { set_error("vsv_pack_weights: missing final_compression"); return -1; }
+                WFn W = [=](int r, int c) { return wc[(size_t)r * Hm + c]; };
+                BFn B = [=](int r) { return bc[r]; };
+                pack_sec(out, e.head, out_nat32(L), in_nat(Hm), W, B);
+            } else {
+                // compress_context = False (:363-366 absent): the embedding is the memory's output itself -- an
+                // identity "head", so the kernels' chain (tile-B h -> row-major embedding) stays the same
+                WFn W = [=](int r, int c) { return r == c ? 1.0f : 0.0f; };
+                BFn B = [=](int) { return 0.0f; };
+                pack_sec(out, e.head, out_nat32(Hm), in_nat(Hm), W, B);
+            }
         }
     }
 
     const DecLayout& dc = lay.dec;
     const int Hd = lay.Hd;
-    (lay.gru ? pack_gru : pack_lstm)(out, dc.lstm, raw->dec_mem, lay.NL, Hd, lay.NTd, 2 * L, dc.kx, in_nat(2 * L));
+    (lay.gru ? pack_gru : pack_lstm)(out, dc.lstm, raw->dec_mem, lay.NL, Hd, lay.NTd, lay.Lc + L, dc.kx, in_nat(lay.Lc + L));
     int hi = 0;
     const int c_last = d.surface_hidden[d.n_conv - 1];
     for (int j = 0; j < lay.NI; ++j) {

@@ -56,10 +56,13 @@ class CVAEMemRandConditionalPrior(CVAEMemRand):
             sub["encoder.interaction." + n.replace("prior_interact", "enc_interact")] = p
         for n, p in pn.mem.named_parameters():
             sub[f"encoder.mem.{n}"] = p
-        Wc, bc = pn.compression.weight, pn.compression.bias
         for head, name in ((pn.prior_mean_layer, "z_mean_layer"), (pn.prior_logvar_layer, "z_log_var_layer")):
-            sub[f"encoder.{name}.weight"] = head.weight @ Wc
-            sub[f"encoder.{name}.bias"] = head.weight @ bc + head.bias
+            if self.config["compress_context"]:
+                Wc, bc = pn.compression.weight, pn.compression.bias
+                sub[f"encoder.{name}.weight"] = head.weight @ Wc
+                sub[f"encoder.{name}.bias"] = head.weight @ bc + head.bias
+            else:                                                   # compression is nn.Identity()
+                sub[f"encoder.{name}.weight"], sub[f"encoder.{name}.bias"] = head.weight, head.bias
         out = []
         for n, p in CVAEMemRandConditionalPrior._hip_named_params(self):
             out.append((n, sub.get(n, p)))
@@ -222,15 +225,19 @@ class CVAEMemRandConditionalPrior(CVAEMemRand):
             pairs.append((p, g["encoder.interaction." + n.replace("prior_interact", "enc_interact")]))
         for n, p in pn.mem.named_parameters():
             pairs.append((p, g[f"encoder.mem.{n}"]))
-        Wc, bc = pn.compression.weight.detach().float(), pn.compression.bias.detach().float()
-        gWc, gbc = torch.zeros_like(Wc), torch.zeros_like(bc)
-        for head, name in ((pn.prior_mean_layer, "z_mean_layer"), (pn.prior_logvar_layer, "z_log_var_layer")):
-            gWf, gbf = g[f"encoder.{name}.weight"], g[f"encoder.{name}.bias"]
-            Wh = head.weight.detach().float()
-            pairs += [(head.weight, gWf @ Wc.t() + torch.outer(gbf, bc)), (head.bias, gbf)]
-            gWc += Wh.t() @ gWf
-            gbc += Wh.t() @ gbf
-        pairs += [(pn.compression.weight, gWc), (pn.compression.bias, gbc)]
+        if self.config["compress_context"]:
+            Wc, bc = pn.compression.weight.detach().float(), pn.compression.bias.detach().float()
+            gWc, gbc = torch.zeros_like(Wc), torch.zeros_like(bc)
+            for head, name in ((pn.prior_mean_layer, "z_mean_layer"), (pn.prior_logvar_layer, "z_log_var_layer")):
+                gWf, gbf = g[f"encoder.{name}.weight"], g[f"encoder.{name}.bias"]
+                Wh = head.weight.detach().float()
+                pairs += [(head.weight, gWf @ Wc.t() + torch.outer(gbf, bc)), (head.bias, gbf)]
+                gWc += Wh.t() @ gWf
+                gbc += Wh.t() @ gbf
+            pairs += [(pn.compression.weight, gWc), (pn.compression.bias, gbc)]
+        else:                                                       # compression is nn.Identity(): heads one for one
+            for head, name in ((pn.prior_mean_layer, "z_mean_layer"), (pn.prior_logvar_layer, "z_log_var_layer")):
+                pairs += [(head.weight, g[f"encoder.{name}.weight"]), (head.bias, g[f"encoder.{name}.bias"])]
         for p, gr in pairs:
             gr = (gr * weight if weight != 1.0 else gr).to(p.dtype).reshape(p.shape)
             p.grad = gr.clone() if p.grad is None else p.grad + gr

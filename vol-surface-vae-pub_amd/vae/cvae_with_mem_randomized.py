@@ -10,8 +10,8 @@ checkpoint compatibility, but their own forward() is never called.  There is no
 CPU fallback: calling a compute method without a GPU raises.
 
 Implemented topology (what the configs in the reference repo use): conv surface
-embedding, mem_type="lstm", compress_context=True, interaction_layers None / 1 / 2,
-ex_feats_hidden=None.  Other switches parse and then raise NotImplementedError
+embedding, mem_type="lstm" / "gru", compress_context True or False, interaction_layers
+None / 1 / 2, ex_feats_hidden=None.  Other switches parse and then raise NotImplementedError
 at the first compute call.
 """
 from __future__ import annotations
@@ -358,10 +358,10 @@ class CVAEMemRand(BaseVAE):
 
     def _decode(self, dec_in: torch.Tensor):
         eng = self._engine()
-        L = eng.L
+        Lc = eng.Lc                               # [context embedding | z], reference :707
         dec_in = dec_in.to(self.device)
         B, T = dec_in.shape[:2]
-        r = eng.decode(B, T, 0, ctx=dec_in[..., :L].contiguous(), zb=dec_in[..., L:].contiguous())
+        r = eng.decode(B, T, 0, ctx=dec_in[..., :Lc].contiguous(), zb=dec_in[..., Lc:].contiguous())
         dt = self._param_dtype()
         if eng.X > 0:
             return r["surf"].to(dt), r["ex"].to(dt)

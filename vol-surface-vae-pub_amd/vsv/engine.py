@@ -21,8 +21,6 @@ def dims_from_config(cfg: dict) -> _lib.VsvDims:
         raise NotImplementedError("HIP path implements mem_type 'lstm' and 'gru' (nn.RNN is not built)")
     if cfg.get("use_dense_surface", False):
         raise NotImplementedError("HIP path implements the conv surface embedding only")
-    if not cfg.get("compress_context", False):
-        raise NotImplementedError("HIP path implements compress_context=True only")
     if cfg.get("ex_feats_hidden") is not None or cfg.get("ctx_ex_feats_hidden") is not None:
         raise NotImplementedError("HIP path implements ex_feats_hidden=None only")
     if tuple(cfg["feat_dim"]) != (5, 5):
@@ -30,7 +28,7 @@ def dims_from_config(cfg: dict) -> _lib.VsvDims:
     dims = _lib.make_dims(cfg["latent_dim"], cfg["ex_feats_dim"], cfg["mem_hidden"], cfg["mem_layers"],
                           list(cfg["surface_hidden"]), list(cfg["ctx_surface_hidden"]),
                           len(cfg.get("quantiles", [0.05, 0.5, 0.95])), cfg.get("interaction_layers") or 0,
-                          cfg.get("mem_type", "lstm"))
+                          cfg.get("mem_type", "lstm"), bool(cfg.get("compress_context", False)))
     # shapes the kernels cannot run are refused here, when the model / Engine is built, not at the first launch
     L = _lib.load()
     if L.vsv_packed_floats(C.byref(dims)) == 0:
@@ -71,7 +69,8 @@ def pack_state_dict(dims: _lib.VsvDims, sd: Dict[str, np.ndarray]) -> np.ndarray
         raw.ctx_conv_w[i] = get(f"ctx_encoder.ctx_surface_embedding.ctx_enc_conv_{i}.weight")
         raw.ctx_conv_b[i] = get(f"ctx_encoder.ctx_surface_embedding.ctx_enc_conv_{i}.bias")
     lstm(raw.ctx_mem, "ctx_encoder.mem")
-    raw.ctx_comp_w, raw.ctx_comp_b = get("ctx_encoder.final_compression.weight"), get("ctx_encoder.final_compression.bias")
+    if dims.compress_context:
+        raw.ctx_comp_w, raw.ctx_comp_b = get("ctx_encoder.final_compression.weight"), get("ctx_encoder.final_compression.bias")
     lstm(raw.dec_mem, "decoder.mem")
     raw.dec_in_w, raw.dec_in_b = get("decoder.surface_decoder_input.weight"), get("decoder.surface_decoder_input.bias")
     names = [f"dec_deconv_{i}" for i in range(dims.n_conv - 1)] + ["dec_final"]
@@ -173,6 +172,11 @@ def build_gather_maps(dims: _lib.VsvDims, spec):
     assert off < 2 ** 24, "parameter count exceeds float32-exact index range"
     idx_a = pack_state_dict(dims, fake_a)
     idx_b = pack_state_dict(dims, fake_b)
+    # constants the packer writes whatever the parameters are (the identity "head" of an uncompressed context
+    # embedding): they are not gathers -- set_weights_from_params adds them from const_blob(dims)
+    const = pack_state_dict(dims, {k: np.zeros_like(v) for k, v in fake_a.items()})
+    idx_a[const != 0] = 0
+    idx_b[const != 0] = 0
     # the folded Linear . ConvT section is a PRODUCT of parameters, not a gather: nothing maps there
     # (set_weights_from_params computes it on the device, build_fold_maps)
     fm = build_fold_maps(dims)
@@ -180,6 +184,12 @@ def build_gather_maps(dims: _lib.VsvDims, spec):
         idx_a[lo:hi] = 0
         idx_b[lo:hi] = 0
     return idx_a.astype(np.int64), idx_b.astype(np.int64)
+
+
+def const_blob(dims: _lib.VsvDims, spec) -> Optional[np.ndarray]:
+    """The parameter-independent part of the packed blob (None when there is none)."""
+    c = pack_state_dict(dims, {name: np.zeros(shape, np.float32) for name, shape in spec})
+    return c if np.any(c != 0) else None
 
 
 def _ptr(t: Optional[torch.Tensor]):
@@ -202,12 +212,15 @@ class Engine:
                                "there is no CPU fallback")
         self.dims = dims_from_config(cfg)
         self.L = self.dims.latent_dim
+        # width of the context embedding: latent_dim with compress_context, else the context memory's hidden size
+        self.Lc = self.L if self.dims.compress_context else self.dims.mem_hidden
         self.X = self.dims.ex_feats_dim
         self.Q = self.dims.n_quantiles
         self.state_floats = int(self.lib.vsv_state_floats(C.byref(self.dims)))
         self.gate_floats = int(self.lib.vsv_gate_floats(C.byref(self.dims)))
         self.packed = None
         self._maps = None
+        self._const = None
         self._fold = None
         self._side = None
         if state_dict is not None:
@@ -228,9 +241,13 @@ class Engine:
             spec = [(n, tuple(p.shape)) for n, p in named_params]
             ia, ib = build_gather_maps(self.dims, spec)
             self._maps = (torch.from_numpy(ia).to(self.device), torch.from_numpy(ib).to(self.device))
+            cb = const_blob(self.dims, spec)
+            self._const = None if cb is None else torch.from_numpy(cb).to(self.device)
         flat = torch.cat([torch.zeros(1, dtype=torch.float32, device=self.device)] +
                          [p.reshape(-1).to(device=self.device, dtype=torch.float32) for _, p in named_params])
         packed = flat[self._maps[0]] + flat[self._maps[1]]
+        if self._const is not None:
+            packed = packed + self._const
         # generation's folded head layer: (first ConvT) . (Linear), two small matmuls on the gathered blob
         if self._fold is None:
             fm = build_fold_maps(self.dims)
@@ -274,7 +291,7 @@ class Engine:
         return self.encode_strided(which, surface, T * 25, 25, ex, T * self.X, self.X, B, T)
 
     def encode_strided(self, which, surf, surf_rs, surf_ts, ex, ex_rs, ex_ts, n_rows, T) -> torch.Tensor:
-        nh = self.L if which else 2 * self.L
+        nh = self.Lc if which else 2 * self.L
         out = torch.empty((n_rows, T, nh), dtype=torch.float32, device=self.device)
         nws = self.lib.vsv_encode_ws_bytes(C.byref(self.dims), n_rows, T)
         ws = self._ws(nws)
@@ -289,7 +306,7 @@ class Engine:
                      want_state=False):
         """vsv_encode_state: encoder `which` over T steps starting from state_in[row // state_div] (or the
         zero state) -> (out (n_rows, T, nh), state (n_rows, enc_state_floats) or None)."""
-        nh = self.L if which else 2 * self.L
+        nh = self.Lc if which else 2 * self.L
         out = torch.empty((n_rows, T, nh), dtype=torch.float32, device=self.device)
         st_out = None
         if want_state:
@@ -323,7 +340,7 @@ class Engine:
     def encode_from_pre(self, which, pre: torch.Tensor, n_rows, T, state_in=None, state_div=1):
         """vsv_encode_from_pre: encoder `which` over the T days whose tables are pre[0:T] (T, table floats)."""
         assert pre.is_contiguous() and pre.shape[0] >= T and pre[0].numel() == self.pre_table_floats(n_rows)
-        nh = self.L if which else 2 * self.L
+        nh = self.Lc if which else 2 * self.L
         out = torch.empty((n_rows, T, nh), dtype=torch.float32, device=self.device)
         ws = self._ws(self.lib.vsv_encode_from_pre_ws_bytes(C.byref(self.dims), n_rows, T))
         with torch.cuda.device(self.device):
@@ -357,7 +374,7 @@ class Engine:
         """Encoder `which` over the overlapping windows vol[r : r + T] (r < n_windows) of a contiguous
         calendar series vol (>= n_windows + T - 1, 5, 5) [, ex (.., X)]: vsv_encode_windows(_state).
         state_in (n_windows, enc_state_floats): continue from it; want_state: -> (out, state)."""
-        nh = self.L if which else 2 * self.L
+        nh = self.Lc if which else 2 * self.L
         out = torch.empty((n_windows, T, nh), dtype=torch.float32, device=self.device)
         ws = self._ws(self.lib.vsv_encode_windows_ws_bytes(C.byref(self.dims), n_windows, T))
         st_out = None
@@ -388,7 +405,7 @@ class Engine:
         return ws
 
     def encode_windows_layer1(self, which, n_windows, T, state_in, state_out, ws):
-        nh = self.L if which else 2 * self.L
+        nh = self.Lc if which else 2 * self.L
         out = torch.empty((n_windows, T, nh), dtype=torch.float32, device=self.device)
         with torch.cuda.device(self.device):
             rc = self.lib.vsv_encode_windows_layer1(C.byref(self.dims), _ptr(self.packed), which, n_windows, T,
@@ -401,7 +418,7 @@ class Engine:
         """Layer `layer` of the decoder's context prefix over (ctx_t, z_mean_t) (ctx, zb: (n_rows, T, L))."""
         din = _lib.VsvDecodeIn()
         if layer == 0:
-            din.ctx, din.ctx_rs, din.ctx_T, din.ctx_div = ctx.data_ptr(), T * self.L, T, 1
+            din.ctx, din.ctx_rs, din.ctx_T, din.ctx_div = ctx.data_ptr(), T * self.Lc, T, 1
             din.zb, din.z_rs, din.z_T, din.z_div = zb.data_ptr(), T * self.L, T, 1
         din.S, din.state_div = 1, 1
         if state_in is not None:
@@ -477,7 +494,8 @@ class Engine:
         din = _lib.VsvDecodeIn()
         if ctx is not None:
             ctx = _f32c(ctx, self.device)
-            din.ctx, din.ctx_rs, din.ctx_T, din.ctx_div = ctx.data_ptr(), ctx.shape[1] * self.L, ctx.shape[1], ctx_div
+            assert ctx.shape[-1] == self.Lc
+            din.ctx, din.ctx_rs, din.ctx_T, din.ctx_div = ctx.data_ptr(), ctx.shape[1] * self.Lc, ctx.shape[1], ctx_div
         else:
             din.ctx_div = 1
         if zb is not None:

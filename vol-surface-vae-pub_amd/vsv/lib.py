@@ -23,6 +23,7 @@ class VsvDims(C.Structure):
         ("mem_layers", C.c_int), ("n_conv", C.c_int), ("surface_hidden", C.c_int * VSV_MAX_CONV),
         ("n_ctx_conv", C.c_int), ("ctx_surface_hidden", C.c_int * VSV_MAX_CONV),
         ("n_quantiles", C.c_int), ("interaction_layers", C.c_int), ("mem_type", C.c_int),
+        ("compress_context", C.c_int),
     ]
 
 
@@ -185,7 +186,7 @@ SIGNATURES = {
                                  C.c_int, C.c_long, C.c_void_p, C.c_void_p]),
     "vsv_profile_next_decode": (None, [C.c_void_p, C.c_void_p]),
     "vsv_reparam_backward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
-                                       C.c_long, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
+                                       C.c_long, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
     "vsv_dropout_mask": (C.c_int, [C.c_float, C.c_uint64, C.c_int, C.c_int, C.c_long, C.c_int, C.c_int,
                                    C.c_void_p, C.c_void_p]),
     "vsv_train_encode": (C.c_int, [C.POINTER(VsvDims), C.c_void_p, C.c_int,
@@ -228,7 +229,7 @@ def load() -> C.CDLL:
             fn = getattr(lib, name)
             fn.restype = res
             fn.argtypes = args
-        if lib.vsv_abi_version() != 16:
+        if lib.vsv_abi_version() != 17:
             raise RuntimeError("libvsv_hip.so ABI version mismatch")
         _lib = lib
     return _lib
@@ -247,8 +248,9 @@ def check(rc: int, what: str) -> None:
 
 
 def make_dims(latent_dim, ex_feats_dim, mem_hidden, mem_layers, surface_hidden, ctx_surface_hidden,
-              n_quantiles, interaction_layers=0, mem_type="lstm") -> VsvDims:
+              n_quantiles, interaction_layers=0, mem_type="lstm", compress_context=True) -> VsvDims:
     d = VsvDims()
+    d.compress_context = int(bool(compress_context))
     if mem_type not in ("lstm", "gru"):
         raise NotImplementedError("HIP path implements mem_type 'lstm' and 'gru' (nn.RNN is not built)")
     d.mem_type = 1 if mem_type == "gru" else 0

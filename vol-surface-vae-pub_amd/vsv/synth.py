@@ -96,9 +96,13 @@ def state_dict_spec(cfg: dict) -> List[Tuple[str, Tuple[int, ...]]]:
     conv_stack("ctx_encoder.ctx_surface_embedding", [f"ctx_enc_conv_{i}" for i in range(len(csh))], csh, 1)
     interaction("ctx_encoder", "ctx", Ec)
     lstm("ctx_encoder.mem", Ec, Hm)
-    spec += [("ctx_encoder.final_compression.weight", (L, Hm)),
-             ("ctx_encoder.final_compression.bias", (L,))]
-    lstm("decoder.mem", 2 * L, Hd)
+    # final_compression is nn.Identity() without compress_context (:225-228); the decoder then takes the
+    # context memory's hidden state next to z (:363-366)
+    Lc = L if cfg.get("compress_context", False) else Hm
+    if cfg.get("compress_context", False):
+        spec += [("ctx_encoder.final_compression.weight", (L, Hm)),
+                 ("ctx_encoder.final_compression.bias", (L,))]
+    lstm("decoder.mem", Lc + L, Hd)
     interaction("decoder", "dec", Hd)
     spec += [("decoder.surface_decoder_input.weight", (sh[-1] * 25, Hd)),
              ("decoder.surface_decoder_input.bias", (sh[-1] * 25,))]

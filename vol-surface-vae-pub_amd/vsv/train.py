@@ -132,6 +132,7 @@ class TrainEngine:
         # dense chain in front of each encoder's LSTM: conv layers [+ interaction Linears]
         self.n_conv = [lay["enc"][0]["n_chain"], lay["enc"][1]["n_chain"]]
         self.L, self.X, self.Q = eng.L, eng.X, eng.Q
+        self.Lc = eng.Lc
         self.Hm = eng.dims.mem_hidden
         NTm, NTd = lay["NTm"], lay["NTd"]
         # ---- backward blob
@@ -150,7 +151,7 @@ class TrainEngine:
                 bb.add(f"e{w}.hh1", e["lstm"][1], 4 * NTm, 4 * NTm, "unit", 4)
             bb.add(f"e{w}.head", e["head"], 0, 4 * NTm, "unit", 4)
         d = lay["dec"]
-        bb.add("d.in0", d["lstm"][0], 0, d["kx"], "nat", 1)
+        bb.add("d.in0", d["lstm"][0], 0, d["kx"], "nat", (eng.Lc + eng.L + 31) // 32)
         bb.add("d.hh0", d["lstm"][0], d["kx"], 4 * NTd, "unit", 4)
         if self.NL == 2:
             bb.add("d.in1", d["lstm"][1], 0, 4 * NTd, "unit", 4)
@@ -452,7 +453,7 @@ class TrainEngine:
                 setattr(s, k, v.data_ptr())
             self._set_drop(c, s, sv_d, NI, NTd, 2)
             din = _lib.VsvDecodeIn()
-            din.ctx, din.ctx_rs, din.ctx_T, din.ctx_div = ctx_out.data_ptr(), Cc * L, Cc, 1
+            din.ctx, din.ctx_rs, din.ctx_T, din.ctx_div = ctx_out.data_ptr(), Cc * self.Lc, Cc, 1
             din.zb, din.lv, din.z_rs, din.z_T, din.z_div = zm.data_ptr(), zl.data_ptr(), T * L, T, 1
             din.mu0, din.std0 = 0.0, 1.0
             if eps is not None:
@@ -510,16 +511,17 @@ class TrainEngine:
             for li, g in gs:
                 self._acc_layer(c, hd[li], g[:, : 16 * hd[li].nt], sv_d["head_acts"][li][:, : 4 * hd[li].nq])
             # decoder LSTM
-            dx = self._e(B, T, 2 * L)
-            dg = self._lstm_bwd(c, "d", lay["Hd"], NTd, sv_d, T, c.Cn, dh_top, 1, 2, dx_rows=dx, dx_f=2 * L)
+            Lc = self.Lc
+            dx = self._e(B, T, Lc + L)
+            dg = self._lstm_bwd(c, "d", lay["Hd"], NTd, sv_d, T, c.Cn, dh_top, (Lc + L + 31) // 32, 2, dx_rows=dx, dx_f=Lc + L)
             self._lstm_wgrads(c, gp, d["lstm"], sv_d, dg, T, NTd, sv_d["xe"])
             # reparameterisation (:199) and the context embedding: one launch (vsv_reparam_backward)
-            d_enc, d_ctx = self._e(B, T, 2 * L), self._e(B, Cn, L)
+            d_enc, d_ctx = self._e(B, T, 2 * L), self._e(B, Cn, Lc)
             f32 = lambda t: None if t is None else t.to(dev, torch.float32).contiguous()
             d_zm, d_zl, d_z = f32(d_zm), f32(d_zl), f32(d_z)
             mask = None if c.ctx_mask is None else c.ctx_mask.reshape(B, Cn).contiguous()
             _lib.check(self.lib.vsv_reparam_backward(dx.data_ptr(), z.data_ptr(), zm.data_ptr(), _ptr(d_zm), _ptr(d_zl),
-                                                     _ptr(d_z), _ptr(mask), B, T, Cn, L, d_enc.data_ptr(),
+                                                     _ptr(d_z), _ptr(mask), B, T, Cn, L, Lc, d_enc.data_ptr(),
                                                      d_ctx.data_ptr(), self._stream()), "vsv_reparam_backward")
             side.wait_stream(main)
             with torch.cuda.stream(side):

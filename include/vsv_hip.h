@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define VSV_ABI_VERSION 17
+#define VSV_ABI_VERSION 18
 #define VSV_MAX_CONV 4
 #define VSV_MAX_CHAIN 8
 #define VSV_MAX_INTERACT 3
@@ -471,6 +471,24 @@ int vsv_loss_grad(const vsv_loss *d, void *stream);
 int vsv_reparam_backward(const float *dx, const float *z, const float *zm, const float *d_zm, const float *d_zl,
                          const float *d_z, const float *ctx_mask, long B, int T, int Tc, int L, int Lc,
                          float *d_enc, float *d_ctx, void *stream);
+
+/* Live nn.Parameters <-> packed blob on the device, one launch each way (train_step re-packs after every
+ * optimizer step, reference :1131, and needs the parameters' gradients, :1127 loss.backward()).
+ * vsv_pack_params: packed[i] = cst[i] + P(map_a[i]) + P(map_b[i]); a map entry is ((tensor + 1) << 24 | element),
+ *   0 = nothing; P reads param_ptrs[tensor][element] (param_ptrs: DEVICE array of the float32 tensors' addresses;
+ *   map_b carries the b_hh half of the b_ih + b_hh sums; cst, the parameter-independent part, may be NULL).  The
+ *   maps are what vsv_pack_weights does to a state_dict, as indices (vsv/engine.py::build_gather_maps).
+ * vsv_param_grads: flat[j] = sum_{k in [row_ptr[j], row_ptr[j+1])} gp[cols[k]]  (j over the n parameter elements in
+ *   state_dict order, cols ascending: a fixed summation order) and partials[b] = sum of squares of workgroup b's 256
+ *   elements (ceil(n / 256) floats) for the clip.
+ * vsv_clip_grad_norm: torch.nn.utils.clip_grad_norm_(max_norm) (reference :1129) on that flat gradient in place:
+ *   coef = min(1, max_norm / (sqrt(sum partials) + 1e-6)); norm_out (may be NULL) gets the norm. */
+int vsv_pack_params(const void *const *param_ptrs, const unsigned *map_a, const unsigned *map_b, const float *cst,
+                    float *packed, long n, void *stream);
+int vsv_param_grads(const float *gp, const int *row_ptr, const int *cols, long n, float *flat, float *partials,
+                    void *stream);
+int vsv_clip_grad_norm(float *flat, long n, const float *partials, int n_partials, float max_norm, float *norm_out,
+                       void *stream);
 
 /* The dropout factors (0 or 1/(1-p)) the training kernels apply to layer `layer`'s output of
  * LSTM `id`: out (n_rows, T, hidden).  Test / debugging aid: the reference draws its masks from

@@ -3489,6 +3489,34 @@ extern "C" int vsv_philox_normal(uint64_t seed, long day0, long n_days, long S, 
     return launch_check("philox_normal_kernel");
 }
 
+// The decoder memory's input [ctx_pad | z] of every (row, step) in the tile-B layout the training kernels save
+// (sv_x: [inst = rowtile*T + t][kx slots][64], slot s of lane hh*32 + r = feature 2s + hh of row 32*rowtile + r),
+// with the reparameterised z written to z_out: what lstm_kernel<.., XMODE 1> assembles on its time loop, as one
+// launch of its own, so that the decoder's first layer can run as a pre-activation GEMM (lstm_pre_kernel) and the
+// register-resident recurrent launch (lstm_rec_kernel) like every other layer of a training step.
+__global__ void __launch_bounds__(256) decoder_input_kernel(const LstmSeqArgs a) {
+    const long total = a.n_rowtiles * a.T * a.kx * 64;
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    const int lane = (int)(i & 63);
+    const int s = (int)((i >> 6) % a.kx);
+    const long inst = (i >> 6) / a.kx;
+    const int t = (int)(inst % a.T);
+    const long rowtile = inst / a.T;
+    const long row_raw = rowtile * 32 + (lane & 31);
+    const bool row_ok = row_raw < a.n_rows;
+    const long row = row_ok ? row_raw : a.n_rows - 1;
+    const vsv_decode_in& d = a.din;
+    DecIn di = {};
+    const long day_rel = row / d.S;
+    if (d.ctx) di.ctx = d.ctx + (row / d.ctx_div) * d.ctx_rs;
+    if (d.zb) di.z_idx = (row / d.z_div) * d.z_rs;
+    di.eps = d.eps_in ? d.eps_in + (size_t)row * d.eps_T * a.L : nullptr;
+    di.sample = (uint32_t)(row - day_rel * d.S);
+    di.day = (uint32_t)d.day0 + (uint32_t)day_rel;
+    a.sv_x[i] = decoder_input(a, di, row, row_ok, true, t, 2 * s + (lane >> 5));
+}
+
 // ---------------------------------------------------------------------------
 // training entry points
 // ---------------------------------------------------------------------------
@@ -3588,11 +3616,27 @@ extern "C" int vsv_train_decode(const vsv_dims* dims, const float* packed, const
     if (int rcd = fill_dropout(l, sv, lay.NL, "vsv_train_decode")) return rcd;
     int rc;
     if (per_layer_forward(lay.NL, rt)) {
-        // layer 0 keeps its (narrow) input product: the latent draw is assembled inside the kernel
         const int NT = lay.NTd;
-        LstmSeqArgs r0 = l;
-        r0.sv_nl = 2; r0.sv_l0 = 0; r0.hout = nullptr;
-        rc = launch_lstm<1>(r0, NT, 1, false, st);
+        static const bool l0_fused = [] { const char* e = getenv("VSV_DEC_L0_PRE"); return e && e[0] == '0'; }();
+        if (l0_fused || rt * T * dc.kx * 64 > 0x7fffffffL * 256) {
+            // layer 0 keeps its (narrow) input product: the latent draw is assembled inside the kernel
+            LstmSeqArgs r0 = l;
+            r0.sv_nl = 2; r0.sv_l0 = 0; r0.hout = nullptr;
+            rc = launch_lstm<1>(r0, NT, 1, false, st);
+        } else {
+            // input assembly, pre-activation GEMM and the recurrent-only launch, like layer 1
+            const long total = rt * T * dc.kx * 64;
+            hipLaunchKernelGGL(decoder_input_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, l);
+            rc = launch_check("decoder_input_kernel");
+            if (rc) return rc;
+            rc = launch_lstm_pre(NT, l.w[0], l.b[0], dc.kx >> 2, sv->xe, (long)dc.kx * 64, sv->gates, (long)lay.NL * 16 * NT * 64,
+                                 rt * T, st);
+            if (rc) return rc;
+            LstmSeqArgs r0 = l;
+            r0.rec = 1; r0.sv_nl = 2; r0.sv_l0 = 0; r0.hout = nullptr;
+            r0.z_out = nullptr; r0.sv_x = nullptr;
+            rc = launch_lstm<0>(r0, NT, 1, false, st);
+        }
         if (rc) return rc;
         const float* x = l.sv_hd ? l.sv_hd : sv->h;
         const long xs = l.sv_hd ? (long)4 * NT * 64 : (long)lay.NL * 4 * NT * 64;
@@ -3894,6 +3938,92 @@ extern "C" int vsv_reparam_backward(const float* dx, const float* z, const float
     hipLaunchKernelGGL(reparam_bwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, dx, z, zm, d_zm, d_zl, d_z,
                        ctx_mask, B, T, Tc, L, Lc, d_enc, d_ctx);
     return launch_check("reparam_bwd_kernel");
+}
+
+// ---- live parameters <-> packed blob, on the device ------------------------------------------------------------
+// A training step re-packs the blob from the nn.Parameters after every optimizer step and turns the blob's gradient
+// back into parameter gradients.  Both are pure index maps (vsv/engine.py::build_gather_maps); as torch index ops
+// they cost ~10 launches each way.  Here: one launch each, the parameters addressed through a device table of their
+// data pointers.  A map entry is (tensor << 24 | element), 0 = nothing.
+__global__ void __launch_bounds__(256) pack_params_kernel(const float* const* __restrict__ ptrs, const unsigned* __restrict__ map_a,
+                                                          const unsigned* __restrict__ map_b, const float* __restrict__ cst,
+                                                          float* __restrict__ packed, long n) {
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+        const unsigned a = map_a[i], b = map_b[i];
+        float v = cst ? cst[i] : 0.0f;
+        if (a) v += ptrs[(a >> 24) - 1][a & 0xffffffu];
+        if (b) v += ptrs[(b >> 24) - 1][b & 0xffffffu];
+        packed[i] = v;
+    }
+}
+
+extern "C" int vsv_pack_params(const void* const* param_ptrs, const unsigned* map_a, const unsigned* map_b, const float* cst,
+                               float* packed, long n, void* stream) {
+    if (!param_ptrs || !map_a || !map_b || !packed || n < 1) { set_error("vsv_pack_params: null pointer or empty blob"); return -1; }
+    const unsigned blocks = (unsigned)((n + 255) / 256 > 2048 ? 2048 : (n + 255) / 256);
+    hipLaunchKernelGGL(pack_params_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const float* const*)param_ptrs,
+                       map_a, map_b, cst, packed, n);
+    return launch_check("pack_params_kernel");
+}
+
+// Parameter gradients from the blob's gradient: flat[j] = sum of gp over the blob positions parameter element j was
+// packed to (CSR rows in ascending blob position: a fixed summation order, unlike an atomic scatter), and per
+// workgroup the sum of squares of what it wrote, for the gradient-norm clip.
+__global__ void __launch_bounds__(256) param_grads_kernel(const float* __restrict__ gp, const int* __restrict__ row_ptr,
+                                                          const int* __restrict__ cols, long n, float* __restrict__ flat,
+                                                          float* __restrict__ partials) {
+    __shared__ float red[4];
+    const long j = (long)blockIdx.x * 256 + threadIdx.x;
+    float g = 0.0f;
+    if (j < n) {
+        const int e = row_ptr[j + 1];
+        for (int k = row_ptr[j]; k < e; ++k) g += gp[cols[k]];
+        flat[j] = g;
+    }
+    float q = g * g;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) q += __shfl_xor(q, o, 64);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = q;
+    __syncthreads();
+    if (threadIdx.x == 0) partials[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+extern "C" int vsv_param_grads(const float* gp, const int* row_ptr, const int* cols, long n, float* flat, float* partials,
+                               void* stream) {
+    if (!gp || !row_ptr || !cols || !flat || !partials || n < 1) { set_error("vsv_param_grads: null pointer or no parameters"); return -1; }
+    if ((n + 255) / 256 > 0x7fffffffL) { set_error("vsv_param_grads: too many parameters"); return -2; }
+    hipLaunchKernelGGL(param_grads_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, gp, row_ptr, cols,
+                       n, flat, partials);
+    return launch_check("param_grads_kernel");
+}
+
+// clip_grad_norm_ (reference :1129) on the flat gradient: every workgroup adds the n_partials partial sums of squares
+// in the same order (so all of them get the same coefficient, run to run), then scales its share in place by
+// min(1, max_norm / (norm + 1e-6)).  norm_out (may be null) receives the total norm.
+__global__ void __launch_bounds__(256) clip_scale_kernel(float* __restrict__ flat, long n, const float* __restrict__ partials,
+                                                         int n_partials, float max_norm, float* __restrict__ norm_out) {
+    __shared__ float red[4];
+    float q = 0.0f;
+    for (int i = threadIdx.x; i < n_partials; i += 256) q += partials[i];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) q += __shfl_xor(q, o, 64);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = q;
+    __syncthreads();
+    const float norm = sqrtf((red[0] + red[1]) + (red[2] + red[3]));
+    if (norm_out && blockIdx.x == 0 && threadIdx.x == 0) *norm_out = norm;
+    const float coef = fminf(max_norm / (norm + 1e-6f), 1.0f);
+    if (coef < 1.0f)
+        for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) flat[i] *= coef;
+}
+
+extern "C" int vsv_clip_grad_norm(float* flat, long n, const float* partials, int n_partials, float max_norm, float* norm_out,
+                                  void* stream) {
+    if (!flat || !partials || n < 1 || n_partials < 1) { set_error("vsv_clip_grad_norm: null pointer or empty"); return -1; }
+    if (!(max_norm > 0.0f)) { set_error("vsv_clip_grad_norm: max_norm must be positive"); return -1; }
+    const unsigned blocks = (unsigned)((n + 255) / 256 > 256 ? 256 : (n + 255) / 256);
+    hipLaunchKernelGGL(clip_scale_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, flat, n, partials, n_partials, max_norm,
+                       norm_out);
+    return launch_check("clip_scale_kernel");
 }
 
 extern "C" int vsv_loss_grad(const vsv_loss* d, void* stream) {

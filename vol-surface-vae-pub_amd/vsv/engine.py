@@ -6,6 +6,7 @@ of libvsv_hip.so; nothing in this module computes on the CPU.
 from __future__ import annotations
 
 import ctypes as C
+import os
 from typing import Dict, Optional, Sequence
 
 import numpy as np
@@ -233,9 +234,9 @@ class Engine:
         self._fold_stale = False                               # (the host packer writes the folded section itself)
 
     def set_weights_from_params(self, named_params) -> torch.Tensor:
-        """Device-side packing of live nn.Parameters: two gathers through the index
-        maps of build_gather_maps (differentiable, so gradients w.r.t. the packed
-        blob flow back to the parameters)."""
+        """Device-side packing of live nn.Parameters through the index maps of build_gather_maps: one launch of
+        vsv_pack_params reading the float32 tensors in place through a device table of their addresses
+        (VSV_NATIVE_PACK=0, other dtypes / devices: torch.cat and two index gathers)."""
         named_params = list(named_params)
         if self._maps is None:
             spec = [(n, tuple(p.shape)) for n, p in named_params]
@@ -243,11 +244,43 @@ class Engine:
             self._maps = (torch.from_numpy(ia).to(self.device), torch.from_numpy(ib).to(self.device))
             cb = const_blob(self.dims, spec)
             self._const = None if cb is None else torch.from_numpy(cb).to(self.device)
-        flat = torch.cat([torch.zeros(1, dtype=torch.float32, device=self.device)] +
-                         [p.reshape(-1).to(device=self.device, dtype=torch.float32) for _, p in named_params])
-        packed = flat[self._maps[0]] + flat[self._maps[1]]
-        if self._const is not None:
-            packed = packed + self._const
+            # the same maps as (tensor + 1) << 24 | element for the one-launch native gather (vsv_pack_params)
+            sizes = np.array([int(np.prod(s)) for _, s in spec], dtype=np.int64)
+            self._pmaps = None
+            if len(spec) < 255 and int(sizes.max()) < (1 << 24):
+                starts = np.concatenate([[1], 1 + np.cumsum(sizes)])
+                enc = []
+                for m in (ia, ib):
+                    t = np.searchsorted(starts, m, side="right") - 1          # tensor of a 1-based flat offset
+                    e = ((t + 1) << 24) | (m - starts[np.clip(t, 0, len(sizes) - 1)])
+                    enc.append(torch.from_numpy(np.where(m == 0, 0, e).astype(np.uint32).view(np.int32)).to(self.device))
+                self._pmaps = tuple(enc)
+            self._ptr_key, self._ptr_tab = None, None
+        ts = [p for _, p in named_params]
+        native = (self._pmaps is not None and os.environ.get("VSV_NATIVE_PACK", "1") != "0" and
+                  all(p.device == self.device and p.dtype == torch.float32 and p.is_contiguous() for p in ts))
+        if native:
+            key = tuple(p.data_ptr() for p in ts)
+            if key != self._ptr_key:
+                if torch.cuda.is_current_stream_capturing():
+                    native = False                                 # (the table upload is a host copy: not inside a capture)
+                else:
+                    self._ptr_tab = torch.tensor(key, dtype=torch.int64).to(self.device)
+                    self._ptr_key = key
+        if native:
+            n = self._maps[0].numel()
+            packed = torch.empty(n, dtype=torch.float32, device=self.device)
+            rc = self.lib.vsv_pack_params(self._ptr_tab.data_ptr(), self._pmaps[0].data_ptr(), self._pmaps[1].data_ptr(),
+                                          None if self._const is None else self._const.data_ptr(), packed.data_ptr(), n,
+                                          self._stream())
+            if rc != 0:
+                raise RuntimeError("vsv_pack_params: " + self.lib.vsv_last_error().decode())
+        else:
+            flat = torch.cat([torch.zeros(1, dtype=torch.float32, device=self.device)] +
+                             [p.reshape(-1).to(device=self.device, dtype=torch.float32) for _, p in named_params])
+            packed = flat[self._maps[0]] + flat[self._maps[1]]
+            if self._const is not None:
+                packed = packed + self._const
         # generation's folded head layer: (first ConvT) . (Linear), two small matmuls on the gathered blob
         if self._fold is None:
             fm = build_fold_maps(self.dims)

@@ -47,6 +47,7 @@ class GraphedLossGrads:
         with torch.cuda.graph(self.graph, capture_error_mode="thread_local"):
             self.loss_vec, self.grads, self.packed = self._body()
         self.flat = te.last_flat                 # the gradients are views of this static buffer
+        self.partials = te.last_partials         # (its sums of squares per 256 elements, for the clip)
 
     def _body(self):
         te, eng = self.te, self.eng
@@ -75,7 +76,7 @@ class GraphedLossGrads:
         self.eng._fold_stale = True              # (generation's folded head section is rebuilt on demand)
         v = self.loss_vec.clone()
         losses = {"loss": v[0], "re_surface": v[1], "re_ex_feats": v[2], "reconstruction_loss": v[3], "kl_loss": v[4]}
-        self.te.last_flat = self.flat
+        self.te.last_flat, self.te.last_partials = self.flat, self.partials
         return losses, self.grads
 
 

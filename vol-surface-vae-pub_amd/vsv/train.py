@@ -174,6 +174,16 @@ class TrainEngine:
         self._idx_b = torch.from_numpy(ib[nz]).to(self.dev)
         self._sizes = [int(np.prod(s)) for _, s in named_shapes]
         self._shapes = [tuple(s) for _, s in named_shapes]
+        # the same maps inverted to CSR rows per parameter element (columns = blob positions, ascending) for the
+        # one-launch gather vsv_param_grads
+        pa, pb = np.nonzero(ia)[0], nz
+        par = np.concatenate([ia[pa], ib[pb]]) - 1
+        pos = np.concatenate([pa, pb])
+        order = np.lexsort((pos, par))
+        counts = np.bincount(par, minlength=n_par)
+        self._row_ptr = torch.from_numpy(np.concatenate([[0], np.cumsum(counts)]).astype(np.int32)).to(self.dev)
+        self._cols = torch.from_numpy(pos[order].astype(np.int32)).to(self.dev)
+        self.last_partials = None
 
     # -- helpers -----------------------------------------------------------------------
     def _stream(self):
@@ -681,9 +691,19 @@ class TrainEngine:
     def param_grads(self, gp: torch.Tensor) -> List[torch.Tensor]:
         """gradient w.r.t. the packed blob -> gradients of the parameters (spec order)."""
         n = sum(self._sizes)
-        flat = torch.zeros(n + 1 + self._DUMP, dtype=torch.float32, device=self.dev)
-        flat.index_add_(0, self._idx_a, gp)
-        flat.index_add_(0, self._idx_b, gp[self._idx_b_pos])
+        if os.environ.get("VSV_NATIVE_PACK", "1") != "0" and gp.dtype == torch.float32 and gp.is_contiguous():
+            flat = torch.empty(n + 1, dtype=torch.float32, device=self.dev)
+            partials = torch.empty((n + 255) // 256, dtype=torch.float32, device=self.dev)
+            rc = self.lib.vsv_param_grads(gp.data_ptr(), self._row_ptr.data_ptr(), self._cols.data_ptr(), n,
+                                          flat.data_ptr() + 4, partials.data_ptr(), self._stream())
+            if rc != 0:
+                raise RuntimeError("vsv_param_grads: " + self.lib.vsv_last_error().decode())
+            self.last_partials = partials                        # sums of squares per 256 elements, for the clip
+        else:
+            flat = torch.zeros(n + 1 + self._DUMP, dtype=torch.float32, device=self.dev)
+            flat.index_add_(0, self._idx_a, gp)
+            flat.index_add_(0, self._idx_b, gp[self._idx_b_pos])
+            self.last_partials = None
         self.last_flat = flat[1:1 + n]                           # the returned gradients are views of this
         out, o = [], 1
         for sz, sh in zip(self._sizes, self._shapes):

@@ -490,6 +490,16 @@ int vsv_param_grads(const float *gp, const int *row_ptr, const int *cols, long n
 int vsv_clip_grad_norm(float *flat, long n, const float *partials, int n_partials, float max_norm, float *norm_out,
                        void *stream);
 
+/* torch.optim.AdamW.step() (the reference's optimizer.step(), :1131) for all parameters in one launch.
+ * params / exp_avg / exp_avg_sq: DEVICE arrays of n_tensors float32 tensor addresses (the optimizer's own state
+ * tensors, updated in place); grad_flat: the n gradient elements in tensor order (vsv_param_grads' output, after
+ * the clip); starts: n_tensors + 1 element offsets of the tensors in grad_flat (device).  step = the step count
+ * AFTER this step (>= 1).  Same operation order as torch's foreach implementation (decoupled weight decay, lerp,
+ * bias corrections as doubles); amsgrad / maximize are not built: the caller keeps torch's step() for those. */
+int vsv_adamw_step(void *const *params, void *const *exp_avg, void *const *exp_avg_sq, const float *grad_flat,
+                   const int *starts, int n_tensors, long n, double lr, double beta1, double beta2, double eps,
+                   double weight_decay, long step, void *stream);
+
 /* The dropout factors (0 or 1/(1-p)) the training kernels apply to layer `layer`'s output of
  * LSTM `id`: out (n_rows, T, hidden).  Test / debugging aid: the reference draws its masks from
  * torch's generator (inside nn.LSTM), so parity is checked with this mask injected into the

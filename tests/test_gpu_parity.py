@@ -925,3 +925,41 @@ def test_uncompressed_context_mc_product_and_model_class(mem, L, X):
     assert float(losses["loss"]) < first
     got2 = model.forward(x)
     assert got2[0].shape == (16, 1, 3, 5, 5)
+
+
+def test_one_launch_adamw_step_equals_torch_adamw():
+    """train_step's optimizer.step() runs as vsv_adamw_step when the optimizer is a plain torch.optim.AdamW over the
+    model's parameters: the parameters, the optimizer's exp_avg / exp_avg_sq and its step counts after several steps
+    against the same steps taken with torch's own step() (VSV_NATIVE_ADAMW=0), from the same seeds."""
+    from vae.cvae_with_mem_randomized import CVAEMemRand
+    rng = np.random.default_rng(3)
+    x = {"surface": torch.from_numpy((0.2 + 0.1 * rng.standard_normal((16, 9, 5, 5))).astype(np.float32)),
+         "ex_feats": torch.from_numpy((0.01 * rng.standard_normal((16, 9, 3))).astype(np.float32))}
+    runs = []
+    for native in ("1", "0"):
+        os.environ["VSV_NATIVE_ADAMW"] = native
+        try:
+            torch.manual_seed(4)
+            model = CVAEMemRand(vo.make_config(5, 3, device="cuda:0"))
+            opt = torch.optim.AdamW(model.parameters(), lr=1e-3, weight_decay=0.02)
+            for _ in range(6):
+                model.train_step(x, opt)
+            torch.cuda.synchronize()
+            runs.append(([p.detach().clone() for p in model.parameters()],
+                         [opt.state[p]["exp_avg"].clone() for p in model.parameters()],
+                         [opt.state[p]["exp_avg_sq"].clone() for p in model.parameters()],
+                         [float(opt.state[p]["step"]) for p in model.parameters()]))
+        finally:
+            os.environ.pop("VSV_NATIVE_ADAMW", None)
+    (pa, ma, va, sa), (pb, mb, vb, sb) = runs
+    assert sa == sb and set(sa) == {6.0}
+    for a, b in zip(pa, pb):
+        assert float((a - b).abs().max()) <= 2e-6 * max(1.0, float(b.abs().max()))
+    for a, b in zip(ma + va, mb + vb):
+        assert float((a - b).abs().max()) <= 1e-5 * max(1e-12, float(b.abs().max()))
+    # anything but the plain case keeps torch's step(): amsgrad here
+    model = CVAEMemRand(vo.make_config(5, 0, device="cuda:0"))
+    opt = torch.optim.AdamW(model.parameters(), lr=1e-3, amsgrad=True)
+    for _ in range(3):
+        model.train_step({"surface": x["surface"]}, opt)
+    assert "max_exp_avg_sq" in opt.state[next(model.parameters())]

@@ -3976,8 +3976,16 @@ __global__ void __launch_bounds__(256) param_grads_kernel(const float* __restric
     const long j = (long)blockIdx.x * 256 + threadIdx.x;
     float g = 0.0f;
     if (j < n) {
+        // (a conv tap sits at up to 25 blob positions: eight independent loads in flight, fixed order)
         const int e = row_ptr[j + 1];
-        for (int k = row_ptr[j]; k < e; ++k) g += gp[cols[k]];
+        int k = row_ptr[j];
+        for (; k + 8 <= e; k += 8) {
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = gp[cols[k + u]];
+            g += ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
+        }
+        for (; k < e; ++k) g += gp[cols[k]];
         flat[j] = g;
     }
     float q = g * g;
@@ -4024,6 +4032,62 @@ extern "C" int vsv_clip_grad_norm(float* flat, long n, const float* partials, in
     hipLaunchKernelGGL(clip_scale_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, flat, n, partials, n_partials, max_norm,
                        norm_out);
     return launch_check("clip_scale_kernel");
+}
+
+// torch.optim.AdamW's step (the reference's optimizer.step(), :1131, for the optimizer its trainers build) over all
+// parameters in one launch: the tensors (parameter, exp_avg, exp_avg_sq: the optimizer's own state, updated in
+// place) are addressed through device pointer tables, the gradient is the flat buffer vsv_param_grads wrote.  The
+// arithmetic follows torch's foreach implementation step by step:
+//   p *= 1 - lr * wd;  m += (g - m) * (1 - b1);  v = v * b2 + (1 - b2) * g * g;
+//   p += -step_size * (m / (sqrt(v) / bc2_sqrt + eps)),   step_size = lr / (1 - b1^t),  bc2_sqrt = sqrt(1 - b2^t)
+struct AdamwArgs {
+    float* const* p; float* const* m; float* const* v;
+    const float* grad; const int* starts; int n_tensors; long n;
+    float decay, w1, b2, w2, eps, neg_step_size, bc2_sqrt;
+};
+
+__global__ void __launch_bounds__(256) adamw_kernel(const AdamwArgs a) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= a.n) return;
+    int lo = 0, hi = a.n_tensors;                                  // starts[lo] <= i < starts[hi]
+    while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if ((long)a.starts[mid] <= i) lo = mid; else hi = mid;
+    }
+    const long o = i - a.starts[lo];
+    const float g = a.grad[i];
+    float p = a.p[lo][o], m = a.m[lo][o], v = a.v[lo][o];
+    p *= a.decay;
+    m = m + (g - m) * a.w1;
+    v = v * a.b2;
+    v = v + (a.w2 * g) * g;
+    const float denom = sqrtf(v) / a.bc2_sqrt + a.eps;
+    p = p + a.neg_step_size * (m / denom);
+    a.p[lo][o] = p; a.m[lo][o] = m; a.v[lo][o] = v;
+}
+
+extern "C" int vsv_adamw_step(void* const* params, void* const* exp_avg, void* const* exp_avg_sq, const float* grad_flat,
+                              const int* starts, int n_tensors, long n, double lr, double beta1, double beta2, double eps,
+                              double weight_decay, long step, void* stream) {
+    if (!params || !exp_avg || !exp_avg_sq || !grad_flat || !starts) { set_error("vsv_adamw_step: null pointer"); return -1; }
+    if (n_tensors < 1 || n < 1 || step < 1) { set_error("vsv_adamw_step: need tensors, elements and step >= 1"); return -1; }
+    if (!(lr >= 0.0) || !(beta1 >= 0.0 && beta1 < 1.0) || !(beta2 >= 0.0 && beta2 < 1.0) || !(eps >= 0.0) || !(weight_decay >= 0.0)) {
+        set_error("vsv_adamw_step: bad hyper-parameters"); return -1;
+    }
+    AdamwArgs a;
+    a.p = (float* const*)params; a.m = (float* const*)exp_avg; a.v = (float* const*)exp_avg_sq;
+    a.grad = grad_flat; a.starts = starts; a.n_tensors = n_tensors; a.n = n;
+    // (the scalars as torch computes them: Python doubles rounded to float where the foreach kernels take them)
+    const double bc1 = 1.0 - pow(beta1, (double)step), bc2 = 1.0 - pow(beta2, (double)step);
+    a.decay = (float)(1.0 - lr * weight_decay);
+    a.w1 = (float)(1.0 - beta1);
+    a.b2 = (float)beta2;
+    a.w2 = (float)(1.0 - beta2);
+    a.eps = (float)eps;
+    a.neg_step_size = (float)(-(lr / bc1));
+    a.bc2_sqrt = (float)sqrt(bc2);
+    hipLaunchKernelGGL(adamw_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a);
+    return launch_check("adamw_kernel");
 }
 
 extern "C" int vsv_loss_grad(const vsv_loss* d, void* stream) {

@@ -113,8 +113,9 @@ class CVAEMem(CVAEMemRand):
         """Reference :651-700: MSE + ex-feature + KL loss, backward, optimizer.step() -- no clipping."""
         optimizer.zero_grad()
         losses, gp = self._legacy_losses(x, True, _eps)
-        self._accumulate_grads(gp)
-        optimizer.step()
+        flat = self._accumulate_grads(gp)
+        if flat is None or not self._adamw_step_(optimizer, flat):
+            optimizer.step()
         return losses
 
     def test_step(self, x, _eps=None):

@@ -643,6 +643,80 @@ class CVAEMemRand(BaseVAE):
         total = torch.linalg.vector_norm(flat)
         flat.mul_(torch.clamp(max_norm / (total + 1e-6), max=1.0))
 
+    def _adamw_step_(self, optimizer, flat: torch.Tensor) -> bool:
+        """optimizer.step() (reference :1131) as ONE launch (vsv_adamw_step) when the optimizer is a plain
+        torch.optim.AdamW over exactly this model's parameters -- what every trainer of the reference builds --
+        updating the optimizer's own state tensors and step counts in place, so the optimizer object stays what
+        torch's step() would have left (state_dict, schedulers, a later torch step() all see the same state).
+        Anything else (other optimizers, amsgrad / maximize / capturable / fused, several parameter groups, hooks,
+        the first step, which creates the state) returns False and the caller runs optimizer.step().
+        VSV_NATIVE_ADAMW=0 turns it off."""
+        import os
+        import torch.optim.optimizer as _oo
+        if os.environ.get("VSV_NATIVE_ADAMW", "1") == "0" or type(optimizer) is not torch.optim.AdamW:
+            return False
+        if len(optimizer.param_groups) != 1 or optimizer._optimizer_step_pre_hooks or optimizer._optimizer_step_post_hooks \
+                or _oo._global_optimizer_pre_hooks or _oo._global_optimizer_post_hooks:
+            return False
+        g = optimizer.param_groups[0]
+        if g.get("amsgrad") or g.get("maximize") or g.get("capturable") or g.get("differentiable") or g.get("fused"):
+            return False
+        lr, (b1, b2) = g["lr"], g["betas"]
+        if not all(isinstance(v, (int, float)) for v in (lr, b1, b2, g["eps"], g["weight_decay"])):
+            return False
+        params = [p for _, p in self._hip_named_params()]
+        gp = g["params"]
+        if len(gp) != len(params) or any(a is not b for a, b in zip(gp, params)):
+            return False
+        st = optimizer.state
+        ms, vs, steps = [], [], []
+        for p in params:
+            s = st.get(p)
+            if not s or "exp_avg" not in s:
+                return False
+            ms.append(s["exp_avg"]); vs.append(s["exp_avg_sq"]); steps.append(s["step"])
+        dev = flat.device
+        if any(t.dtype != torch.float32 or t.device != dev or not t.is_contiguous() for t in params + ms + vs):
+            return False
+        if any(t.device.type != "cpu" for t in steps):
+            return False
+        step = float(steps[0])
+        if any(float(t) != step for t in steps[1:]) or step < 1 or step != int(step):
+            return False
+        te = self.__dict__["_vsv_train_engine"]
+        key = tuple(t.data_ptr() for t in params + ms + vs)
+        cache = self.__dict__.get("_vsv_adamw")
+        if cache is None or cache[0] != key:
+            n = len(params)
+            tab = torch.tensor(key, dtype=torch.int64).to(dev)
+            offs = [0]
+            for p in params:
+                offs.append(offs[-1] + p.numel())
+            starts = torch.tensor(offs, dtype=torch.int32).to(dev)
+            cache = (key, tab, starts, n)
+            self.__dict__["_vsv_adamw"] = cache
+        _, tab, starts, n = cache
+        if flat.numel() != int(sum(p.numel() for p in params)):
+            return False
+        base = tab.data_ptr()
+        rc = te.lib.vsv_adamw_step(base, base + 8 * n, base + 16 * n, flat.data_ptr(), starts.data_ptr(), n, flat.numel(),
+                                   float(lr), float(b1), float(b2), float(g["eps"]), float(g["weight_decay"]),
+                                   int(step) + 1, te._stream())
+        if rc != 0:
+            raise RuntimeError("vsv_adamw_step: " + te.lib.vsv_last_error().decode())
+        torch._foreach_add_(steps, 1)
+        # the tensors were written through their addresses: bump the version counters an in-place torch op would
+        # have bumped (the engine's re-pack test and autograd's saved-tensor checks read them)
+        touched = params + ms + vs
+        try:
+            torch._C._autograd._unsafe_set_version_counter(touched, [t._version + 1 for t in touched])
+        except (AttributeError, TypeError, RuntimeError):
+            pass
+        self.__dict__["_vsv_key"] = None
+        if hasattr(optimizer, "_opt_called"):
+            optimizer._opt_called = True                           # (what LRScheduler's wrapper of step() records)
+        return True
+
     def test_step(self, x):
         """Reference :1265-1308: forward + losses, returns a dict of tensors."""
         return self._loss_terms(x, self.horizon, False)[0]
@@ -659,7 +733,8 @@ class CVAEMemRand(BaseVAE):
             self._clip_flat_(flat, 1.0)
         else:
             torch.nn.utils.clip_grad_norm_(self.parameters(), max_norm=1.0)
-        optimizer.step()
+        if flat is None or not self._adamw_step_(optimizer, flat):
+            optimizer.step()
         return losses
 
     def train_step_multihorizon(self, x, optimizer: torch.optim.Optimizer, horizons=[1, 7, 14, 30],
@@ -682,8 +757,9 @@ class CVAEMemRand(BaseVAE):
         losses, gp = te.loss_and_grads_multihorizon(
             surf, ex, list(horizons), [weights.get(h, 1.0) for h in horizons], self._loss_cfg(),
             eps=_eps_per_horizon, seed=self._draw_seed(), dropout_p=p, dropout_seed=self._draw_seed() if p > 0 else 0)
-        self._accumulate_grads(gp)
-        optimizer.step()
+        flat = self._accumulate_grads(gp)
+        if flat is None or not self._adamw_step_(optimizer, flat):
+            optimizer.step()
         # one read-back for all the reported numbers
         vals = torch.cat([torch.stack([losses["loss"], losses["reconstruction_loss"], losses["kl_loss"]]),
                           losses["horizon_losses"]]).tolist()

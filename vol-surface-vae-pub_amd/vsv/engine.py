@@ -222,6 +222,8 @@ class Engine:
         self.packed = None
         self._maps = None
         self._const = None
+        self._pmaps = None
+        self._from_params = False
         self._fold = None
         self._side = None
         if state_dict is not None:
@@ -231,6 +233,7 @@ class Engine:
         """Host packing through vsv_pack_weights (numpy state_dict)."""
         blob = pack_state_dict(self.dims, state_dict)
         self.packed = torch.from_numpy(blob).to(self.device)
+        self._from_params = False
         self._fold_stale = False                               # (the host packer writes the folded section itself)
 
     def set_weights_from_params(self, named_params) -> torch.Tensor:
@@ -275,7 +278,11 @@ class Engine:
                                           self._stream())
             if rc != 0:
                 raise RuntimeError("vsv_pack_params: " + self.lib.vsv_last_error().decode())
+            # the blob is a pure function of _ptr_tab's tensors; later gathers (gather_from_params) may read them
+            # again only if they all outlive this call: nn.Parameters, not expressions packed in a parameter's place
+            self._from_params = all(isinstance(p, torch.nn.Parameter) for p in ts)
         else:
+            self._from_params = False
             flat = torch.cat([torch.zeros(1, dtype=torch.float32, device=self.device)] +
                              [p.reshape(-1).to(device=self.device, dtype=torch.float32) for _, p in named_params])
             packed = flat[self._maps[0]] + flat[self._maps[1]]
@@ -291,6 +298,26 @@ class Engine:
         self.packed = packed.detach()
         self._fold_stale = True
         return packed
+
+    def gather_from_params(self, idx1: torch.Tensor, cache: dict) -> Optional[torch.Tensor]:
+        """blob_ext[idx1] with blob_ext = [0, packed...] (idx1: int64 positions, 0 = the zero slot), read straight
+        from the parameters by one vsv_pack_params launch through maps composed once (kept in `cache`); None
+        when the current blob was not packed from live float32 parameters."""
+        if not self._from_params or self._pmaps is None:
+            return None
+        m = cache.get("maps")
+        if m is None:
+            z = torch.zeros(1, dtype=torch.int32, device=self.device)
+            m = [torch.cat([z, pm])[idx1].contiguous() for pm in self._pmaps]
+            m.append(None if self._const is None else
+                     torch.cat([torch.zeros(1, dtype=torch.float32, device=self.device), self._const])[idx1].contiguous())
+            cache["maps"] = m
+        out = torch.empty(idx1.numel(), dtype=torch.float32, device=self.device)
+        rc = self.lib.vsv_pack_params(self._ptr_tab.data_ptr(), m[0].data_ptr(), m[1].data_ptr(),
+                                      None if m[2] is None else m[2].data_ptr(), out.data_ptr(), out.numel(), self._stream())
+        if rc != 0:
+            raise RuntimeError("vsv_pack_params: " + self.lib.vsv_last_error().decode())
+        return out
 
     def _ensure_fold(self) -> None:
         """The folded (first ConvT) . (Linear) section of a blob packed from live parameters, on demand."""

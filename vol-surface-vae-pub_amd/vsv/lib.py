@@ -190,6 +190,8 @@ SIGNATURES = {
     "vsv_pack_params": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_long, C.c_void_p]),
     "vsv_param_grads": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_long, C.c_void_p, C.c_void_p, C.c_void_p]),
     "vsv_clip_grad_norm": (C.c_int, [C.c_void_p, C.c_long, C.c_void_p, C.c_int, C.c_float, C.c_void_p, C.c_void_p]),
+    "vsv_adamw_step": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_long,
+                                 C.c_double, C.c_double, C.c_double, C.c_double, C.c_double, C.c_long, C.c_void_p]),
     "vsv_dropout_mask": (C.c_int, [C.c_float, C.c_uint64, C.c_int, C.c_int, C.c_long, C.c_int, C.c_int,
                                    C.c_void_p, C.c_void_p]),
     "vsv_train_encode": (C.c_int, [C.POINTER(VsvDims), C.c_void_p, C.c_int,

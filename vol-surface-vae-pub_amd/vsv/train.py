@@ -162,6 +162,7 @@ class TrainEngine:
         self.bb = bb
         idx = bb.index()
         self._bwd_idx = torch.from_numpy(np.where(idx < 0, 0, idx + 1)).to(self.dev)      # 0 -> the zero slot
+        self._bwd_cache = {}
         # ---- parameter scatter maps (same maps as the device-side packing)
         ia, ib = build_gather_maps(self.dims, list(named_shapes))
         # blob positions that hold no parameter (zero padding) are scattered over a dump region
@@ -277,8 +278,13 @@ class TrainEngine:
 
     def _blobT(self, c):
         if c.blobT is None:
-            ext = torch.cat([self._z(1), c.packed])
-            c.blobT = ext[self._bwd_idx]
+            # the backward kernels' transposed sections: a gather of the blob -- straight from the parameters when
+            # the blob was packed from them (one launch), else through the blob
+            if c.packed is self.eng.packed:
+                c.blobT = self.eng.gather_from_params(self._bwd_idx, self._bwd_cache)
+            if c.blobT is None:
+                ext = torch.cat([self._z(1), c.packed])
+                c.blobT = ext[self._bwd_idx]
         return c.blobT
 
     def _dense_bwd(self, c, layers, n_inst_T, in_mode, in_t, in_f, want_dx):

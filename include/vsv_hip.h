@@ -51,7 +51,7 @@ typedef struct vsv_dims {
     int ctx_surface_hidden[VSV_MAX_CONV];
     int n_quantiles;                   /* Q = len(config["quantiles"])       */
     int interaction_layers;            /* config["interaction_layers"] or 0: n Linear+ReLU + 1 Linear, width kept */
-    int mem_type;                      /* config["mem_type"]: 0 "lstm" (nn.LSTM), 1 "gru" (nn.GRU), :154-159 */
+    int mem_type;                      /* config["mem_type"]: 0 "lstm" (nn.LSTM), 1 "gru" (nn.GRU), 2 anything else (nn.RNN, tanh), :154-159 */
     int compress_context;              /* config["compress_context"]: 1 = the context encoder ends in Linear(mem_hidden
                                           -> latent_dim) (:363-366); 0 = its embedding is the memory's output itself
                                           (mem_hidden wide: the class default, :1014-1015) and the decoder memory reads
@@ -390,7 +390,7 @@ typedef struct vsv_lstm_bwd {
     float drop_p;                           /* as in vsv_train_save: masks d(layer 0 output) coming from layer 1 */
     uint64_t drop_seed;
     int drop_id;
-    int gru;                                /* 1: the saved gates are nn.GRU's (r, z, n, W_hn h + b_hn) */
+    int gru;                                /* 1: the saved gates are nn.GRU's (r, z, n, W_hn h + b_hn); 2: nn.RNN's (h' in slot 0) */
     const uint64_t* drop_seed_dev;          /* as in vsv_train_save */
     int sv_nl, sv_l0;                       /* sv_nl > 0: sv_gates / sv_c / dgates hold sv_nl layers per instance and
                                              * this call handles `layers` of them from sv_l0 (wT_hh[0] is layer sv_l0's):

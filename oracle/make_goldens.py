@@ -498,6 +498,24 @@ def main_nocompress():
     case_cprior_train("g8_cprior_train_nocomp_ex5_B4_T24_h3", ex5, 100, 2.0, 4, 24, 3, [1, 7])
 
 
+def main_rnn():
+    """mem_type other than "lstm" / "gru": nn.RNN (tanh) memories (:158-159, :310-311, :479-480)."""
+    f32, f64 = np.float32, np.float64
+    ex5 = vo.make_config(5, 3, mem_type="rnn")
+    noex = vo.make_config(5, 0, mem_type="rnn", compress_context=False)
+    ex12 = vo.make_config(12, 3, mem_type="rnn", quantile_loss_weights=[5.0, 1.0, 5.0], kl_weight=1e-3)
+    one = vo.make_config(5, 0, mem_layers=1, mem_type="rnn")
+    case_forward("g1_fwd_rnn_ex5_T21_h1_f32", ex5, 110, 2.0, f32, 4, 21, 1)
+    case_forward("g1_fwd_rnn_nocomp_noex_T9_h3_f64", noex, 111, 2.0, f64, 3, 9, 3)
+    case_forward("g1_fwd_rnn_1layer_T6_h1_f32", one, 112, 1.0, f32, 2, 6, 1)
+    case_prior("g2_prior_rnn_ex12_C20_H7_f32", ex12, 113, 2.0, f32, 6, 20, 7)
+    case_grads("g4_grads_rnn_ex5_B6_T21_h3", ex5, 114, 2.0, 6, 21, 3, full=False)
+    case_grads("g4_grads_rnn_ex12_B4_T20_h7", ex12, 115, 2.0, 4, 20, 7, full=False)
+    case_grads("g4_grads_rnn_1layer_B5_T9_h2", one, 116, 2.0, 5, 9, 2, full=False)
+    case_ar("g6_ar_rnn_ex5_C20_H30", ex5, 117, 2.0, 4, 20, 30)
+    case_cprior_train("g8_cprior_train_rnn_ex5_B4_T24_h3", ex5, 118, 2.0, 4, 24, 3, [1, 7])
+
+
 def main_cprior():
     f32, f64 = np.float32, np.float64
     ex5 = vo.make_config(5, 3)
@@ -802,6 +820,9 @@ if __name__ == "__main__":
     elif len(sys.argv) > 1 and sys.argv[1] == "nocompress":
         os.makedirs(OUT, exist_ok=True)
         main_nocompress()
+    elif len(sys.argv) > 1 and sys.argv[1] == "rnn":
+        os.makedirs(OUT, exist_ok=True)
+        main_rnn()
     elif len(sys.argv) > 1 and sys.argv[1] == "legacy":
         os.makedirs(OUT, exist_ok=True)
         main_legacy()

@@ -36,7 +36,7 @@ class TorchPort(nn.Module):
         self.mems = nn.ModuleDict()
         Lc = self.L if cfg.get("compress_context", False) else Hm                         # :363-366
         for name, inp, hid in (("encoder", E, Hm), ("ctx_encoder", E, Hm), ("decoder", Lc + self.L, self.Hd)):
-            kind = nn.GRU if cfg.get("mem_type", "lstm") == "gru" else nn.LSTM            # :154-159
+            kind = {"lstm": nn.LSTM, "gru": nn.GRU}.get(cfg.get("mem_type", "lstm"), nn.RNN)   # :154-159
             m = kind(inp, hid, num_layers=self.nl, batch_first=True, dropout=dropout)     # :155, :307, :476
             m = m.to(dtype)
             with torch.no_grad():
@@ -63,7 +63,9 @@ class TorchPort(nn.Module):
         for l in range(self.nl):
             ws = [getattr(m, f"{p}_l{l}") for p in ("weight_ih", "weight_hh", "bias_ih", "bias_hh")]
             z = torch.zeros(1, B, m.hidden_size, dtype=x.dtype)
-            if isinstance(m, nn.GRU):
+            if isinstance(m, nn.RNN):
+                h = torch._VF.rnn_tanh(h, z, ws, True, 1, 0.0, False, False, True)[0]
+            elif isinstance(m, nn.GRU):
                 h = torch._VF.gru(h, z, ws, True, 1, 0.0, False, False, True)[0]
             else:
                 h = torch._VF.lstm(h, (z, z), ws, True, 1, 0.0, False, False, True)[0]

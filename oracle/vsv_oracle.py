@@ -52,7 +52,7 @@ def prior_state_dict_spec(cfg: dict) -> List[Tuple[str, Tuple[int, ...]]]:
     if n_int > 0:
         for nm in [f"prior_interact_linear_{i}" for i in range(n_int)] + ["prior_interact_linear_final"]:
             spec += [(f"prior_network.interaction.{nm}.weight", (E, E)), (f"prior_network.interaction.{nm}.bias", (E,))]
-    ng = 3 if cfg.get("mem_type", "lstm") == "gru" else 4
+    ng = {"lstm": 4, "gru": 3}.get(cfg.get("mem_type", "lstm"), 1)
     for l in range(nl):
         i = E if l == 0 else Hm
         spec += [(f"prior_network.mem.weight_ih_l{l}", (ng * Hm, i)), (f"prior_network.mem.weight_hh_l{l}", (ng * Hm, Hm)),
@@ -139,6 +139,18 @@ def lstm_forward(x: np.ndarray, W: Weights, prefix: str, n_layers: int,
         w_ih = W[f"{prefix}.weight_ih_l{l}"]
         w_hh = W[f"{prefix}.weight_hh_l{l}"]
         Hh = w_hh.shape[1]
+        if w_hh.shape[0] == Hh:
+            # nn.RNN (tanh), any mem_type other than "lstm" / "gru" (:158-159): h' = tanh(W_ih x + b_ih + W_hh h + b_hh)
+            assert not return_cache
+            h = np.zeros((B, Hh), dtype=x.dtype) if state is None else np.broadcast_to(state[l][0], (B, Hh)).copy()
+            xproj = inp @ w_ih.T + W[f"{prefix}.bias_ih_l{l}"] + W[f"{prefix}.bias_hh_l{l}"]
+            out = np.empty((B, T, Hh), dtype=x.dtype)
+            for t in range(T):
+                h = np.tanh(xproj[:, t] + h @ w_hh.T)
+                out[:, t] = h
+            finals.append((h, h))
+            inp = out
+            continue
         if w_hh.shape[0] == 3 * Hh:
             assert not return_cache
             b_ih, b_hh = W[f"{prefix}.bias_ih_l{l}"], W[f"{prefix}.bias_hh_l{l}"]

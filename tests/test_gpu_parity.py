@@ -82,7 +82,8 @@ def test_forward_vs_reference(name):
 
 
 @pytest.mark.parametrize("L,X,D,S,C,H,mem", [(5, 0, 3, 40, 20, 1, "lstm"), (12, 3, 5, 24, 60, 7, "lstm"),
-                                             (5, 3, 2, 1000, 5, 2, "lstm"), (5, 3, 3, 300, 7, 4, "gru")])
+                                             (5, 3, 2, 1000, 5, 2, "lstm"), (5, 3, 3, 300, 7, 4, "gru"),
+                                             (5, 3, 3, 300, 7, 4, "rnn")])
 def test_prior_mc_vs_oracle_ragged_tiles(L, X, D, S, C, H, mem):
     """rows = D*S is not a multiple of the 16-row tile and tiles straddle days."""
     from vsv import paths
@@ -112,7 +113,7 @@ def test_fused_mc_decode_many_rows_vs_oracle():
     MC production path), ragged last tile, tiles straddling days, both output layouts."""
     from vsv import paths
     for L, X, D, S, C, H, mem in ((12, 3, 37, 1000, 4, 2, "lstm"), (5, 0, 67, 500, 3, 1, "lstm"),
-                                  (5, 3, 35, 1000, 3, 3, "gru")):
+                                  (5, 3, 35, 1000, 3, 3, "gru"), (12, 0, 40, 1000, 3, 2, "rnn")):
         cfg = vo.make_config(L, X, mem_type=mem)
         eng, W = _engine(cfg, 21, 2.0)
         rng = np.random.default_rng(17)
@@ -226,10 +227,13 @@ def test_autoregressive_sequence_vs_reference(name):
         assert err(_n(e), g["ex_out"]) <= TOL
     # the shared-prefix schedule (encoders / decoder continue from the state after the days that are
     # still original context) runs the same products in the same order
+    # (the first step from a shared state adds bias + W_hh . h_prev before the input product, the literal schedule
+    # after it: last-place differences, which an ungated tanh RNN carries through 30 fed-back steps undamped)
     s2, e2 = paths.ar_generate(eng, surf, ex, int(g["horizon"]), 1, eps=eps, share_prefix=True)
-    assert float((s2 - s).abs().max()) <= 1e-6
+    tol2 = 1e-6 if str(cfg.get("mem_type", "lstm")) in ("lstm", "gru") else 5e-6
+    assert float((s2 - s).abs().max()) <= tol2
     if ex is not None:
-        assert float((e2 - e).abs().max()) <= 1e-6
+        assert float((e2 - e).abs().max()) <= tol2
 
 
 def test_autoregressive_shared_prefix_equals_literal_rollout():
@@ -416,7 +420,8 @@ def test_multihorizon_losses_and_gradients_vs_reference():
 
 
 @pytest.mark.parametrize("L,X,B,T,h,p,mem", [(5, 3, 37, 12, 3, 0.25, "lstm"), (12, 3, 8, 30, 7, 0.3, "lstm"),
-                                             (5, 0, 64, 6, 1, 0.2, "lstm"), (5, 3, 20, 14, 4, 0.3, "gru")])
+                                             (5, 0, 64, 6, 1, 0.2, "lstm"), (5, 3, 20, 14, 4, 0.3, "gru"),
+                                             (5, 3, 20, 14, 4, 0.3, "rnn")])
 def test_train_with_lstm_dropout_vs_autograd_oracle(L, X, B, T, h, p, mem):
     """nn.LSTM's inter-layer dropout (train mode, mem_dropout 0.2-0.3 in every production config).  The
     reference draws its masks from torch's generator inside nn.LSTM, so they cannot be reproduced: the

@@ -209,20 +209,26 @@ def test_interaction_layers_state_dict_keys():
     assert "prior_network.interaction.prior_interact_linear_1.bias" in sd
 
 
-def test_mem_type_gru_accepted_rnn_rejected():
-    """mem_type "gru" maps to vsv_dims.mem_type 1 and packs into the same blob size as "lstm" (four gate
-    slots per unit: r, z, n_x, n_h); nn.RNN memories are not built and must be refused, not approximated."""
+def test_mem_types_share_one_blob_shape():
+    """mem_type "gru" maps to vsv_dims.mem_type 1 and any value other than "lstm" / "gru" to 2 (the reference builds
+    nn.RNN for those, :158-159); all pack into the same blob size as "lstm" (four gate slots per unit: r, z, n_x,
+    n_h for the GRU; the pre-activation in slot 0 and zero rows in the others for the RNN)."""
     import ctypes as C
     from oracle import vsv_oracle as vo
     from vsv import lib as L_
     from vsv.engine import dims_from_config, pack_state_dict
     d0 = dims_from_config(vo.make_config(5, 3))
     d1 = dims_from_config(vo.make_config(5, 3, mem_type="gru"))
-    assert (d0.mem_type, d1.mem_type) == (0, 1)
+    d2 = dims_from_config(vo.make_config(5, 3, mem_type="rnn"))
+    assert (d0.mem_type, d1.mem_type, d2.mem_type) == (0, 1, 2)
     lib = L_.load()
-    assert lib.vsv_packed_floats(C.byref(d0)) == lib.vsv_packed_floats(C.byref(d1))
-    with pytest.raises(NotImplementedError):
-        dims_from_config(vo.make_config(5, 3, mem_type="rnn"))
+    assert lib.vsv_packed_floats(C.byref(d0)) == lib.vsv_packed_floats(C.byref(d1)) == lib.vsv_packed_floats(C.byref(d2))
+    cfg = vo.make_config(5, 3, mem_type="rnn")
+    W = vo.init_weights(cfg, 3, 1.0, np.float32)
+    assert W["encoder.mem.weight_hh_l0"].shape == (100, 100) and W["decoder.mem.weight_ih_l0"].shape == (128, 10)
+    blob = pack_state_dict(d2, W)
+    tot = sum(float(np.abs(v).sum()) for k, v in W.items() if "bias" not in k)
+    assert np.isfinite(blob).all() and float(np.abs(blob).sum()) >= tot * (1 - 1e-5)
     cfg = vo.make_config(5, 3, mem_type="gru")
     W = vo.init_weights(cfg, 3, 1.0, np.float32)
     assert W["encoder.mem.weight_hh_l0"].shape == (300, 100)

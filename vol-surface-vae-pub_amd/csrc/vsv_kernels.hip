@@ -676,7 +676,7 @@ struct LstmSeqArgs {
     // which is also saved ([inst][4*NT][64]) as the X of layer 1's weight gradient
     DropArgs drop;
     float* sv_hd;
-    int gru;                // memory cell: 0 nn.LSTM, 1 nn.GRU
+    int gru;                // memory cell: 0 nn.LSTM, 1 nn.GRU, 2 nn.RNN (tanh)
     // training, one launch per layer (NL = 1): the saved arrays hold sv_nl layers per instance and this
     // launch is layer sv_l0 (w[0] / b[0] are that layer's); rec: the gate accumulators start from the
     // pre-activations b + W_ih . x that lstm_pre_kernel left in sv_gates for every step, and only the
@@ -745,8 +745,23 @@ __device__ __forceinline__ float decoder_input(const LstmSeqArgs& a, const DecIn
 
 // LSTM cell: lane holds gates (i,f,g,o) of unit 8t + 2jj + hh in acc[i][4jj .. 4jj+3]
 template <bool KEEP, int OWN>
-__device__ __forceinline__ void lstm_cell(f32x16 (&acc)[OWN], float (&c)[OWN][4], float (&hn)[OWN][4], bool gru) {
-    if (gru) {
+__device__ __forceinline__ void lstm_cell(f32x16 (&acc)[OWN], float (&c)[OWN][4], float (&hn)[OWN][4], int kind) {
+    if (kind == 2) {
+        // nn.RNN: slot 0 holds W_ih x + b_ih + W_hh h + b_hh, h' = tanh of it (slots 1-3 are zero rows).  The `c`
+        // registers carry h like the GRU's; KEEP leaves h' in slot 0 for the backward pass.
+#pragma unroll
+        for (int i = 0; i < OWN; ++i) {
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) {
+                const float h = fast_tanh(acc[i][4 * jj + 0]);
+                c[i][jj] = h;
+                hn[i][jj] = h;
+                if (KEEP) acc[i][4 * jj + 0] = h;
+            }
+        }
+        return;
+    }
+    if (kind == 1) {
         // nn.GRU: slots (r, z, n_x, n_h); n = tanh(n_x + r * n_h), h' = (1 - z) * n + z * h.  The `c`
         // registers carry this lane's units of h.  KEEP leaves (r, z, n, n_h) for the backward pass.
 #pragma unroll
@@ -1140,7 +1155,7 @@ lstm_kernel(const LstmSeqArgs a) {
                 if (l == NL - 1 && head_now) head_preload<NT>(a, wq, bq, opaque<OWN == 4>(lane), wave);
             }
             VSV_STAMP(2 + 3 * l);
-            lstm_cell<SAVE, OWN>(acc, c[l], hn, a.gru != 0);
+            lstm_cell<SAVE, OWN>(acc, c[l], hn, a.gru);
             VSV_STAMP(3 + 3 * l);
             if (SAVE) {
                 const size_t il = (size_t)(rowtile * a.T + t) * SL + L0 + l;
@@ -1377,7 +1392,7 @@ __global__ void __launch_bounds__(64 * NT, (NT + 3) / 4) lstm_rec_kernel(const L
             }
         }
         float hn[1][4];
-        lstm_cell<SAVE, 1>(acc, c, hn, a.gru != 0);
+        lstm_cell<SAVE, 1>(acc, c, hn, a.gru);
         if (SAVE) {
             const size_t il = (size_t)(rowtile * a.T + t) * SL + L0;
             float* sg = a.sv_gates + il * (16 * NT) * 64 + lane;
@@ -1558,7 +1573,7 @@ __global__ void __launch_bounds__(256, 2) mc_decode1_kernel(const LstmSeqArgs a)
                 for (int j = 0; j < 4; ++j) bv[j] = bcol[(4 * q + j) * 64];
             });
             MC1_STAMP(2 * (l * NP + p) + 2);
-            lstm_cell<false, 4>(acc, c, hn, false);
+            lstm_cell<false, 4>(acc, c, hn, 0);
             // (pinned: left to itself the compiler sinks the cell math of all four passes below the last
             // pass's GEMM and parks the earlier passes' accumulators in scratch meanwhile)
 #pragma unroll
@@ -1987,7 +2002,11 @@ __global__ void __launch_bounds__(256, 1) lstm_bwd_kernel(const LstmBwdArgs a) {
                 for (int r = 0; r < 4; ++r) {
                     const int reg = 4 * jq + r;
                     float di = 0.0f, df = 0.0f, dgg = 0.0f, dog = 0.0f;
-                    if (tg < NT && a.gru) {
+                    if (tg < NT && a.gru == 2) {
+                        // nn.RNN: saved slot 0 is h' = tanh(pre); d pre = dh * (1 - h'^2)
+                        const float hv = gsv[reg][0];
+                        di = acc[0][reg] * (1.0f - hv * hv);
+                    } else if (tg < NT && a.gru) {
                         // nn.GRU: saved slots (r, z, n, n_h); sv_c holds h.  dc carries dh' * z, the direct path
                         const float rg = gsv[reg][0], zg = gsv[reg][1], ng = gsv[reg][2], nh = gsv[reg][3];
                         const float hp = cpv[reg];

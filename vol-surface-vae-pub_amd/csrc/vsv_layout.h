@@ -72,7 +72,7 @@ struct Layout {
     int L = 0, X = 0, Hm = 0, NL = 0, Q = 0;
     int Lc = 0;                    // context-embedding width: L (compress_context) or Hm
     int NI = 0;                    // interaction Linears per module: 0, or interaction_layers + 1
-    int gru = 0;                   // memory cell: 0 nn.LSTM, 1 nn.GRU (gate slots r, z, n_x, n_h)
+    int gru = 0;                   // memory cell: 0 nn.LSTM, 1 nn.GRU (gate slots r, z, n_x, n_h), 2 nn.RNN (slot 0)
     int Hd = 0;                    // decoder LSTM hidden = c_last*25 + X
     int NTm = 0, NTd = 0;          // gate tiles (8 hidden units each) of encoder / decoder LSTMs
     EncLayout enc[2];              // 0 = encoder, 1 = ctx_encoder

@@ -83,7 +83,7 @@ int make_layout(const vsv_dims& d, Layout& lay, const char** msg) {
     if (lay.Q < 1 || lay.Q * 25 > kMaxFeat) return fail("n_quantiles*25 must be <= 128");
     if (d.interaction_layers < 0 || d.interaction_layers + 1 > VSV_MAX_INTERACT) return fail("interaction_layers must be in [0,2]");
     lay.NI = d.interaction_layers > 0 ? d.interaction_layers + 1 : 0;
-    if (d.mem_type < 0 || d.mem_type > 1) return fail("mem_type must be 0 (lstm) or 1 (gru)");
+    if (d.mem_type < 0 || d.mem_type > 2) return fail("mem_type must be 0 (lstm), 1 (gru) or 2 (rnn)");
     lay.gru = d.mem_type;
     lay.Lc = d.compress_context ? lay.L : lay.Hm;
     if (d.n_conv < 1 || d.n_conv > VSV_MAX_CONV || d.n_ctx_conv < 1 || d.n_ctx_conv > VSV_MAX_CONV)
@@ -286,6 +286,31 @@ static void pack_gru(float* blob, const Sec* secs, const vsv_lstm_raw& raw, int 
     }
 }
 
+// nn.RNN (tanh) in slot 0 of a hidden unit's four gate slots: pre = W_ih x + b_ih + W_hh h + b_hh, h' = tanh(pre);
+// slots 1-3 are zero rows (the gate GEMM keeps the LSTM's shape, the cell reads slot 0 only).
+static void pack_rnn(float* blob, const Sec* secs, const vsv_lstm_raw& raw, int NL, int H, int NT, int in0,
+                     int kx, const InMap& x_map) {
+    for (int l = 0; l < NL; ++l) {
+        const float *wih = raw.w_ih[l], *whh = raw.w_hh[l], *bih = raw.b_ih[l], *bhh = raw.b_hh[l];
+        const int n_in = (l == 0) ? in0 : H;
+        const int kin = (l == 0) ? kx : 4 * NT;
+        const InMap imap = (l == 0) ? x_map : in_nat(H);
+        const InMap hmap = in_nat(H);
+        InMap fi = [=](int s, int hh) {
+            if (s < kin) return imap(s, hh);
+            const int c = hmap(s - kin, hh);
+            return c < 0 ? -1 : n_in + c;
+        };
+        WFn W = [=](int r, int c) {
+            const int g = r / H, u = r % H;
+            if (g != 0) return 0.0f;
+            return c < n_in ? wih[(size_t)u * n_in + c] : whh[(size_t)u * H + (c - n_in)];
+        };
+        BFn B = [=](int r) { return r < H ? bih[r] + bhh[r] : 0.0f; };
+        pack_sec(blob, secs[l], out_gate(H), fi, W, B);
+    }
+}
+
 static void pack_lstm(float* blob, const Sec* secs, const vsv_lstm_raw& raw, int NL, int H, int NT, int in0,
                       int kx, const InMap& x_map) {
     for (int l = 0; l < NL; ++l) {
@@ -396,7 +421,7 @@ extern "C" int vsv_pack_weights(const vsv_dims* dims, const vsv_raw_weights* raw
             pack_sec(out, e.conv[e.n_conv + j], out_nat32(E), in_perm(E), W, B);
         }
         const vsv_lstm_raw& mem = which ? raw->ctx_mem : raw->enc_mem;
-        (lay.gru ? pack_gru : pack_lstm)(out, e.lstm, mem, lay.NL, Hm, lay.NTm, e.E, e.kx, in_perm(e.E));
+        (lay.gru == 2 ? pack_rnn : lay.gru ? pack_gru : pack_lstm)(out, e.lstm, mem, lay.NL, Hm, lay.NTm, e.E, e.kx, in_perm(e.E));
         if (which == 0) {
             const float *wm = raw->z_mean_w, *bm = raw->z_mean_b, *wv = raw->z_log_var_w, *bv = raw->z_log_var_b;
             WFn W = [=](int r, int c) { return r < L ? wm[(size_t)r * Hm + c] : wv[(size_t)(r - L) * Hm + c]; };
@@ -421,7 +446,8 @@ extern "C" int vsv_pack_weights(const vsv_dims* dims, const vsv_raw_weights* raw
 
     const DecLayout& dc = lay.dec;
     const int Hd = lay.Hd;
-    (lay.gru ? pack_gru : pack_lstm)(out, dc.lstm, raw->dec_mem, lay.NL, Hd, lay.NTd, lay.Lc + L, dc.kx, in_nat(lay.Lc + L));
+    (lay.gru == 2 ? pack_rnn : lay.gru ? pack_gru : pack_lstm)(out, dc.lstm, raw->dec_mem, lay.NL, Hd, lay.NTd, lay.Lc + L, dc.kx,
+                                                                 in_nat(lay.Lc + L));
     int hi = 0;
     const int c_last = d.surface_hidden[d.n_conv - 1];
     for (int j = 0; j < lay.NI; ++j) {

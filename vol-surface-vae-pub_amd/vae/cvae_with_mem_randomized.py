@@ -10,7 +10,7 @@ checkpoint compatibility, but their own forward() is never called.  There is no
 CPU fallback: calling a compute method without a GPU raises.
 
 Implemented topology (what the configs in the reference repo use): conv surface
-embedding, mem_type="lstm" / "gru", compress_context True or False, interaction_layers
+embedding, mem_type "lstm" / "gru" / anything else (nn.RNN), compress_context True or False, interaction_layers
 None / 1 / 2, ex_feats_hidden=None.  Other switches parse and then raise NotImplementedError
 at the first compute call.
 """

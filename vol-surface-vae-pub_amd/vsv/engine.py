@@ -18,8 +18,6 @@ from . import lib as _lib
 def dims_from_config(cfg: dict) -> _lib.VsvDims:
     """vsv_dims from a reference model config dict
     (keys as validated by cvae_with_mem_randomized.py:969-1020)."""
-    if cfg.get("mem_type", "lstm") not in ("lstm", "gru"):
-        raise NotImplementedError("HIP path implements mem_type 'lstm' and 'gru' (nn.RNN is not built)")
     if cfg.get("use_dense_surface", False):
         raise NotImplementedError("HIP path implements the conv surface embedding only")
     if cfg.get("ex_feats_hidden") is not None or cfg.get("ctx_ex_feats_hidden") is not None:

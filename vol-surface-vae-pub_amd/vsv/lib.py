@@ -256,9 +256,8 @@ def make_dims(latent_dim, ex_feats_dim, mem_hidden, mem_layers, surface_hidden, 
               n_quantiles, interaction_layers=0, mem_type="lstm", compress_context=True) -> VsvDims:
     d = VsvDims()
     d.compress_context = int(bool(compress_context))
-    if mem_type not in ("lstm", "gru"):
-        raise NotImplementedError("HIP path implements mem_type 'lstm' and 'gru' (nn.RNN is not built)")
-    d.mem_type = 1 if mem_type == "gru" else 0
+    # the reference builds nn.LSTM for "lstm", nn.GRU for "gru" and nn.RNN for ANY other value (:154-159)
+    d.mem_type = {"lstm": 0, "gru": 1}.get(mem_type, 2)
     d.interaction_layers = int(interaction_layers or 0)
     if d.interaction_layers + 1 > VSV_MAX_INTERACT:
         raise NotImplementedError("at most 2 interaction layers are supported by the HIP path")

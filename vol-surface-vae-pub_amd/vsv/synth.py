@@ -69,7 +69,8 @@ def state_dict_spec(cfg: dict) -> List[Tuple[str, Tuple[int, ...]]]:
             spec.append((f"{prefix}.{nm}.bias", (co,)))
             cin = co
 
-    ng = 3 if cfg.get("mem_type", "lstm") == "gru" else 4     # gate row blocks: nn.GRU [r; z; n], nn.LSTM [i; f; g; o]
+    # gate row blocks: nn.LSTM [i; f; g; o], nn.GRU [r; z; n], nn.RNN (any other mem_type, :158-159) one
+    ng = {"lstm": 4, "gru": 3}.get(cfg.get("mem_type", "lstm"), 1)
 
     def lstm(prefix, inp, hid):
         for l in range(nl):

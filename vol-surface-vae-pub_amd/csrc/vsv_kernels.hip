@@ -1449,6 +1449,210 @@ __global__ void __launch_bounds__(64 * NT, (NT + 3) / 4) lstm_rec_kernel(const L
     }
 }
 
+// ---------------------------------------------------------------------------
+// lstm_rec16_kernel: the recurrent-only launch of ONE nn.LSTM layer (pre-activations given: pre_t or pre_g) on
+// 16-ROW tiles with v_mfma_f32_16x16x4_f32, for the date-range prefix: its launches have few row tiles (4000 days
+// = 125 tiles of 32 rows = 125 of 256 CUs, each bound by its own matrix pipe for every one of the 2 x 60 sequential
+// steps), so halving the tile doubles the CUs in use and halves the matrix time per step.
+//   * a 16x16x4 D tile is (16 gate rows) x (16 days); gate tile q holds hidden units 4q .. 4q+3, D row 4*unit + gate,
+//     so lane l (day l & 15, unit 4q + (l >> 4)) holds the four gates of ONE unit of ONE day in its four D registers:
+//     the cell is lane-local;
+//   * the B operand of k-step j (hidden units 4j .. 4j+3) wants unit 4j + (l >> 4) of day l & 15 in lane l -- exactly
+//     where the cell of gate tile j left h': h goes through LDS as [k-step][lane], no transposition;
+//   * 8 waves per workgroup, wave w owns gate tiles w, w+8, w+16, w+24; its W_hh fragments (one register per tile and
+//     k-step: 4 x 32 = 128 at hidden 128) are gathered ONCE from the blob's 32x32x2 section and stay in registers for
+//     all T steps; h is double-buffered in LDS, one barrier per step; the next step's pre-activations are fetched
+//     while the products run.
+// Reads and writes the 32-row formats of the other kernels (pre_t / pre_g, hout in tile-B, state and gate arrays).
+// The products are summed four k at a time instead of two: results agree with lstm_kernel's to rounding, not bit
+// for bit.
+// ---------------------------------------------------------------------------
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
+
+template <int NT>
+__global__ void __launch_bounds__(512) lstm_rec16_kernel(const LstmSeqArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    constexpr int KS = 2 * NT;                                     // k-steps of 4 hidden units = gate tiles of 16 rows
+    constexpr int TPW = (KS + 7) / 8;                              // gate tiles per wave
+    constexpr int HP = 8 * NT, HPK = 4 * NT;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const long tile16 = (long)blockIdx.x;
+    const int d = lane & 15, ul = lane >> 4;
+    const long row_raw = tile16 * 16 + d;
+    const bool row_ok = row_raw < a.n_rows;
+    const long row = row_ok ? row_raw : a.n_rows - 1;
+    const long rowtile = tile16 >> 1;                              // the 32-row tile of the other kernels' layouts
+    const int m = 16 * (int)(tile16 & 1) + d;                      // ... and this lane's row inside it
+    const int SNL = a.st_nl > 0 ? a.st_nl : 1;
+    const int ntile = __builtin_amdgcn_readfirstlane((KS - wave + 7) / 8);     // tiles this wave owns (TPW or TPW - 1)
+    float* const hbase = smem + lane;
+
+    // per owned tile: this lane's hidden unit and where its values live in the 32-row layouts
+    int gslot[TPW], l32[TPW], hpos[TPW], hslot[TPW];
+#pragma unroll
+    for (int i = 0; i < TPW; ++i) {
+        const int q = (i < ntile) ? wave + 8 * i : KS - 1;
+        const int u = 4 * q + ul;
+        gslot[i] = 16 * (u >> 3) + 4 * ((u & 7) >> 1);             // + gate: slot of the gate value
+        l32[i] = (u & 1) * 32 + m;                                 // lane of the 32-row layouts
+        hslot[i] = 4 * (u >> 3) + ((u & 7) >> 1);                  // slot of h in tile-B
+        hpos[i] = 8 * (u >> 3) + 4 * (u & 1) + ((u & 7) >> 1);     // position in the state arrays
+    }
+
+    // W_hh fragments: A[i][k] of tile q, k-step j = W_hh[gate row of (unit 4q + (i >> 2), gate i & 3)][unit 4j + k],
+    // lane = i + 16 k, gathered from the blob's 32x32x2 fragment layout (vsv_layout.h)
+    float wreg[TPW][KS];
+    {
+        const int ir = lane & 15;
+#pragma unroll
+        for (int i = 0; i < TPW; ++i) {
+            const int q = (i < ntile) ? wave + 8 * i : KS - 1;
+            const int ua = 4 * q + (ir >> 2);
+            const int n = 32 * (ua >> 3) + 4 * (ua & 7) + (ir & 3);
+#pragma unroll
+            for (int j = 0; j < KS; ++j) {
+                const int kk = 2 * a.kx + 4 * j + ul;
+                wreg[i][j] = a.w[0][((size_t)((kk >> 3) * NT + (n >> 5)) * 64 + ((kk & 1) * 32 + (n & 31))) * 4 + ((kk >> 1) & 3)];
+            }
+        }
+    }
+    auto load_pre = [&](f32x4 (&pre)[TPW], int t) {
+#pragma unroll
+        for (int i = 0; i < TPW; ++i) {
+            if (a.pre_t) {
+                const float* p = a.pre_t + (size_t)(2 * gslot[i] + (l32[i] >> 5)) * a.pre_stride + row + (size_t)t * a.pre_tstride;
+                const size_t st = 2 * (size_t)a.pre_stride;
+                pre[i] = f32x4{p[0], p[st], p[2 * st], p[3 * st]};
+            } else {
+                const float* p = a.pre_g + ((size_t)(rowtile * a.T + t) * (16 * NT) + gslot[i]) * 64 + l32[i];
+                pre[i] = f32x4{p[0], p[64], p[128], p[192]};
+            }
+        }
+    };
+    f32x4 pre[TPW];
+    load_pre(pre, 0);
+
+    float c[TPW], h[TPW];
+    const bool has_state = a.din.state_in != nullptr;              // wave-uniform
+#pragma unroll
+    for (int i = 0; i < TPW; ++i) {
+        c[i] = 0.0f;
+        h[i] = 0.0f;
+        if (has_state) {
+            const long srow = a.din.state_div == 1 ? row : row / a.din.state_div;
+            const float* ps = a.din.state_in + ((size_t)srow * SNL + a.st_l0) * 2 * HP + hpos[i];
+            h[i] = ps[0];
+            c[i] = ps[HP];
+        }
+        if (i < ntile) hbase[(wave + 8 * i) * 64] = h[i];
+    }
+    __syncthreads();
+    const int t_outs = a.T - a.t_out0;
+    auto products = [&](f32x4 (&acc)[TPW], const float* hr) {
+        // (ntile is wave-uniform: two straight-line variants instead of a test per product)
+        if (ntile == TPW) {
+#pragma unroll
+            for (int j = 0; j < KS; ++j) {
+                const float b = hr[j * 64];
+#pragma unroll
+                for (int i = 0; i < TPW; ++i) acc[i] = mfma16(wreg[i][j], b, acc[i]);
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < KS; ++j) {
+                const float b = hr[j * 64];
+#pragma unroll
+                for (int i = 0; i < TPW - 1; ++i) acc[i] = mfma16(wreg[i][j], b, acc[i]);
+            }
+        }
+    };
+    for (int t = 0; t < a.T; ++t) {
+        const float* hr = hbase + (t & 1) * (KS * 64);
+        float* hw = hbase + ((t + 1) & 1) * (KS * 64);
+        f32x4 acc[TPW];
+#pragma unroll
+        for (int i = 0; i < TPW; ++i) acc[i] = pre[i];
+        if (t + 1 < a.T) load_pre(pre, t + 1);                     // lands while the products run
+        if (t > 0 || has_state) products(acc, hr);
+#pragma unroll
+        for (int i = 0; i < TPW; ++i) {
+            const float ig = fast_sigmoid(acc[i][0]);
+            const float fg = fast_sigmoid(acc[i][1]);
+            const float gg = fast_tanh(acc[i][2]);
+            const float og = fast_sigmoid(acc[i][3]);
+            c[i] = __builtin_fmaf(fg, c[i], ig * gg);
+            h[i] = og * fast_tanh(c[i]);
+            if (i < ntile) hw[(wave + 8 * i) * 64] = h[i];
+        }
+        if (a.hout && t >= a.t_out0) {                             // (padding rows too: the next stage reads whole tiles)
+            float* ho = a.hout + (size_t)(rowtile * t_outs + (t - a.t_out0)) * HPK * 64;
+#pragma unroll
+            for (int i = 0; i < TPW; ++i)
+                if (i < ntile) ho[hslot[i] * 64 + l32[i]] = h[i];
+        }
+        __syncthreads();                                           // h(t) published (the other buffer is free again)
+    }
+    if (a.state_out && row_ok) {
+        float* st = a.state_out + ((size_t)row_raw * SNL + a.st_l0) * 2 * HP;
+#pragma unroll
+        for (int i = 0; i < TPW; ++i)
+            if (i < ntile) {
+                st[hpos[i]] = h[i];
+                st[HP + hpos[i]] = c[i];
+            }
+    }
+    if (a.din.gate_out) {
+        // bias + W_hh . h_final: the part of the next step's gates shared by all rows continuing from this state
+        const float* hf = hbase + (a.T & 1) * (KS * 64);
+        f32x4 g[TPW];
+#pragma unroll
+        for (int i = 0; i < TPW; ++i) {
+            // bias of (unit, gate): tile32 * 32 + hh * 16 + 4 * jj + gate, with gslot = 16 * tile32 + 4 * jj
+            const int bi = (gslot[i] >> 4) * 32 + (l32[i] >> 5) * 16 + (gslot[i] & 15);
+            g[i] = f32x4{a.b[0][bi], a.b[0][bi + 1], a.b[0][bi + 2], a.b[0][bi + 3]};
+        }
+        products(g, hf);
+        if (row_ok) {
+            float* go = a.din.gate_out + ((size_t)row_raw * SNL + a.st_l0) * NT * 32;
+#pragma unroll
+            for (int i = 0; i < TPW; ++i)
+                if (i < ntile) {
+                    const int bi = (gslot[i] >> 4) * 32 + (l32[i] >> 5) * 16 + (gslot[i] & 15);
+                    *(float4*)(go + bi) = make_float4(g[i][0], g[i][1], g[i][2], g[i][3]);
+                }
+        }
+    }
+}
+
+// The decoder memory's input [ctx_pad | z] of every (row, step) in the tile-B layout the training kernels save
+// (sv_x: [inst = rowtile*T + t][kx slots][64], slot s of lane hh*32 + r = feature 2s + hh of row 32*rowtile + r),
+// with the reparameterised z written to z_out: what lstm_kernel<.., XMODE 1> assembles on its time loop, as one
+// launch of its own, so that the decoder's first layer can run as a pre-activation GEMM (lstm_pre_kernel) and the
+// register-resident recurrent launch (lstm_rec_kernel) like every other layer of a training step.
+__global__ void __launch_bounds__(256) decoder_input_kernel(const LstmSeqArgs a) {
+    const long total = a.n_rowtiles * a.T * a.kx * 64;
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    const int lane = (int)(i & 63);
+    const int s = (int)((i >> 6) % a.kx);
+    const long inst = (i >> 6) / a.kx;
+    const int t = (int)(inst % a.T);
+    const long rowtile = inst / a.T;
+    const long row_raw = rowtile * 32 + (lane & 31);
+    const bool row_ok = row_raw < a.n_rows;
+    const long row = row_ok ? row_raw : a.n_rows - 1;
+    const vsv_decode_in& d = a.din;
+    DecIn di = {};
+    const long day_rel = row / d.S;
+    if (d.ctx) di.ctx = d.ctx + (row / d.ctx_div) * d.ctx_rs;
+    if (d.zb) di.z_idx = (row / d.z_div) * d.z_rs;
+    di.eps = d.eps_in ? d.eps_in + (size_t)row * d.eps_T * a.L : nullptr;
+    di.sample = (uint32_t)(row - day_rel * d.S);
+    di.day = (uint32_t)d.day0 + (uint32_t)day_rel;
+    a.sv_x[i] = decoder_input(a, di, row, row_ok, true, t, 2 * s + (lane >> 5));
+}
+
 // layer[li] of the decoder head (LstmSeqArgs::head, part of the by-value kernel argument) for a run-time li,
 // read from the kernarg segment by scalar loads: indexing the by-value copy itself would put it in scratch.
 // The struct is the kernel's only explicit argument, so it sits at offset 0 of the segment.
@@ -2503,9 +2707,29 @@ static bool lstm_rec_applies(const LstmSeqArgs& a, int NL) {
     return infer && (a.pre_t != nullptr || a.pre_g != nullptr);
 }
 
+// the 16-row-tile recurrent launch: inference, one nn.LSTM layer, pre-activations given, few row tiles
+static bool lstm_rec16_applies(const LstmSeqArgs& a, int NL) {
+    static const bool off = [] { const char* e = getenv("VSV_REC16"); return e && e[0] == '0'; }();
+    return !off && NL == 1 && !a.sv_gates && (a.pre_t || a.pre_g) && a.gru == 0 && !a.din.gate_in &&
+           a.n_rowtiles <= kWideMaxRowtiles;
+}
+
+template <int NT>
+static int launch_lstm_rec16(const LstmSeqArgs& a, hipStream_t st) {
+    const size_t lds = (size_t)2 * 2 * NT * 64 * sizeof(float);
+    // (two 16-row tiles per 32-row tile: the odd one of a ragged tail runs on clamped rows, so that the tile-B
+    // outputs the next stage reads are written whole)
+    hipLaunchKernelGGL((lstm_rec16_kernel<NT>), dim3((unsigned)(2 * a.n_rowtiles)), dim3(512), lds, st, a);
+    return launch_check("lstm_rec16_kernel");
+}
+
 template <int XMODE>
 static int launch_lstm(const LstmSeqArgs& a, int NT, int NL, bool head, hipStream_t st) {
     if (a.n_rowtiles <= 0 || a.T <= 0) return 0;
+    if (XMODE == 0 && !head && lstm_rec16_applies(a, NL)) {
+        if (NT == 13) return launch_lstm_rec16<13>(a, st);
+        if (NT == 16) return launch_lstm_rec16<16>(a, st);
+    }
     if (XMODE == 0 && !head && lstm_rec_applies(a, NL)) {
         if (NT == 13) return a.sv_gates ? launch_lstm_rec<13, true>(a, st) : launch_lstm_rec<13, false>(a, st);
         if (NT == 16) return a.sv_gates ? launch_lstm_rec<16, true>(a, st) : launch_lstm_rec<16, false>(a, st);
@@ -2519,6 +2743,7 @@ static int launch_lstm(const LstmSeqArgs& a, int NT, int NL, bool head, hipStrea
     }
 }
 
+constexpr int kPreMaxQ = 16;     // input quads (8 features each) of a layer: <= 128 features
 // Gate pre-activations b + W_ih . x of one layer for every (row tile, t) instance at once (training):
 // the half of the gate products that does not depend on the recurrence, taken off the time loop and
 // spread over as many CUs as there are instances.  One workgroup per instance, one wave per gate tile;
@@ -2526,23 +2751,51 @@ static int launch_lstm(const LstmSeqArgs& a, int NT, int NL, bool head, hipStrea
 // later overwrites it with the activated gates.
 template <int NT>
 __global__ void __launch_bounds__(64 * NT) lstm_pre_kernel(const float* w, const float* b, int nq_in, const float* x,
-                                                           long x_stride, float* gates, long g_stride) {
+                                                           long x_stride, float* gates, long g_stride, long n_inst, int ipw) {
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const size_t inst = blockIdx.x;
-    const int toff1[1] = {wave * 64};
-    f32x16 acc[1];
-    load_bias<1>(acc, b, toff1, lane >> 5);
-    gemm_seg<1>(acc, (const float4*)w, lane, toff1, NT * 64, x + inst * (size_t)x_stride + lane, nq_in);
-    float* o = gates + inst * (size_t)g_stride + (size_t)(16 * wave) * 64 + lane;
+    // this wave's gate tile of W_ih stays in registers for the workgroup's ipw consecutive instances: streamed per
+    // instance the launch is bound by L2 (NT x 13-16 KB of fragments for 0.4 us of products per wave)
+    float4 wr[kPreMaxQ];
+    {
+        const float4* wp = (const float4*)w + wave * 64 + lane;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) o[r * 64] = acc[0][r];
+        for (int q = 0; q < kPreMaxQ; ++q) wr[q] = wp[(size_t)(q < nq_in ? q : nq_in - 1) * NT * 64];
+    }
+    const int toff1[1] = {wave * 64};
+    f32x16 bias[1];
+    load_bias<1>(bias, b, toff1, lane >> 5);
+    const long i0 = (long)blockIdx.x * ipw;
+    for (int k = 0; k < ipw && i0 + k < n_inst; ++k) {
+        const size_t inst = (size_t)(i0 + k);
+        const float* xb = x + inst * (size_t)x_stride + lane;
+        f32x16 acc = bias[0];
+#pragma unroll
+        for (int q = 0; q < kPreMaxQ; ++q) {
+            if (q < nq_in) {
+                const float b0 = xb[(4 * q + 0) * 64], b1 = xb[(4 * q + 1) * 64], b2 = xb[(4 * q + 2) * 64], b3 = xb[(4 * q + 3) * 64];
+                acc = mfma32(wr[q].x, b0, acc);
+                acc = mfma32(wr[q].y, b1, acc);
+                acc = mfma32(wr[q].z, b2, acc);
+                acc = mfma32(wr[q].w, b3, acc);
+            }
+        }
+        float* o = gates + inst * (size_t)g_stride + (size_t)(16 * wave) * 64 + lane;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[r * 64] = acc[r];
+    }
 }
 
 static int launch_lstm_pre(int NT, const float* w, const float* b, int nq_in, const float* x, long x_stride,
                            float* gates, long g_stride, long insts, hipStream_t st) {
     if (insts > 0x7fffffffL) { set_error("lstm_pre_kernel: too many instances"); return -2; }
-    if (NT == 13) hipLaunchKernelGGL(lstm_pre_kernel<13>, dim3((unsigned)insts), dim3(64 * 13), 0, st, w, b, nq_in, x, x_stride, gates, g_stride);
-    else if (NT == 16) hipLaunchKernelGGL(lstm_pre_kernel<16>, dim3((unsigned)insts), dim3(64 * 16), 0, st, w, b, nq_in, x, x_stride, gates, g_stride);
+    if (nq_in < 1 || nq_in > kPreMaxQ) { set_error("lstm_pre_kernel: %d input quads (1..%d built)", nq_in, kPreMaxQ); return -4; }
+    if (insts <= 0) return 0;
+    // instances per workgroup: as many as still leave four workgroups per CU
+    int ipw = (int)(insts / 1024);
+    ipw = ipw < 1 ? 1 : (ipw > 16 ? 16 : ipw);
+    const unsigned grid = (unsigned)((insts + ipw - 1) / ipw);
+    if (NT == 13) hipLaunchKernelGGL(lstm_pre_kernel<13>, dim3(grid), dim3(64 * 13), 0, st, w, b, nq_in, x, x_stride, gates, g_stride, insts, ipw);
+    else if (NT == 16) hipLaunchKernelGGL(lstm_pre_kernel<16>, dim3(grid), dim3(64 * 16), 0, st, w, b, nq_in, x, x_stride, gates, g_stride, insts, ipw);
     else { set_error("unsupported LSTM hidden size: %d tiles of 8 units", NT); return -4; }
     return launch_check("lstm_pre_kernel");
 }
@@ -2848,23 +3101,25 @@ static int encode_windows_layer1_impl(const vsv_dims* dims, const float* packed,
     return launch_dense_chain(h, st);
 }
 
-static size_t dec_split_bytes(const Layout& lay, long n_rows, int T, size_t off[2]) {
+static size_t dec_split_bytes(const Layout& lay, long n_rows, int T, size_t off[4]) {
     const long rt = (n_rows + 31) / 32;
-    off[0] = 0;
-    off[1] = align256((size_t)rt * T * 4 * lay.NTd * 64 * sizeof(float));                      // h0 | layer-1 pre-activations
-    return off[1] + align256((size_t)rt * T * 16 * lay.NTd * 64 * sizeof(float)) + 256;
+    off[0] = 0;                                                                                // h0
+    off[1] = align256((size_t)rt * T * 4 * lay.NTd * 64 * sizeof(float));                      // layer-1 pre-activations
+    off[2] = off[1] + align256((size_t)rt * T * 16 * lay.NTd * 64 * sizeof(float));            // layer-0 pre-activations
+    off[3] = off[2] + align256((size_t)rt * T * 16 * lay.NTd * 64 * sizeof(float));            // [ctx | z] in tile-B
+    return off[3] + align256((size_t)rt * T * lay.dec.kx * 64 * sizeof(float)) + 256;
 }
 
 extern "C" size_t vsv_decode_prefix_split_ws_bytes(const vsv_dims* dims, long n_rows, int T) {
     Layout lay;
     const char* msg = nullptr;
-    size_t off[2];
+    size_t off[4];
     if (!dims || make_layout(*dims, lay, &msg) != 0 || n_rows < 0 || T < 0) return 0;
     return dec_split_bytes(lay, n_rows, T, off);
 }
 
 static int decode_prefix_check(const char* who, const Layout& lay, const float* packed, const vsv_decode_in* in, long n_rows,
-                               int T, void* ws, size_t ws_bytes, size_t off[2]) {
+                               int T, void* ws, size_t ws_bytes, size_t off[4]) {
     if (lay.NL != 2) { set_error("%s: the layer split is for two-layer memories", who); return -4; }
     if (!packed || !in || !ws) { set_error("%s: null pointer", who); return -1; }
     if (n_rows < 1 || n_rows > 0x7fffffffL || T < 1) { set_error("%s: bad sizes", who); return -1; }
@@ -2878,7 +3133,7 @@ static int decode_prefix_check(const char* who, const Layout& lay, const float* 
 extern "C" int vsv_decode_prefix_layer0(const vsv_dims* dims, const float* packed, const vsv_decode_in* in, long n_rows,
                                         int T, float* state_out, void* ws, size_t ws_bytes, void* stream) {
     VSV_LAYOUT_OR_FAIL("vsv_decode_prefix_layer0")
-    size_t off[2];
+    size_t off[4];
     if (int rc = decode_prefix_check("vsv_decode_prefix_layer0", lay, packed, in, n_rows, T, ws, ws_bytes, off)) return rc;
     if (in->ctx_T != T || in->z_T != T || !in->ctx || !in->zb || in->lv) {
         set_error("vsv_decode_prefix_layer0: the prefix runs on (ctx_t, z_mean_t) for all T steps"); return -1;
@@ -2897,13 +3152,32 @@ extern "C" int vsv_decode_prefix_layer0(const vsv_dims* dims, const float* packe
     l.state_out = state_out;
     l.hout = (float*)(base + off[0]); l.t_out0 = 0;
     l.st_nl = 2; l.st_l0 = 0;
-    return launch_lstm<1>(l, lay.NTd, 1, false, (hipStream_t)stream);
+    hipStream_t st = (hipStream_t)stream;
+    LstmSeqArgs r = l;
+    r.pre_g = (const float*)(base + off[2]);
+    if (!lstm_rec16_applies(r, 1)) return launch_lstm<1>(l, lay.NTd, 1, false, st);
+    // [ctx_t | z_mean_t] of every step, its gate pre-activations as one GEMM over all (row tile, step) instances, and
+    // the 16-row recurrent launch
+    float* x = (float*)(base + off[3]);
+    l.sv_x = x;
+    const long total = l.n_rowtiles * T * dc.kx * 64;
+    if ((total + 255) / 256 > 0x7fffffffL) { set_error("vsv_decode_prefix_layer0: too many instances"); return -2; }
+    hipLaunchKernelGGL(decoder_input_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, l);
+    int rc = launch_check("decoder_input_kernel");
+    if (rc) return rc;
+    rc = launch_lstm_pre(lay.NTd, l.w[0], l.b[0], dc.kx >> 2, x, (long)dc.kx * 64, (float*)(base + off[2]), (long)16 * lay.NTd * 64,
+                         l.n_rowtiles * T, st);
+    if (rc) return rc;
+    r.din = vsv_decode_in();
+    r.din.state_in = in->state_in; r.din.state_div = 1;
+    r.din.gate_out = in->gate_out;
+    return launch_lstm<0>(r, lay.NTd, 1, false, st);
 }
 
 extern "C" int vsv_decode_prefix_layer1(const vsv_dims* dims, const float* packed, const vsv_decode_in* in, long n_rows,
                                         int T, float* state_out, void* ws, size_t ws_bytes, void* stream) {
     VSV_LAYOUT_OR_FAIL("vsv_decode_prefix_layer1")
-    size_t off[2];
+    size_t off[4];
     if (int rc = decode_prefix_check("vsv_decode_prefix_layer1", lay, packed, in, n_rows, T, ws, ws_bytes, off)) return rc;
     hipStream_t st = (hipStream_t)stream;
     const DecLayout& dc = lay.dec;
@@ -2947,7 +3221,7 @@ static int prefix_plan(const Layout& lay, long n_days, int C, int n_seg, PrefixP
     const size_t nse = (size_t)lay.NL * 2 * 8 * lay.NTm, nsd = (size_t)lay.NL * 2 * 8 * lay.NTd;
     for (int i = 0; i < n_seg; ++i) {
         const int T = ((i + 1) * C) / n_seg - (i * C) / n_seg;
-        size_t off5[5], off2[2];
+        size_t off5[5], off2[4];
         p.seg_off[i] = cur;
         // (the largest segment's sizes serve all: blocks are laid out with the first segment's T or larger)
         const size_t wse = enc_split_bytes(lay, n_days, T, off5), wsd = dec_split_bytes(lay, n_days, T, off2);
@@ -2981,7 +3255,7 @@ extern "C" int vsv_context_prefix(const vsv_dims* dims, const float* packed, con
     if (!packed || !vol || !streams || !state_out || !gate_out || !ws) { set_error("vsv_context_prefix: null pointer"); return -1; }
     if (lay.X > 0 && !ex) { set_error("vsv_context_prefix: ex_feats_dim > 0 but ex is null"); return -1; }
     if (n_days < 1 || (n_days + 31) / 32 > kWideMaxRowtiles) { set_error("vsv_context_prefix: 1..%ld days per call", kWideMaxRowtiles * 32); return -5; }
-    if (n_streams != 3 && n_streams != 4 && n_streams != 6) { set_error("vsv_context_prefix: 3, 4 or 6 worker streams"); return -1; }
+    if (n_streams != 2 && n_streams != 3 && n_streams != 4 && n_streams != 6) { set_error("vsv_context_prefix: 2, 3, 4 or 6 worker streams"); return -1; }
     PrefixPlan pl;
     if (prefix_plan(lay, n_days, ctx_len, n_seg, pl) != 0) { set_error("vsv_context_prefix: 1 <= n_seg <= min(64, ctx_len)"); return -1; }
     if (ws_bytes < pl.total) { set_error("vsv_context_prefix: workspace too small"); return -1; }
@@ -2990,8 +3264,10 @@ extern "C" int vsv_context_prefix(const vsv_dims* dims, const float* packed, con
     // streams (HIP's default number of hardware queues) the two encoders' same-layer stages share one
     hipStream_t sq[6];
     for (int k = 0; k < 6; ++k) {
-        static const int map4[6] = {0, 0, 1, 1, 2, 3}, map3[6] = {0, 0, 1, 1, 2, 2};
-        sq[k] = (hipStream_t)streams[n_streams == 6 ? k : (n_streams == 4 ? map4[k] : map3[k])];
+        // (two: the posterior encoder and the decoder on one stream -- it may be the caller's own --, the context
+        // encoder beside them on the other: the fewest hardware queues, the schedule for unsegmented prefixes)
+        static const int map4[6] = {0, 0, 1, 1, 2, 3}, map3[6] = {0, 0, 1, 1, 2, 2}, map2[6] = {0, 0, 1, 1, 0, 0};
+        sq[k] = (hipStream_t)streams[n_streams == 6 ? k : (n_streams == 4 ? map4[k] : (n_streams == 3 ? map3[k] : map2[k]))];
     }
     auto ev_new = [](hipEvent_t& e) { return hipEventCreateWithFlags(&e, hipEventDisableTiming) == hipSuccess; };
     auto fail_hip = [](const char* what) { set_error("vsv_context_prefix: %s: %s", what, hipGetErrorString(hipGetLastError())); return -3; };
@@ -3008,7 +3284,7 @@ extern "C" int vsv_context_prefix(const vsv_dims* dims, const float* packed, con
     for (int i = 0; i < n_seg && rc == 0; ++i) {
         const int t0 = (i * ctx_len) / n_seg, T = ((i + 1) * ctx_len) / n_seg - t0;
         const bool last = i == n_seg - 1;
-        size_t off5[5], off2[2];
+        size_t off5[5], off2[4];
         const size_t wse = enc_split_bytes(lay, n_days, T, off5), wsd = dec_split_bytes(lay, n_days, T, off2);
         char* b = base + pl.seg_off[i];
         void* ws_e = b; b += align256(wse);
@@ -3506,34 +3782,6 @@ extern "C" int vsv_philox_normal(uint64_t seed, long day0, long n_days, long S, 
     hipLaunchKernelGGL(philox_normal_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream,
                        seed, day0, S, step0, n_steps, L, total, out);
     return launch_check("philox_normal_kernel");
-}
-
-// The decoder memory's input [ctx_pad | z] of every (row, step) in the tile-B layout the training kernels save
-// (sv_x: [inst = rowtile*T + t][kx slots][64], slot s of lane hh*32 + r = feature 2s + hh of row 32*rowtile + r),
-// with the reparameterised z written to z_out: what lstm_kernel<.., XMODE 1> assembles on its time loop, as one
-// launch of its own, so that the decoder's first layer can run as a pre-activation GEMM (lstm_pre_kernel) and the
-// register-resident recurrent launch (lstm_rec_kernel) like every other layer of a training step.
-__global__ void __launch_bounds__(256) decoder_input_kernel(const LstmSeqArgs a) {
-    const long total = a.n_rowtiles * a.T * a.kx * 64;
-    const long i = (long)blockIdx.x * 256 + threadIdx.x;
-    if (i >= total) return;
-    const int lane = (int)(i & 63);
-    const int s = (int)((i >> 6) % a.kx);
-    const long inst = (i >> 6) / a.kx;
-    const int t = (int)(inst % a.T);
-    const long rowtile = inst / a.T;
-    const long row_raw = rowtile * 32 + (lane & 31);
-    const bool row_ok = row_raw < a.n_rows;
-    const long row = row_ok ? row_raw : a.n_rows - 1;
-    const vsv_decode_in& d = a.din;
-    DecIn di = {};
-    const long day_rel = row / d.S;
-    if (d.ctx) di.ctx = d.ctx + (row / d.ctx_div) * d.ctx_rs;
-    if (d.zb) di.z_idx = (row / d.z_div) * d.z_rs;
-    di.eps = d.eps_in ? d.eps_in + (size_t)row * d.eps_T * a.L : nullptr;
-    di.sample = (uint32_t)(row - day_rel * d.S);
-    di.day = (uint32_t)d.day0 + (uint32_t)day_rel;
-    a.sv_x[i] = decoder_input(a, di, row, row_ok, true, t, 2 * s + (lane >> 5));
 }
 
 // ---------------------------------------------------------------------------

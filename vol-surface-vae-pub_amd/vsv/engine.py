@@ -495,10 +495,17 @@ class Engine:
     def context_prefix(self, vol, ex, n_days: int, ctx_len: int, n_seg: int, n_streams: int = 4):
         """vsv_context_prefix: decoder state after the context steps + first-step shared gates for the windows
         vol[d : d + ctx_len], as a pipeline of layer stages over time segments on the engine's worker streams."""
-        pool = getattr(self, "_stage_streams", None)
-        if pool is None or len(pool) < n_streams:
-            pool = self._stage_streams = [torch.cuda.Stream(self.device) for _ in range(6)]
-        arr = (C.c_void_p * n_streams)(*[s.cuda_stream for s in pool[:n_streams]])
+        if n_streams == 2:
+            # the caller's stream and the engine's side stream (the pair encode_both_windows runs on)
+            if self._side is None:
+                self._side = torch.cuda.Stream(self.device)
+            handles = [torch.cuda.current_stream(self.device).cuda_stream, self._side.cuda_stream]
+        else:
+            pool = getattr(self, "_stage_streams", None)
+            if pool is None or len(pool) < n_streams:
+                pool = self._stage_streams = [torch.cuda.Stream(self.device) for _ in range(6)]
+            handles = [s.cuda_stream for s in pool[:n_streams]]
+        arr = (C.c_void_p * n_streams)(*handles)
         state = torch.empty((n_days, self.state_floats), dtype=torch.float32, device=self.device)
         gates = torch.empty((n_days, self.gate_floats), dtype=torch.float32, device=self.device)
         ws = self._ws(self.lib.vsv_context_prefix_ws_bytes(C.byref(self.dims), n_days, ctx_len, n_seg))

@@ -56,33 +56,37 @@ def prior_generate(eng: Engine, surf_ctx: torch.Tensor, ex_ctx: Optional[torch.T
     return r["surf"], r["ex"], zm
 
 
+SPLIT_MAX_DAYS = 3500      # beyond: the fused three-segment schedule (see _context_prefix)
+
+
 def _context_prefix(eng: Engine, sv: torch.Tensor, se: Optional[torch.Tensor], n_days: int, ctx_len: int,
                     n_seg: Optional[int] = None):
     """Decoder state after the C context steps of the windows sv[d : d + C] (d < n_days), and the first
     future step's shared gates: posterior mean and context embedding from the two encoders, then the
     decoder over (ctx_t, z_mean_t).
-    Every recurrent launch is bound by one CU per 32-day tile stepping through time, so the C steps are cut
-    into time segments whose stages overlap on several streams, the memory states handed from segment to
-    segment.  Two schedules (same products in the same order, bit-equal results):
-      * fused stacks, three streams (posterior encoder, context encoder, decoder), three segments;
-      * opt-in, VSV_PREFIX_LAYERS=1 (two-layer memories): every stack also split into its two layers -- layer 1's input
-        product b + W_ih . h0 leaves the time loop for one launch over all steps -- with the decoder's two
-        layers on streams of their own (four worker streams = HIP's default number of hardware queues), all
-        launches issued by the native vsv_context_prefix.  Measured prefix latency, context 60: 2.11 / 2.21 /
-        2.47 ms at 500 / 1000 / 2000 days against 2.40 / 2.56 / 2.59 ms fused when no two busy streams share a
-        hardware queue, 3.2 ms at 500 days when they do; beyond 2000 days the CUs are saturated and the extra
-        launches cost more than the overlap gains (4000 days: 3.4 vs 3.06 ms).
-    VSV_PREFIX_SEGMENTS overrides the segment count (1 = one fused launch per stack); VSV_PREFIX_LAYERS = 0 /
-    1 / py forces the fused / split / split-driven-from-Python schedule, VSV_PREFIX_STREAMS = 3 / 4 / 6."""
+    Every recurrent launch is a chain of C sequential steps, each bound by the matrix pipe of the one CU a row tile
+    sits on.  Two schedules (same products in the same order, bit-equal results):
+      * layer stages (the default for two-layer nn.LSTM memories up to SPLIT_MAX_DAYS days): every stack as one launch
+        per layer -- layer 1's input product b + W_ih . h0 leaves the time loop for one GEMM over all steps -- and the
+        recurrent launches on 16-day tiles (lstm_rec16_kernel: twice the CUs, half the matrix time per step, W_hh in
+        registers), issued by the native vsv_context_prefix on two streams (posterior encoder + decoder on the
+        caller's, context encoder beside them).  Context 60: 1.32 / 1.52 / 1.88 / 2.56 ms at 500 / 1000 / 2000 / 3000
+        days;
+      * fused stacks (one two-layer launch per stack and time segment) on three streams in three segments, the
+        encoders' segment i+1 beside the decoder's segment i: 2.5 - 2.6 ms up to 2000 days, 2.96 ms at 4000, where
+        all 256 CUs are busy either way and the stages' extra launches cost more than the smaller tiles gain.
+    VSV_PREFIX_LAYERS = 0 / 1 / py forces the fused / layer-stage / layer-stage-driven-from-Python schedule,
+    VSV_PREFIX_SEGMENTS the segment count, VSV_PREFIX_STREAMS = 2 / 3 / 4 / 6 the worker streams of the layer stages
+    (with HIP's default of four hardware queues more than two busy streams may share a queue and serialise: 1.2 or
+    1.9 ms at 500 days from one process to the next with four)."""
     L = eng.L
     mode = os.environ.get("VSV_PREFIX_LAYERS", "")
-    # (opt-in: with HIP's default of four hardware queues the worker streams may share a queue with each other
-    # or with the caller's stream, and the pipeline then serialises -- 2.1 or 3.2 ms at 500 days from one
-    # process to the next; the fused three-stream schedule measures 2.5 ms every time)
-    split = eng.dims.mem_layers == 2 and mode in ("1", "py")
+    two_lstm = eng.dims.mem_layers == 2 and eng.dims.mem_type == 0
+    split = eng.dims.mem_layers == 2 and (mode in ("1", "py") or (mode == "" and two_lstm and n_days <= SPLIT_MAX_DAYS))
+    auto = split and mode == ""
     if n_seg is None:
-        n_seg = int(os.environ.get("VSV_PREFIX_SEGMENTS", "0")) or (4 if split else 3)
-    if n_seg <= 1 or n_days > eng.MAX_WINDOWS or ctx_len < 4 * n_seg:
+        n_seg = int(os.environ.get("VSV_PREFIX_SEGMENTS", "0")) or (1 if auto else (4 if split else 3))
+    if (n_seg <= 1 and not split) or n_days > eng.MAX_WINDOWS or ctx_len < 4 * n_seg:
         enc, ctx = eng.encode_both_windows(sv, se, n_days, ctx_len)
         zm = enc[..., :L].contiguous()
         pre = eng.decode(n_days, ctx_len, ctx_len, ctx=ctx, zb=zm, want_state=True, want_gates=True)
@@ -92,7 +96,8 @@ def _context_prefix(eng: Engine, sv: torch.Tensor, se: Optional[torch.Tensor], n
     if split and mode == "py":
         return _context_prefix_layers(eng, sv, se, n_days, ctx_len, n_seg, main)
     if split:
-        return eng.context_prefix(sv, se, n_days, ctx_len, n_seg, int(os.environ.get("VSV_PREFIX_STREAMS", "4")))
+        return eng.context_prefix(sv, se, n_days, ctx_len, max(n_seg, 1),
+                                  int(os.environ.get("VSV_PREFIX_STREAMS", "2" if n_seg <= 1 else "4")))
     if eng._side is None:
         eng._side = torch.cuda.Stream(dev)
     if getattr(eng, "_third", None) is None:

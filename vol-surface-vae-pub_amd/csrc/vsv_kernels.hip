@@ -1470,7 +1470,7 @@ __global__ void __launch_bounds__(64 * NT, (NT + 3) / 4) lstm_rec_kernel(const L
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
 
-template <int NT>
+template <int NT, bool SAVE>
 __global__ void __launch_bounds__(512) lstm_rec16_kernel(const LstmSeqArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int KS = 2 * NT;                                     // k-steps of 4 hidden units = gate tiles of 16 rows
@@ -1485,6 +1485,10 @@ __global__ void __launch_bounds__(512) lstm_rec16_kernel(const LstmSeqArgs a) {
     const long rowtile = tile16 >> 1;                              // the 32-row tile of the other kernels' layouts
     const int m = 16 * (int)(tile16 & 1) + d;                      // ... and this lane's row inside it
     const int SNL = a.st_nl > 0 ? a.st_nl : 1;
+    const int SL = (SAVE && a.sv_nl > 0) ? a.sv_nl : 1;           // training: layers per instance in the saved arrays
+    const int L0 = (SAVE && a.sv_nl > 0) ? a.sv_l0 : 0;           // ... and the model's layer this launch runs
+    const bool dropping = SAVE && L0 + 1 < SL && a.drop.p > 0.0f;
+    const DropArgs drop = dropping ? resolve_drop(a.drop) : a.drop;
     const int ntile = __builtin_amdgcn_readfirstlane((KS - wave + 7) / 8);     // tiles this wave owns (TPW or TPW - 1)
     float* const hbase = smem + lane;
 
@@ -1520,7 +1524,11 @@ __global__ void __launch_bounds__(512) lstm_rec16_kernel(const LstmSeqArgs a) {
     auto load_pre = [&](f32x4 (&pre)[TPW], int t) {
 #pragma unroll
         for (int i = 0; i < TPW; ++i) {
-            if (a.pre_t) {
+            if (SAVE) {
+                // (training: lstm_pre_kernel left the pre-activations in the layer's slots of sv_gates)
+                const float* p = a.sv_gates + (((size_t)(rowtile * a.T + t) * SL + L0) * (16 * NT) + gslot[i]) * 64 + l32[i];
+                pre[i] = f32x4{p[0], p[64], p[128], p[192]};
+            } else if (a.pre_t) {
                 const float* p = a.pre_t + (size_t)(2 * gslot[i] + (l32[i] >> 5)) * a.pre_stride + row + (size_t)t * a.pre_tstride;
                 const size_t st = 2 * (size_t)a.pre_stride;
                 pre[i] = f32x4{p[0], p[st], p[2 * st], p[3 * st]};
@@ -1584,6 +1592,20 @@ __global__ void __launch_bounds__(512) lstm_rec16_kernel(const LstmSeqArgs a) {
             c[i] = __builtin_fmaf(fg, c[i], ig * gg);
             h[i] = og * fast_tanh(c[i]);
             if (i < ntile) hw[(wave + 8 * i) * 64] = h[i];
+            if (SAVE && i < ntile) {
+                // activated gates, cell and hidden state of the step, where the backward kernels read them
+                const size_t il = (size_t)(rowtile * a.T + t) * SL + L0;
+                float* sg = a.sv_gates + (il * (16 * NT) + gslot[i]) * 64 + l32[i];
+                sg[0] = ig; sg[64] = fg; sg[128] = gg; sg[192] = og;
+                a.sv_c[(il * HPK + hslot[i]) * 64 + l32[i]] = c[i];
+                a.sv_h[(il * HPK + hslot[i]) * 64 + l32[i]] = h[i];
+                if (dropping) {
+                    float fct[4];
+                    const int u = 4 * (wave + 8 * i) + ul;
+                    dropout_factors(drop, (uint32_t)row, (uint32_t)t, u >> 3, u & 1, L0, fct);
+                    a.sv_hd[((size_t)(rowtile * a.T + t) * HPK + hslot[i]) * 64 + l32[i]] = h[i] * fct[(u & 7) >> 1];
+                }
+            }
         }
         if (a.hout && t >= a.t_out0) {                             // (padding rows too: the next stage reads whole tiles)
             float* ho = a.hout + (size_t)(rowtile * t_outs + (t - a.t_out0)) * HPK * 64;
@@ -2707,11 +2729,13 @@ static bool lstm_rec_applies(const LstmSeqArgs& a, int NL) {
     return infer && (a.pre_t != nullptr || a.pre_g != nullptr);
 }
 
-// the 16-row-tile recurrent launch: inference, one nn.LSTM layer, pre-activations given, few row tiles
+// the 16-row-tile recurrent launch: one nn.LSTM layer, pre-activations given (inference: pre_t / pre_g; training: the
+// layer's slots of sv_gates), few row tiles
 static bool lstm_rec16_applies(const LstmSeqArgs& a, int NL) {
     static const bool off = [] { const char* e = getenv("VSV_REC16"); return e && e[0] == '0'; }();
-    return !off && NL == 1 && !a.sv_gates && (a.pre_t || a.pre_g) && a.gru == 0 && !a.din.gate_in &&
-           a.n_rowtiles <= kWideMaxRowtiles;
+    if (off || NL != 1 || a.gru != 0 || a.din.gate_in || a.n_rowtiles > kWideMaxRowtiles) return false;
+    if (a.sv_gates) return a.rec != 0 && a.st_nl == 0;
+    return a.pre_t != nullptr || a.pre_g != nullptr;
 }
 
 template <int NT>
@@ -2719,7 +2743,8 @@ static int launch_lstm_rec16(const LstmSeqArgs& a, hipStream_t st) {
     const size_t lds = (size_t)2 * 2 * NT * 64 * sizeof(float);
     // (two 16-row tiles per 32-row tile: the odd one of a ragged tail runs on clamped rows, so that the tile-B
     // outputs the next stage reads are written whole)
-    hipLaunchKernelGGL((lstm_rec16_kernel<NT>), dim3((unsigned)(2 * a.n_rowtiles)), dim3(512), lds, st, a);
+    if (a.sv_gates) hipLaunchKernelGGL((lstm_rec16_kernel<NT, true>), dim3((unsigned)(2 * a.n_rowtiles)), dim3(512), lds, st, a);
+    else hipLaunchKernelGGL((lstm_rec16_kernel<NT, false>), dim3((unsigned)(2 * a.n_rowtiles)), dim3(512), lds, st, a);
     return launch_check("lstm_rec16_kernel");
 }
 

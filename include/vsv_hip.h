@@ -29,15 +29,15 @@
 extern "C" {
 #endif
 
-#define VSV_ABI_VERSION 18
+#define VSV_ABI_VERSION 19
 #define VSV_MAX_CONV 4
 #define VSV_MAX_CHAIN 8
 #define VSV_MAX_INTERACT 3
 
 /* Model shape: the subset of the reference's config dict that fixes tensor
  * shapes (cvae_with_mem_randomized.py:969-1020; state_dict layout SURVEY.md
- * appendix A).  Only the production topology is implemented: conv surface
- * embedding on a 5x5 grid, LSTM or GRU memory, compress_context=True, ex_feats_hidden=None;
+ * appendix A): conv (or, use_dense_surface, Linear) surface embedding on a 5x5 grid, LSTM / GRU / RNN
+ * memory, compress_context on or off, ex_feats_hidden=None;
  * interaction_layers 0..2 (the Linear+ReLU "interaction" stacks of :131-142, :283-294, :452-463,
  * turned on by the v3 conditional-prior trainer). */
 typedef struct vsv_dims {
@@ -56,6 +56,13 @@ typedef struct vsv_dims {
                                           -> latent_dim) (:363-366); 0 = its embedding is the memory's output itself
                                           (mem_hidden wide: the class default, :1014-1015) and the decoder memory reads
                                           [ctx (mem_hidden) | z (latent_dim)] */
+    int use_dense_surface;             /* config["use_dense_surface"]: 1 = the surface embeddings are Flatten + Linear+ReLU
+                                          stacks (:84-93, :237-246) and the decoder head Linear stacks (:394-407);
+                                          surface_hidden / ctx_surface_hidden then hold layer WIDTHS, the embedding
+                                          is surface_hidden[-1] wide and the decoder memory surface_hidden[-1] +
+                                          ex_feats_dim (:375-380).  The raw-weight slots *_conv_w / dec_deconv_w /
+                                          dec_out_w then take the nn.Linear weights (out, in) of enc_dense_i /
+                                          ctx_enc_dense_i / dec_dense_i, dec_final / dec_output */
 } vsv_dims;
 
 /* Raw parameters in PyTorch state_dict layout (HOST pointers, float32,

@@ -498,6 +498,34 @@ def main_nocompress():
     case_cprior_train("g8_cprior_train_nocomp_ex5_B4_T24_h3", ex5, 100, 2.0, 4, 24, 3, [1, 7])
 
 
+def main_dense():
+    """use_dense_surface=True: Flatten + Linear+ReLU surface embeddings (:84-93, :237-246), decoder memory of width
+    surface_hidden[-1] + ex_feats_dim (:375-380), Linear decoder stack back to the grid (:394-407), the prior
+    network's dense embedding (conditional_prior_network.py:90-99).  No reference config turns it on; widths chosen
+    to cross tile boundaries (40 > 32 units, 8 < one tile) and to differ between encoder and context encoder."""
+    f32, f64 = np.float32, np.float64
+
+    def mk(L, X, sh, csh=None, **kw):
+        cfg = vo.make_config(L, X, surface_hidden=sh, use_dense_surface=True, **kw)
+        cfg["ctx_surface_hidden"] = list(csh if csh is not None else sh)
+        return cfg
+    ex5 = mk(5, 3, (40, 16, 8))
+    noex = mk(5, 0, (24, 12), csh=(30,))
+    ex12 = mk(12, 3, (64, 32, 16), csh=(48, 20), quantile_loss_weights=[5.0, 1.0, 5.0], kl_weight=1e-3)
+    gru = mk(5, 3, (33,), mem_type="gru", interaction_layers=1, compress_context=False)
+    case_forward("g1_fwd_dense_ex5_T21_h1_f32", ex5, 130, 2.0, f32, 4, 21, 1)
+    case_forward("g1_fwd_dense_noex_T9_h3_f64", noex, 131, 2.0, f64, 3, 9, 3)
+    case_forward("g1_fwd_dense_gru_int1_T12_h2_f32", gru, 132, 2.0, f32, 3, 12, 2)
+    case_prior("g2_prior_dense_ex12_C20_H7_f32", ex12, 133, 2.0, f32, 6, 20, 7)
+    case_prior("g2_prior_dense_noex_C5_H1_f64", noex, 134, 2.0, f64, 8, 5, 1)
+    case_grads("g4_grads_dense_ex5_B6_T21_h3", ex5, 135, 2.0, 6, 21, 3, full=False)
+    case_grads("g4_grads_dense_ex12_B4_T20_h7", ex12, 136, 2.0, 4, 20, 7, full=False)
+    case_grads("g4_grads_dense_gru_int1_B5_T9_h2", gru, 137, 2.0, 5, 9, 2, full=False)
+    case_ar("g6_ar_dense_ex5_C20_H30", ex5, 138, 2.0, 4, 20, 30)
+    case_cprior_gen("g8_cprior_gen_dense_ex5_C20_H7_f32", ex5, 139, 2.0, f32, 4, 20, 7, True, 0.3)
+    case_cprior_train("g8_cprior_train_dense_ex5_B4_T24_h3", ex5, 140, 2.0, 4, 24, 3, [1, 7])
+
+
 def main_rnn():
     """mem_type other than "lstm" / "gru": nn.RNN (tanh) memories (:158-159, :310-311, :479-480)."""
     f32, f64 = np.float32, np.float64
@@ -556,6 +584,10 @@ def save(name, cfg, d):
     d["cfg_interaction_layers"] = int(cfg.get("interaction_layers") or 0)
     d["cfg_mem_type"] = np.asarray(cfg.get("mem_type", "lstm"))
     d["cfg_compress_context"] = np.asarray(bool(cfg.get("compress_context", False)))
+    if cfg.get("use_dense_surface", False):
+        d["cfg_use_dense_surface"] = np.asarray(True)
+        d["cfg_surface_hidden"] = np.asarray(list(cfg["surface_hidden"]))
+        d["cfg_ctx_surface_hidden"] = np.asarray(list(cfg["ctx_surface_hidden"]))
     d["cfg_quantile_loss_weights"] = np.asarray(cfg.get("quantile_loss_weights") or [1.0, 1.0, 1.0])
     for k in ("ex_loss_on_ret_only", "ex_feats_loss_type", "kl_weight", "re_feat_weight"):
         d["cfg_" + k] = np.asarray(cfg[k])
@@ -817,6 +849,9 @@ if __name__ == "__main__":
     elif len(sys.argv) > 1 and sys.argv[1] == "round2":
         os.makedirs(OUT, exist_ok=True)
         main_round2()
+    elif len(sys.argv) > 1 and sys.argv[1] == "dense":
+        os.makedirs(OUT, exist_ok=True)
+        main_dense()
     elif len(sys.argv) > 1 and sys.argv[1] == "nocompress":
         os.makedirs(OUT, exist_ok=True)
         main_nocompress()

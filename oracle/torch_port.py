@@ -29,13 +29,15 @@ class TorchPort(nn.Module):
         self.nl = cfg["mem_layers"]
         Hm = cfg["mem_hidden"]
         sh = cfg["surface_hidden"]
-        E = sh[-1] * 25 + self.X
+        self.dense = bool(cfg.get("use_dense_surface", False))
+        E = sh[-1] * (1 if self.dense else 25) + self.X                                   # :93, :109, :375-378
         self.Hd = E
+        Ec = cfg["ctx_surface_hidden"][-1] * (1 if self.dense else 25) + self.X
         self.p = nn.ParameterDict({k.replace(".", "/"): nn.Parameter(torch.tensor(v, dtype=dtype))
                                    for k, v in W.items() if ".mem." not in k})
         self.mems = nn.ModuleDict()
         Lc = self.L if cfg.get("compress_context", False) else Hm                         # :363-366
-        for name, inp, hid in (("encoder", E, Hm), ("ctx_encoder", E, Hm), ("decoder", Lc + self.L, self.Hd)):
+        for name, inp, hid in (("encoder", E, Hm), ("ctx_encoder", Ec, Hm), ("decoder", Lc + self.L, self.Hd)):
             kind = {"lstm": nn.LSTM, "gru": nn.GRU}.get(cfg.get("mem_type", "lstm"), nn.RNN)   # :154-159
             m = kind(inp, hid, num_layers=self.nl, batch_first=True, dropout=dropout)     # :155, :307, :476
             m = m.to(dtype)
@@ -86,6 +88,12 @@ class TorchPort(nn.Module):
     # -- modules ---------------------------------------------------------------
     def _embed(self, surf, prefix, stem, n):
         B, T = surf.shape[:2]
+        if self.dense:                                                                # :84-93, :237-246
+            x = surf.reshape(B * T, 25)
+            stem = stem.replace("_conv", "_dense")
+            for i in range(n):
+                x = F.relu(F.linear(x, self.w(f"{prefix}.{stem}_{i}.weight"), self.w(f"{prefix}.{stem}_{i}.bias")))
+            return x.reshape(B, T, -1)
         x = surf.reshape(B * T, 1, 5, 5)
         for i in range(n):
             x = F.relu(F.conv2d(x, self.w(f"{prefix}.{stem}_{i}.weight"), self.w(f"{prefix}.{stem}_{i}.bias"),
@@ -131,13 +139,21 @@ class TorchPort(nn.Module):
         h = self._interact(h, "decoder", "dec")                                       # :492
         sh = self.cfg["surface_hidden"]
         s = F.linear(h, self.w("decoder.surface_decoder_input.weight"), self.w("decoder.surface_decoder_input.bias"))
-        s = s.reshape(B * T, sh[-1], 5, 5)                                            # :501
-        names = [f"dec_deconv_{i}" for i in range(len(sh) - 1)] + ["dec_final"]
-        for nm in names:
-            s = F.relu(F.conv_transpose2d(s, self.w(f"decoder.surface_decoder.{nm}.weight"),
-                                          self.w(f"decoder.surface_decoder.{nm}.bias"), padding=1))
-        s = F.conv2d(s, self.w("decoder.surface_decoder.dec_output.weight"),
-                     self.w("decoder.surface_decoder.dec_output.bias"), padding=1)
+        if self.dense:                                                                # :394-407, :495-499
+            s = s.reshape(B * T, sh[-1])
+            for nm in [f"dec_dense_{i}" for i in range(len(sh) - 1)] + ["dec_final"]:
+                s = F.relu(F.linear(s, self.w(f"decoder.surface_decoder.{nm}.weight"),
+                                    self.w(f"decoder.surface_decoder.{nm}.bias")))
+            s = F.linear(s, self.w("decoder.surface_decoder.dec_output.weight"),
+                         self.w("decoder.surface_decoder.dec_output.bias"))
+        else:
+            s = s.reshape(B * T, sh[-1], 5, 5)                                        # :501
+            names = [f"dec_deconv_{i}" for i in range(len(sh) - 1)] + ["dec_final"]
+            for nm in names:
+                s = F.relu(F.conv_transpose2d(s, self.w(f"decoder.surface_decoder.{nm}.weight"),
+                                              self.w(f"decoder.surface_decoder.{nm}.bias"), padding=1))
+            s = F.conv2d(s, self.w("decoder.surface_decoder.dec_output.weight"),
+                         self.w("decoder.surface_decoder.dec_output.bias"), padding=1)
         s = s.reshape(B, T, -1, 5, 5)
         e = None
         if self.X > 0:

@@ -41,12 +41,17 @@ def prior_state_dict_spec(cfg: dict) -> List[Tuple[str, Tuple[int, ...]]]:
     compression is nn.Identity() and the heads read the memory's hidden state (:73-78)."""
     L, X, Hm, nl = cfg["latent_dim"], cfg["ex_feats_dim"], cfg["mem_hidden"], cfg["mem_layers"]
     csh = list(cfg["ctx_surface_hidden"])
-    E = csh[-1] * 25 + X
+    dense = bool(cfg.get("use_dense_surface", False))
+    E = csh[-1] * (1 if dense else 25) + X
     spec: List[Tuple[str, Tuple[int, ...]]] = []
-    cin = 1
+    cin = 25 if dense else 1
     for i, co in enumerate(csh):
-        spec.append((f"prior_network.surface_embedding.prior_enc_conv_{i}.weight", (co, cin, 3, 3)))
-        spec.append((f"prior_network.surface_embedding.prior_enc_conv_{i}.bias", (co,)))
+        if dense:                                           # prior_enc_dense_i, conditional_prior_network.py:90-99
+            spec.append((f"prior_network.surface_embedding.prior_enc_dense_{i}.weight", (co, cin)))
+            spec.append((f"prior_network.surface_embedding.prior_enc_dense_{i}.bias", (co,)))
+        else:
+            spec.append((f"prior_network.surface_embedding.prior_enc_conv_{i}.weight", (co, cin, 3, 3)))
+            spec.append((f"prior_network.surface_embedding.prior_enc_conv_{i}.bias", (co,)))
         cin = co
     n_int = cfg.get("interaction_layers") or 0
     if n_int > 0:
@@ -215,6 +220,13 @@ def _embed(surface: np.ndarray, W: Weights, prefix: str, names: Sequence[str]) -
     """Conv2d+ReLU stack then Flatten: (B,T,5,5) -> (B,T,C*25), index
     ch*25+row*5+col (cvae_with_mem_randomized.py:96-110, 176-178)."""
     B, T = surface.shape[:2]
+    if f"{prefix}.{names[0]}.weight" not in W:
+        # use_dense_surface: Flatten, then Linear+ReLU layers named *_dense_i (:84-93, :237-246)
+        x = surface.reshape(B * T, 25)
+        for nm in names:
+            nm = nm.replace("_conv_", "_dense_")
+            x = np.maximum(linear(x, W[f"{prefix}.{nm}.weight"], W[f"{prefix}.{nm}.bias"]), 0)
+        return x.reshape(B, T, -1)
     x = surface.reshape(B * T, 1, 5, 5)
     for nm in names:
         x = np.maximum(conv2d_3x3_same(x, W[f"{prefix}.{nm}.weight"], W[f"{prefix}.{nm}.bias"]), 0)
@@ -329,6 +341,19 @@ def decoder_head(W: Weights, cfg: dict, h: np.ndarray):
     Q = len(cfg["quantiles"])
     h = _interact(h, W, cfg, "decoder", "dec")                  # :492
     s = linear(h, W["decoder.surface_decoder_input.weight"], W["decoder.surface_decoder_input.bias"])
+    if cfg.get("use_dense_surface", False):
+        # Linear+ReLU stack, Linear(-> 25)+ReLU, Linear(25 -> 25 Q) (:394-407, :495-499)
+        s = s.reshape(B * T, sh[-1])
+        for nm in [f"dec_dense_{i}" for i in range(len(sh) - 1)] + ["dec_final"]:
+            p = f"decoder.surface_decoder.{nm}"
+            s = np.maximum(linear(s, W[p + ".weight"], W[p + ".bias"]), 0)
+        p = "decoder.surface_decoder.dec_output"
+        s = linear(s, W[p + ".weight"], W[p + ".bias"]).reshape(B, T, Q, 5, 5)
+        if cfg["ex_feats_dim"] > 0:
+            e = linear(h, W["decoder.ex_feats_decoder_input.weight"], W["decoder.ex_feats_decoder_input.bias"])
+            e = linear(e, W["decoder.ex_feats_decoder.weight"], W["decoder.ex_feats_decoder.bias"])
+            return s, e
+        return s, None
     s = s.reshape(B * T, sh[-1], 5, 5)
     for i in range(len(sh) - 1):
         p = f"decoder.surface_decoder.dec_deconv_{i}"

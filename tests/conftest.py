@@ -39,6 +39,10 @@ def cfg_of(g):
         cfg["mem_type"] = str(g["cfg_mem_type"])
     if "cfg_compress_context" in g:
         cfg["compress_context"] = bool(g["cfg_compress_context"])
+    if "cfg_use_dense_surface" in g and bool(g["cfg_use_dense_surface"]):
+        cfg["use_dense_surface"] = True
+        cfg["surface_hidden"] = [int(x) for x in g["cfg_surface_hidden"]]
+        cfg["ctx_surface_hidden"] = [int(x) for x in g["cfg_ctx_surface_hidden"]]
     for k in ("ex_loss_on_ret_only", "ex_feats_loss_type", "kl_weight", "re_feat_weight"):
         if "cfg_" + k in g:
             v = g["cfg_" + k]

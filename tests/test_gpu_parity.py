@@ -968,3 +968,67 @@ def test_one_launch_adamw_step_equals_torch_adamw():
     for _ in range(3):
         model.train_step({"surface": x["surface"]}, opt)
     assert "max_exp_avg_sq" in opt.state[next(model.parameters())]
+
+
+@pytest.mark.parametrize("mem,L,X,sh,csh", [("lstm", 5, 3, (40, 16, 8), (40, 16, 8)), ("lstm", 12, 0, (24, 12), (30,)),
+                                            ("gru", 5, 3, (96,), (7, 33))])
+def test_dense_surface_mc_product_and_model_class(mem, L, X, sh, csh):
+    """use_dense_surface=True (reference :84-93, :237-246, :375-380, :394-407): Linear stacks in place of the conv
+    embeddings and the conv-transpose head, decoder memory of width surface_hidden[-1] + ex_feats_dim.  The goldens
+    named *_dense_* cover forward / generation / gradients / AR / conditional prior against the reference; here the
+    Monte-Carlo product (shared prefix, fused one-wave decode with Philox noise, one-channel output, percentile
+    reduction, the segmented prefix) against the oracle, and the drop-in class (state_dict keys, device-side packing,
+    training)."""
+    from vsv import paths
+    from vae.cvae_with_mem_randomized import CVAEMemRand
+    C, H, S, N = 6, 2, 1000, 40
+    mk = dict(mem_type=mem, use_dense_surface=True, surface_hidden=sh)
+    cfg = vo.make_config(L, X, **mk)
+    cfg["ctx_surface_hidden"] = list(csh)
+    eng, W = _engine(cfg, 63, 2.0)
+    rng = np.random.default_rng(31)
+    vol = (0.2 + 0.1 * rng.standard_normal((N + C, 5, 5))).astype(np.float32)
+    ex = (0.01 * rng.standard_normal((N + C, X))).astype(np.float32) if X else None
+    q = paths.prior_mc_windows(eng, _t(vol), _t(ex), C, N, C, H, S, seed=7, chunk_days=16, channel=None)
+    eps = _n(eng.philox_normal(7, C, N, S, 0, H)).reshape(N, S, H, L)
+    win = np.stack([vol[d:d + C] for d in range(N)])
+    wex = np.stack([ex[d:d + C] for d in range(N)]) if X else None
+    smp, _ = vo.prior_mc_shared_prefix(W, cfg, win, wex, eps.astype(np.float32))
+    want = np.percentile(smp.astype(np.float64), [5, 50, 95], axis=1).transpose(1, 2, 0, 3, 4, 5)
+    assert err(_n(q), want) <= TOL
+    # horizon 1, one channel: the one-wave decode kernel with the packed one-channel output section
+    q1 = paths.prior_mc_windows(eng, _t(vol), _t(ex), C, N, C, 1, S, seed=7, channel=1)
+    assert err(_n(q1), want[:, :1, :, 1]) <= TOL
+    s1, g1 = paths._context_prefix(eng, _t(vol), _t(ex), N, C, n_seg=1)
+    for layers in ("0", "1"):
+        os.environ["VSV_PREFIX_LAYERS"] = layers
+        try:
+            s2, g2 = paths._context_prefix(eng, _t(vol), _t(ex), N, C, n_seg=2)
+            torch.cuda.synchronize()
+            assert torch.equal(s1, s2) and torch.equal(g1, g2), layers
+        finally:
+            os.environ.pop("VSV_PREFIX_LAYERS", None)
+    torch.manual_seed(1)
+    mcfg = vo.make_config(L, X, device="cuda:0", **mk)
+    mcfg["ctx_surface_hidden"] = list(csh)
+    model = CVAEMemRand(mcfg)
+    assert set(k for k in model.state_dict() if not k.startswith("quantile_loss_fn")) == set(k for k, _ in vo.state_dict_spec(cfg))
+    assert model.decoder.mem.hidden_size == sh[-1] + X
+    x = {"surface": torch.from_numpy(win[:16].copy())}
+    if X:
+        x["ex_feats"] = torch.from_numpy(wex[:16].copy())
+    sd = {k: v.detach().cpu().numpy().astype(np.float64) for k, v in model.state_dict().items()
+          if not k.startswith("quantile_loss_fn")}
+    e_in = rng.standard_normal((16, C, L))
+    want_f = vo.forward(sd, cfg, x["surface"].numpy().astype(np.float64),
+                        x["ex_feats"].numpy().astype(np.float64) if X else None, e_in, 1)
+    got = paths.forward(model._engine(), x["surface"].cuda(), x["ex_feats"].cuda() if X else None, 1, eps=_t(e_in))
+    assert err(_n(got[0]), want_f[0]) <= TOL
+    opt = torch.optim.AdamW(model.parameters(), lr=1e-3)
+    first = None
+    for _ in range(20):
+        losses = model.train_step(x, opt)
+        assert torch.isfinite(losses["loss"])
+        first = first if first is not None else float(losses["loss"])
+    assert float(losses["loss"]) < first
+    assert model.forward(x)[0].shape == (16, 1, 3, 5, 5)

@@ -27,6 +27,7 @@ constexpr int kMaxDenseLayers = 8;
 constexpr int kMaxFeat = 128;      // widest activation vector (4 tiles of 32)
 constexpr int kMaxChannels = 5;  // n_quantiles * 25 <= kMaxFeat
 constexpr int kHeadTiles = 4;      // decoder-head layers (all but the last) are padded to 4 tiles
+constexpr int kDenseEx0 = 96;      // use_dense_surface: first ex-feature slot of a layer that carries them (its last tile)
 
 struct Sec {                       // one packed layer
     size_t w_off = 0, b_off = 0;   // offsets in floats into the blob
@@ -46,9 +47,9 @@ struct EncLayout {
     Sec lstm[2];                   // k-space: layer 0 = [x: kx | h0: 4*NTm], layer 1 = [h0 | h1]
     Sec head;                      // [z_mean; z_log_var] (which=0) or final_compression / identity (which=1)
     int nh = 0;                    // head outputs: 2L or Lc
-    int E = 0;                     // LSTM input features: c_last*25 + X
+    int E = 0;                     // LSTM input features: c_last*25 + X (dense surfaces: c_last + X)
     int kx = 0;                    // k-steps of the LSTM x part (PERM32 order): 16 * tiles of the chain's last layer
-    int ex_f0 = 0;                 // first ex-feature slot in the embedding (c_last*25)
+    int ex_f0 = 0;                 // first ex-feature slot in the embedding (c_last*25; dense surfaces: kDenseEx0)
 };
 
 struct DecLayout {
@@ -72,6 +73,7 @@ struct Layout {
     int L = 0, X = 0, Hm = 0, NL = 0, Q = 0;
     int Lc = 0;                    // context-embedding width: L (compress_context) or Hm
     int NI = 0;                    // interaction Linears per module: 0, or interaction_layers + 1
+    bool dense = false;            // use_dense_surface: Linear stacks in place of the conv / conv-transpose stacks
     int gru = 0;                   // memory cell: 0 nn.LSTM, 1 nn.GRU (gate slots r, z, n_x, n_h), 2 nn.RNN (slot 0)
     int Hd = 0;                    // decoder LSTM hidden = c_last*25 + X
     int NTm = 0, NTd = 0;          // gate tiles (8 hidden units each) of encoder / decoder LSTMs

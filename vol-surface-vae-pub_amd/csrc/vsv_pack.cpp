@@ -90,12 +90,15 @@ int make_layout(const vsv_dims& d, Layout& lay, const char** msg) {
         return fail("1..4 conv layers supported");
     if (d.n_conv + lay.NI > kMaxDenseLayers || d.n_ctx_conv + lay.NI > kMaxDenseLayers || 2 + d.n_conv + lay.NI > kMaxDenseLayers)
         return fail("too many conv + interaction layers for one dense chain (8)");
+    lay.dense = d.use_dense_surface != 0;
+    // feature count of an embedding / head layer with `c` channels (conv: c maps of 5x5) or `c` units (dense)
+    const int per = lay.dense ? 1 : 25;
     for (int i = 0; i < d.n_conv; ++i)
-        if (d.surface_hidden[i] < 1 || d.surface_hidden[i] * 25 + lay.X > kMaxFeat)
-            return fail("surface_hidden[i]*25 + ex_feats_dim must be <= 128");
+        if (d.surface_hidden[i] < 1 || d.surface_hidden[i] * per + (lay.dense ? 0 : lay.X) > kMaxFeat)
+            return fail(lay.dense ? "surface_hidden[i] must be in [1,128]" : "surface_hidden[i]*25 + ex_feats_dim must be <= 128");
     for (int i = 0; i < d.n_ctx_conv; ++i)
-        if (d.ctx_surface_hidden[i] < 1 || d.ctx_surface_hidden[i] * 25 + lay.X > kMaxFeat)
-            return fail("ctx_surface_hidden[i]*25 + ex_feats_dim must be <= 128");
+        if (d.ctx_surface_hidden[i] < 1 || d.ctx_surface_hidden[i] * per + (lay.dense ? 0 : lay.X) > kMaxFeat)
+            return fail(lay.dense ? "ctx_surface_hidden[i] must be in [1,128]" : "ctx_surface_hidden[i]*25 + ex_feats_dim must be <= 128");
     // gate tiles of 8 hidden units.  The recurrent kernels are built for 13 and 16 tiles (hidden 97..104 and
     // 121..128, the widths of every reference config); any other width runs on the next built size: the
     // extra units have all-zero weights and biases, so their gates are sigmoid(0) / tanh(0), their c and h
@@ -103,14 +106,22 @@ int make_layout(const vsv_dims& d, Layout& lay, const char** msg) {
     auto built_tiles = [](int nt) { return nt <= 13 ? 13 : 16; };
     lay.NTm = built_tiles(cdiv(lay.Hm, 8));
     const int c_last = d.surface_hidden[d.n_conv - 1];
-    if (lay.X > 0) {
+    if (lay.X > 0 && !lay.dense) {
         // the kernels look for the ex-feature slots only in the last (4th) tile of a layer
         const int cc = d.ctx_surface_hidden[d.n_ctx_conv - 1];
         const int c0 = d.n_conv > 1 ? d.surface_hidden[d.n_conv - 2] : c_last;
         if (c_last * 25 < 96 || cc * 25 < 96 || c0 * 25 < 96)
             return fail("with ex_feats_dim > 0 the last conv layers need >= 4 channels (ex slots live in features 96..127)");
     }
-    lay.Hd = c_last * 25 + lay.X;
+    if (lay.X > 0 && lay.dense) {
+        // dense surfaces: the ex-feature slots sit at kDenseEx0 = 96 .. 96 + X of their layers (the last tile, where
+        // the kernels look for them), the surface units below them
+        const int cc = d.ctx_surface_hidden[d.n_ctx_conv - 1];
+        const int c0 = d.n_conv > 1 ? d.surface_hidden[d.n_conv - 2] : 25;
+        if (c_last > kDenseEx0 || cc > kDenseEx0 || c0 > kDenseEx0)
+            return fail("use_dense_surface with ex_feats_dim > 0: the last embedding layers must be <= 96 wide");
+    }
+    lay.Hd = c_last * per + lay.X;
     lay.NTd = built_tiles(cdiv(lay.Hd, 8));
 
     size_t cur = 0;
@@ -119,21 +130,23 @@ int make_layout(const vsv_dims& d, Layout& lay, const char** msg) {
         const int* ch = which ? d.ctx_surface_hidden : d.surface_hidden;
         e.n_conv = which ? d.n_ctx_conv : d.n_conv;
         int nt_prev = 0;
+        // first ex-feature slot of the embedding: right behind the surface features, or (dense surfaces) at 96
+        e.ex_f0 = (lay.dense && lay.X > 0) ? kDenseEx0 : ch[e.n_conv - 1] * per;
+        const int e_ext = e.ex_f0 + lay.X;                     // extent of the embedding in feature slots
         for (int i = 0; i < e.n_conv; ++i) {
             const bool last = (i == e.n_conv - 1);
-            const int n_out = ch[i] * 25 + (last ? lay.X : 0);
+            const int n_out = last ? e_ext : ch[i] * per;
             const int nt = cdiv(n_out, 32);
             const int nq = (i == 0) ? cdiv(cdiv(25, 2), 4) : 4 * nt_prev;
-            e.conv[i] = alloc_sec(cur, nq, nt, n_out, ch[i] * 25);
+            e.conv[i] = alloc_sec(cur, nq, nt, n_out, ch[i] * per);
             nt_prev = nt;
         }
-        e.E = ch[e.n_conv - 1] * 25 + lay.X;
-        e.ex_f0 = ch[e.n_conv - 1] * 25;
+        e.E = ch[e.n_conv - 1] * per + lay.X;
         e.n_chain = e.n_conv;
         for (int j = 0; j < lay.NI; ++j) {
             // interaction Linear j: E -> E, ReLU on all but the final one
-            const int nt = cdiv(e.E, 32);
-            e.conv[e.n_chain++] = alloc_sec(cur, 4 * nt_prev, nt, e.E, j < lay.NI - 1 ? e.E : 0);
+            const int nt = cdiv(e_ext, 32);
+            e.conv[e.n_chain++] = alloc_sec(cur, 4 * nt_prev, nt, e_ext, j < lay.NI - 1 ? e_ext : 0);
             nt_prev = nt;
         }
         e.kx = 16 * nt_prev;
@@ -153,21 +166,23 @@ int make_layout(const vsv_dims& d, Layout& lay, const char** msg) {
     for (int j = 0; j < lay.NI; ++j)       // interaction Linears on the LSTM output: Hd -> Hd
         dc.head[nh++] = alloc_sec(cur, j == 0 ? lay.NTd : 4 * kHeadTiles, kHeadTiles, lay.Hd, j < lay.NI - 1 ? lay.Hd : 0);
     {
-        const int n_out = c_last * 25 + lay.X;
+        const int n_out = (lay.dense && lay.X > 0) ? kDenseEx0 + lay.X : c_last * per + lay.X;
         dc.head[nh++] = alloc_sec(cur, lay.NI > 0 ? 4 * kHeadTiles : lay.NTd, kHeadTiles, n_out, 0);
     }
     int cin = c_last;
     for (int i = 0; i < d.n_conv; ++i) {
-        // dec_deconv_i maps reversed(surface_hidden[:-1])[i]; dec_final keeps the channel count
-        const int cout = (i < d.n_conv - 1) ? d.surface_hidden[d.n_conv - 2 - i] : cin;
+        // dec_deconv_i / dec_dense_i maps reversed(surface_hidden[:-1])[i]; dec_final keeps the channel count
+        // (conv) or maps to the 25 grid points (dense, :401-404)
+        const int cout = (i < d.n_conv - 1) ? d.surface_hidden[d.n_conv - 2 - i] : (lay.dense ? 25 : cin);
         const bool carries_ex = (i == 0 && lay.X > 0);
-        const int n_out = cout * 25 + (carries_ex ? lay.X : 0);
+        const int f_ex = lay.dense ? kDenseEx0 : cout * 25;
+        const int n_out = carries_ex ? f_ex + lay.X : cout * per;
         if (carries_ex) {
             dc.ex_layer = nh;
-            dc.ex_f0 = cout * 25;
+            dc.ex_f0 = f_ex;
         }
-        dc.head[nh++] = alloc_sec(cur, 4 * kHeadTiles, kHeadTiles, n_out, cout * 25);
-        if (i > 0) conv_band(dc.head[nh - 1], cin, cout);      // (layer 0 carries the ex riders and is folded)
+        dc.head[nh++] = alloc_sec(cur, 4 * kHeadTiles, kHeadTiles, n_out, cout * per);
+        if (i > 0 && !lay.dense) conv_band(dc.head[nh - 1], cin, cout);      // (layer 0 carries the ex riders and is folded)
         cin = cout;
     }
     dc.head[nh++] = alloc_sec(cur, 4 * kHeadTiles, cdiv(lay.Q * 25, 32), lay.Q * 25, 0);
@@ -232,6 +247,15 @@ static InMap in_perm(int n_in) {
         const int f = 32 * (s >> 4) + 8 * ((s >> 2) & 3) + 4 * hh + (s & 3);
         return f < n_in ? f : -1;
     };
+}
+// Dense surfaces (use_dense_surface): a layer's h surface units sit at slots 0..h-1 and the X ex-feature riders at
+// slots x0..x0+X-1 (x0 = kDenseEx0 >= h); index = position in the reference's [surface | ex] concatenation.
+static inline int gap2orig(int f, int h, int X, int x0) { return f < h ? f : (f >= x0 && f < x0 + X ? h + (f - x0) : -1); }
+static OutMap out_gap(int h, int X, int x0) {
+    return [=](int t, int i) { return gap2orig(32 * t + i, h, X, x0); };
+}
+static InMap in_perm_gap(int h, int X, int x0) {
+    return [=](int s, int hh) { return gap2orig(32 * (s >> 4) + 8 * ((s >> 2) & 3) + 4 * hh + (s & 3), h, X, x0); };
 }
 
 // Dense (Toeplitz) matrix of a 3x3, stride 1, pad 1 conv on a 5x5 grid.
@@ -398,18 +422,37 @@ extern "C" int vsv_pack_weights(const vsv_dims* dims, const vsv_raw_weights* raw
         const int* ch = which ? d.ctx_surface_hidden : d.surface_hidden;
         const float* const* cw = which ? raw->ctx_conv_w : raw->enc_conv_w;
         const float* const* cb = which ? raw->ctx_conv_b : raw->enc_conv_b;
-        int cin = 1;
-        for (int i = 0; i < e.n_conv; ++i) {
-            if (!cw[i] || !cb[i]) { set_error("vsv_pack_weights: missing conv weight"); return -1; }
-            const int cout = ch[i];
-            std::vector<float> M = conv_matrix(cw[i], cin, cout, false);
-            const int n_in = cin * 25, n_out = cout * 25;
-            const float* bias = cb[i];
-            WFn W = [&, n_in](int r, int c) { return M[(size_t)r * n_in + c]; };
-            BFn B = [=](int r) { return bias[r / 25]; };
-            // rows >= n_out (ex-feature slots of the last layer) stay zero: out map limited to n_out
-            pack_sec(out, e.conv[i], out_nat32(n_out), i == 0 ? in_nat(n_in) : in_perm(n_in), W, B);
-            cin = cout;
+        const int h_last = ch[e.n_conv - 1];
+        // slot -> column of the reference's [surface embedding | ex-features] concatenation (:188)
+        const InMap emb_in = lay.dense ? in_perm_gap(h_last, X, e.ex_f0) : in_perm(e.E);
+        const OutMap emb_out = lay.dense ? out_gap(h_last, X, e.ex_f0) : out_nat32(e.E);
+        if (lay.dense) {
+            // Flatten + Linear(in -> surface_hidden[i]) + ReLU (:84-93, :237-246); nn.Linear weights are (out, in)
+            int n_in = 25;
+            for (int i = 0; i < e.n_conv; ++i) {
+                if (!cw[i] || !cb[i]) { set_error("vsv_pack_weights: missing dense embedding weight"); return -1; }
+                const int n_out = ch[i];
+                const float *w = cw[i], *bias = cb[i];
+                WFn W = [=](int r, int c) { return w[(size_t)r * n_in + c]; };
+                BFn B = [=](int r) { return bias[r]; };
+                // (the ex-feature slots of the last layer stay zero rows: out map limited to n_out)
+                pack_sec(out, e.conv[i], out_nat32(n_out), i == 0 ? in_nat(n_in) : in_perm(n_in), W, B);
+                n_in = n_out;
+            }
+        } else {
+            int cin = 1;
+            for (int i = 0; i < e.n_conv; ++i) {
+                if (!cw[i] || !cb[i]) { set_error("vsv_pack_weights: missing conv weight"); return -1; }
+                const int cout = ch[i];
+                std::vector<float> M = conv_matrix(cw[i], cin, cout, false);
+                const int n_in = cin * 25, n_out = cout * 25;
+                const float* bias = cb[i];
+                WFn W = [&, n_in](int r, int c) { return M[(size_t)r * n_in + c]; };
+                BFn B = [=](int r) { return bias[r / 25]; };
+                // rows >= n_out (ex-feature slots of the last layer) stay zero: out map limited to n_out
+                pack_sec(out, e.conv[i], out_nat32(n_out), i == 0 ? in_nat(n_in) : in_perm(n_in), W, B);
+                cin = cout;
+            }
         }
         for (int j = 0; j < lay.NI; ++j) {
             const float* w = (which ? raw->ctx_int_w : raw->enc_int_w)[j];
@@ -418,10 +461,10 @@ extern "C" int vsv_pack_weights(const vsv_dims* dims, const vsv_raw_weights* raw
             const int E = e.E;
             WFn W = [=](int r, int c) { return w[(size_t)r * E + c]; };
             BFn B = [=](int r) { return b[r]; };
-            pack_sec(out, e.conv[e.n_conv + j], out_nat32(E), in_perm(E), W, B);
+            pack_sec(out, e.conv[e.n_conv + j], emb_out, emb_in, W, B);
         }
         const vsv_lstm_raw& mem = which ? raw->ctx_mem : raw->enc_mem;
-        (lay.gru == 2 ? pack_rnn : lay.gru ? pack_gru : pack_lstm)(out, e.lstm, mem, lay.NL, Hm, lay.NTm, e.E, e.kx, in_perm(e.E));
+        (lay.gru == 2 ? pack_rnn : lay.gru ? pack_gru : pack_lstm)(out, e.lstm, mem, lay.NL, Hm, lay.NTm, e.E, e.kx, emb_in);
         if (which == 0) {
             const float *wm = raw->z_mean_w, *bm = raw->z_mean_b, *wv = raw->z_log_var_w, *bv = raw->z_log_var_b;
             WFn W = [=](int r, int c) { return r < L ? wm[(size_t)r * Hm + c] : wv[(size_t)(r - L) * Hm + c]; };
@@ -459,36 +502,48 @@ extern "C" int vsv_pack_weights(const vsv_dims* dims, const vsv_raw_weights* raw
     }
     WFn W_lin;
     BFn B_lin;
-    const int n_lin = c_last * 25 + X;
+    const int per = lay.dense ? 1 : 25;
+    const int n_lin = c_last * per + X;
+    // where a head layer with `c` channels / units keeps its features: conv layers pixel-major with the ex riders
+    // right behind, dense layers in natural order with the riders at kDenseEx0
+    auto head_out = [&](int n_surf, int n_ex, int c) -> OutMap {
+        return lay.dense ? out_gap(n_surf, n_ex, kDenseEx0) : out_px(n_surf + n_ex, c);
+    };
+    auto head_in = [&](int n_surf, int n_ex, int c) -> InMap {
+        return lay.dense ? in_perm_gap(n_surf, n_ex, kDenseEx0) : in_perm_px(n_surf + n_ex, c);
+    };
     {   // Linear: rows [surface_decoder_input ; ex_feats_decoder_input]
-        const int ns = c_last * 25;
+        const int ns = c_last * per;
         const float *ws = raw->dec_in_w, *bs = raw->dec_in_b, *we = raw->ex_in_w, *be = raw->ex_in_b;
         if (X > 0 && (!we || !be)) { set_error("vsv_pack_weights: missing ex_feats_decoder_input"); return -1; }
         W_lin = [=](int r, int c) { return r < ns ? ws[(size_t)r * Hd + c] : we[(size_t)(r - ns) * Hd + c]; };
         B_lin = [=](int r) { return r < ns ? bs[r] : be[r - ns]; };
-        pack_sec(out, dc.head[hi++], out_px(ns + X, c_last), lay.NI > 0 ? in_perm(Hd) : in_nat(Hd), W_lin, B_lin);
+        pack_sec(out, dc.head[hi++], head_out(ns, X, c_last), lay.NI > 0 ? in_perm(Hd) : in_nat(Hd), W_lin, B_lin);
     }
     int cin = c_last;
     for (int i = 0; i < d.n_conv; ++i) {
-        const int cout = (i < d.n_conv - 1) ? d.surface_hidden[d.n_conv - 2 - i] : cin;
+        const int cout = (i < d.n_conv - 1) ? d.surface_hidden[d.n_conv - 2 - i] : (lay.dense ? 25 : cin);
         if (!raw->dec_deconv_w[i] || !raw->dec_deconv_b[i]) { set_error("vsv_pack_weights: missing deconv weight"); return -1; }
-        std::vector<float> M = conv_matrix(raw->dec_deconv_w[i], cin, cout, true);
-        const int n_in = cin * 25, n_out = cout * 25;
+        std::vector<float> M;
+        if (!lay.dense) M = conv_matrix(raw->dec_deconv_w[i], cin, cout, true);
+        const float* wd = raw->dec_deconv_w[i];                  // dense: nn.Linear (cout, cin), :397-404
+        const int n_in = cin * per, n_out = cout * per;
         const float* bias = raw->dec_deconv_b[i];
+        const bool dense = lay.dense;
         const bool carries_ex = (i == 0 && X > 0);
         const float *w2 = raw->ex_out_w, *b2 = raw->ex_out_b;
         if (carries_ex && (!w2 || !b2)) { set_error("vsv_pack_weights: missing ex_feats_decoder"); return -1; }
         // ex path rides in features [n_out, n_out+X) of this layer: ex = W2 * ex_in + b2 (no ReLU)
-        WFn W = [&, n_in, n_out](int r, int c) {
-            if (r < n_out) return c < n_in ? M[(size_t)r * n_in + c] : 0.0f;
+        WFn W = [&, n_in, n_out, dense, wd](int r, int c) {
+            if (r < n_out) return c < n_in ? (dense ? wd[(size_t)r * n_in + c] : M[(size_t)r * n_in + c]) : 0.0f;
             return c >= n_in ? w2[(size_t)(r - n_out) * X + (c - n_in)] : 0.0f;
         };
-        BFn B = [=](int r) { return r < n_out ? bias[r / 25] : b2[r - n_out]; };
-        const int n_in_tot = n_in + ((i == 0) ? X : 0);
-        pack_sec(out, dc.head[hi++], out_px(n_out + (carries_ex ? X : 0), cout), in_perm_px(n_in_tot, cin), W, B);
+        BFn B = [=](int r) { return r < n_out ? bias[dense ? r : r / 25] : b2[r - n_out]; };
+        const int x_in = (i == 0) ? X : 0, x_out = carries_ex ? X : 0;
+        pack_sec(out, dc.head[hi++], head_out(n_out, x_out, cout), head_in(n_in, x_in, cin), W, B);
         if (i == 0) {
             // inference: this layer applied to the Linear above, as one matrix (float64 accumulation)
-            const int n_f = n_out + (carries_ex ? X : 0);
+            const int n_f = n_out + x_out;
             std::vector<float> F((size_t)n_f * Hd), bF(n_f);
             for (int r = 0; r < n_f; ++r) {
                 double bacc = B(r);
@@ -504,20 +559,23 @@ extern "C" int vsv_pack_weights(const vsv_dims* dims, const vsv_raw_weights* raw
             }
             WFn Wf = [&](int r, int c) { return F[(size_t)r * Hd + c]; };
             BFn Bf = [&](int r) { return bF[r]; };
-            pack_sec(out, dc.head_fold, out_px(n_f, cout), lay.NI > 0 ? in_perm(Hd) : in_nat(Hd), Wf, Bf);
+            pack_sec(out, dc.head_fold, head_out(n_out, x_out, cout), lay.NI > 0 ? in_perm(Hd) : in_nat(Hd), Wf, Bf);
         }
         cin = cout;
     }
     {
-        std::vector<float> M = conv_matrix(raw->dec_out_w, cin, lay.Q, false);
-        const int n_in = cin * 25;
+        std::vector<float> M;
+        if (!lay.dense) M = conv_matrix(raw->dec_out_w, cin, lay.Q, false);
+        const float* wo = raw->dec_out_w;                        // dense: nn.Linear (Q*25, 25), :407
+        const int n_in = cin * per;
         const float* bias = raw->dec_out_b;
-        WFn W = [&, n_in](int r, int c) { return M[(size_t)r * n_in + c]; };
-        BFn B = [=](int r) { return bias[r / 25]; };
-        pack_sec(out, dc.head[hi++], out_nat32(lay.Q * 25), in_perm_px(n_in, cin), W, B);
+        const bool dense = lay.dense;
+        WFn W = [&, n_in, dense, wo](int r, int c) { return dense ? wo[(size_t)r * n_in + c] : M[(size_t)r * n_in + c]; };
+        BFn B = [=](int r) { return bias[dense ? r : r / 25]; };
+        pack_sec(out, dc.head[hi++], out_nat32(lay.Q * 25), head_in(n_in, 0, cin), W, B);
         for (int c = 0; c < lay.Q; ++c) {
             OutMap one = [=](int t, int i) { return (t == 0 && i < 25) ? c * 25 + i : -1; };
-            pack_sec(out, dc.head_ch[c], one, in_perm_px(n_in, cin), W, B);
+            pack_sec(out, dc.head_ch[c], one, head_in(n_in, 0, cin), W, B);
         }
     }
     // the bands are structural: nothing outside them may be non-zero

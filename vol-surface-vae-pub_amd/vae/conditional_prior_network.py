@@ -23,17 +23,24 @@ class ConditionalPriorNetwork(nn.Module):
         L = config["latent_dim"]
         fh, fw = config["feat_dim"]
         hidden = config["ctx_surface_hidden"]
-        if config["use_dense_surface"]:
-            raise NotImplementedError("use_dense_surface=True is not built for gfx950 (no reference config uses it)")
         layers = OrderedDict()
-        cin = 1
-        for i, cout in enumerate(hidden):
-            layers[f"prior_enc_conv_{i}"] = nn.Conv2d(cin, cout, kernel_size=3, stride=1, padding=config["padding"])
-            layers[f"prior_enc_activation_{i}"] = nn.ReLU()
-            cin = cout
-        layers["flatten"] = nn.Flatten()
+        if config["use_dense_surface"]:                      # Flatten + Linear+ReLU stack (reference :90-99)
+            cin = fh * fw
+            layers["flatten"] = nn.Flatten()
+            for i, cout in enumerate(hidden):
+                layers[f"prior_enc_dense_{i}"] = nn.Linear(cin, cout)
+                layers[f"prior_enc_activation_{i}"] = nn.ReLU()
+                cin = cout
+            width = cin
+        else:
+            cin = 1
+            for i, cout in enumerate(hidden):
+                layers[f"prior_enc_conv_{i}"] = nn.Conv2d(cin, cout, kernel_size=3, stride=1, padding=config["padding"])
+                layers[f"prior_enc_activation_{i}"] = nn.ReLU()
+                cin = cout
+            layers["flatten"] = nn.Flatten()
+            width = cin * fh * fw
         self.surface_embedding = nn.Sequential(layers)
-        width = cin * fh * fw
         if config["ex_feats_dim"] > 0:
             if config["ctx_ex_feats_hidden"] is not None:
                 raise NotImplementedError("ctx_ex_feats_hidden must be None")

@@ -48,10 +48,11 @@ class CVAEMemRandConditionalPrior(CVAEMemRand):
         conv and LSTM tensors one for one, compression and heads folded into the two head Linears."""
         pn = self.prior_network
         sub = {}
+        kind = "dense" if self.config["use_dense_surface"] else "conv"
         for i in range(len(self.config["ctx_surface_hidden"])):
-            conv = getattr(pn.surface_embedding, f"prior_enc_conv_{i}")
-            sub[f"encoder.surface_embedding.enc_conv_{i}.weight"] = conv.weight
-            sub[f"encoder.surface_embedding.enc_conv_{i}.bias"] = conv.bias
+            conv = getattr(pn.surface_embedding, f"prior_enc_{kind}_{i}")
+            sub[f"encoder.surface_embedding.enc_{kind}_{i}.weight"] = conv.weight
+            sub[f"encoder.surface_embedding.enc_{kind}_{i}.bias"] = conv.bias
         for n, p in pn.interaction.named_parameters():              # prior_interact_linear_* -> enc_interact_linear_*
             sub["encoder.interaction." + n.replace("prior_interact", "enc_interact")] = p
         for n, p in pn.mem.named_parameters():
@@ -218,9 +219,10 @@ class CVAEMemRandConditionalPrior(CVAEMemRand):
         pn = self.prior_network
         pairs = []
         for i in range(len(self.config["ctx_surface_hidden"])):
-            conv = getattr(pn.surface_embedding, f"prior_enc_conv_{i}")
-            pairs += [(conv.weight, g[f"encoder.surface_embedding.enc_conv_{i}.weight"]),
-                      (conv.bias, g[f"encoder.surface_embedding.enc_conv_{i}.bias"])]
+            kind = "dense" if self.config["use_dense_surface"] else "conv"
+            conv = getattr(pn.surface_embedding, f"prior_enc_{kind}_{i}")
+            pairs += [(conv.weight, g[f"encoder.surface_embedding.enc_{kind}_{i}.weight"]),
+                      (conv.bias, g[f"encoder.surface_embedding.enc_{kind}_{i}.bias"])]
         for n, p in pn.interaction.named_parameters():
             pairs.append((p, g["encoder.interaction." + n.replace("prior_interact", "enc_interact")]))
         for n, p in pn.mem.named_parameters():

@@ -9,10 +9,10 @@ give the model the reference's parameter names, shapes, default initialisation a
 checkpoint compatibility, but their own forward() is never called.  There is no
 CPU fallback: calling a compute method without a GPU raises.
 
-Implemented topology (what the configs in the reference repo use): conv surface
-embedding, mem_type "lstm" / "gru" / anything else (nn.RNN), compress_context True or False, interaction_layers
-None / 1 / 2, ex_feats_hidden=None.  Other switches parse and then raise NotImplementedError
-at the first compute call.
+Implemented topology: conv or dense (use_dense_surface) surface embedding, mem_type "lstm" / "gru" / anything
+else (nn.RNN), compress_context True or False, interaction_layers None / 1 / 2, ex_feats_hidden=None (any other
+value raises the TypeError the reference's check_input raises, :991-994).  Shapes the kernels are not built for
+(hidden widths above 128, more than 4 embedding layers) raise NotImplementedError when the engine is built.
 """
 from __future__ import annotations
 

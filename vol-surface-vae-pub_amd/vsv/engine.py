@@ -18,8 +18,6 @@ from . import lib as _lib
 def dims_from_config(cfg: dict) -> _lib.VsvDims:
     """vsv_dims from a reference model config dict
     (keys as validated by cvae_with_mem_randomized.py:969-1020)."""
-    if cfg.get("use_dense_surface", False):
-        raise NotImplementedError("HIP path implements the conv surface embedding only")
     if cfg.get("ex_feats_hidden") is not None or cfg.get("ctx_ex_feats_hidden") is not None:
         raise NotImplementedError("HIP path implements ex_feats_hidden=None only")
     if tuple(cfg["feat_dim"]) != (5, 5):
@@ -27,7 +25,8 @@ def dims_from_config(cfg: dict) -> _lib.VsvDims:
     dims = _lib.make_dims(cfg["latent_dim"], cfg["ex_feats_dim"], cfg["mem_hidden"], cfg["mem_layers"],
                           list(cfg["surface_hidden"]), list(cfg["ctx_surface_hidden"]),
                           len(cfg.get("quantiles", [0.05, 0.5, 0.95])), cfg.get("interaction_layers") or 0,
-                          cfg.get("mem_type", "lstm"), bool(cfg.get("compress_context", False)))
+                          cfg.get("mem_type", "lstm"), bool(cfg.get("compress_context", False)),
+                          bool(cfg.get("use_dense_surface", False)))
     # shapes the kernels cannot run are refused here, when the model / Engine is built, not at the first launch
     L = _lib.load()
     if L.vsv_packed_floats(C.byref(dims)) == 0:
@@ -58,21 +57,23 @@ def pack_state_dict(dims: _lib.VsvDims, sd: Dict[str, np.ndarray]) -> np.ndarray
             dst.b_ih[l] = get(f"{prefix}.bias_ih_l{l}")
             dst.b_hh[l] = get(f"{prefix}.bias_hh_l{l}")
 
+    # use_dense_surface: the Linear stacks enc_dense_i / ctx_enc_dense_i / dec_dense_i ride in the conv slots
+    kind, dkind = ("dense", "dense") if dims.use_dense_surface else ("conv", "deconv")
     for i in range(dims.n_conv):
-        raw.enc_conv_w[i] = get(f"encoder.surface_embedding.enc_conv_{i}.weight")
-        raw.enc_conv_b[i] = get(f"encoder.surface_embedding.enc_conv_{i}.bias")
+        raw.enc_conv_w[i] = get(f"encoder.surface_embedding.enc_{kind}_{i}.weight")
+        raw.enc_conv_b[i] = get(f"encoder.surface_embedding.enc_{kind}_{i}.bias")
     lstm(raw.enc_mem, "encoder.mem")
     raw.z_mean_w, raw.z_mean_b = get("encoder.z_mean_layer.weight"), get("encoder.z_mean_layer.bias")
     raw.z_log_var_w, raw.z_log_var_b = get("encoder.z_log_var_layer.weight"), get("encoder.z_log_var_layer.bias")
     for i in range(dims.n_ctx_conv):
-        raw.ctx_conv_w[i] = get(f"ctx_encoder.ctx_surface_embedding.ctx_enc_conv_{i}.weight")
-        raw.ctx_conv_b[i] = get(f"ctx_encoder.ctx_surface_embedding.ctx_enc_conv_{i}.bias")
+        raw.ctx_conv_w[i] = get(f"ctx_encoder.ctx_surface_embedding.ctx_enc_{kind}_{i}.weight")
+        raw.ctx_conv_b[i] = get(f"ctx_encoder.ctx_surface_embedding.ctx_enc_{kind}_{i}.bias")
     lstm(raw.ctx_mem, "ctx_encoder.mem")
     if dims.compress_context:
         raw.ctx_comp_w, raw.ctx_comp_b = get("ctx_encoder.final_compression.weight"), get("ctx_encoder.final_compression.bias")
     lstm(raw.dec_mem, "decoder.mem")
     raw.dec_in_w, raw.dec_in_b = get("decoder.surface_decoder_input.weight"), get("decoder.surface_decoder_input.bias")
-    names = [f"dec_deconv_{i}" for i in range(dims.n_conv - 1)] + ["dec_final"]
+    names = [f"dec_{dkind}_{i}" for i in range(dims.n_conv - 1)] + ["dec_final"]
     for i, nm in enumerate(names):
         raw.dec_deconv_w[i] = get(f"decoder.surface_decoder.{nm}.weight")
         raw.dec_deconv_b[i] = get(f"decoder.surface_decoder.{nm}.bias")

@@ -23,7 +23,7 @@ class VsvDims(C.Structure):
         ("mem_layers", C.c_int), ("n_conv", C.c_int), ("surface_hidden", C.c_int * VSV_MAX_CONV),
         ("n_ctx_conv", C.c_int), ("ctx_surface_hidden", C.c_int * VSV_MAX_CONV),
         ("n_quantiles", C.c_int), ("interaction_layers", C.c_int), ("mem_type", C.c_int),
-        ("compress_context", C.c_int),
+        ("compress_context", C.c_int), ("use_dense_surface", C.c_int),
     ]
 
 
@@ -234,7 +234,7 @@ def load() -> C.CDLL:
             fn = getattr(lib, name)
             fn.restype = res
             fn.argtypes = args
-        if lib.vsv_abi_version() != 18:
+        if lib.vsv_abi_version() != 19:
             raise RuntimeError("libvsv_hip.so ABI version mismatch")
         _lib = lib
     return _lib
@@ -253,9 +253,11 @@ def check(rc: int, what: str) -> None:
 
 
 def make_dims(latent_dim, ex_feats_dim, mem_hidden, mem_layers, surface_hidden, ctx_surface_hidden,
-              n_quantiles, interaction_layers=0, mem_type="lstm", compress_context=True) -> VsvDims:
+              n_quantiles, interaction_layers=0, mem_type="lstm", compress_context=True,
+              use_dense_surface=False) -> VsvDims:
     d = VsvDims()
     d.compress_context = int(bool(compress_context))
+    d.use_dense_surface = int(bool(use_dense_surface))
     # the reference builds nn.LSTM for "lstm", nn.GRU for "gru" and nn.RNN for ANY other value (:154-159)
     d.mem_type = {"lstm": 0, "gru": 1}.get(mem_type, 2)
     d.interaction_layers = int(interaction_layers or 0)

@@ -58,12 +58,22 @@ def state_dict_spec(cfg: dict) -> List[Tuple[str, Tuple[int, ...]]]:
     sh = list(cfg["surface_hidden"])
     csh = list(cfg["ctx_surface_hidden"])
     Q = len(cfg["quantiles"])
-    E = sh[-1] * 25 + X
-    Ec = csh[-1] * 25 + X
-    Hd = sh[-1] * 25 + X
+    dense = bool(cfg.get("use_dense_surface", False))
+    per = 1 if dense else 25                     # features per channel (conv) / unit (dense, :84-93, :375-378)
+    E = sh[-1] * per + X
+    Ec = csh[-1] * per + X
+    Hd = sh[-1] * per + X
     spec: List[Tuple[str, Tuple[int, ...]]] = []
 
     def conv_stack(prefix, names, chans, cin):
+        if dense:
+            # Flatten + Linear stacks named *_dense_i (:84-93, :237-246)
+            cin = 25
+            for nm, co in zip(names, chans):
+                spec.append((f"{prefix}.{nm.replace('_conv_', '_dense_')}.weight", (co, cin)))
+                spec.append((f"{prefix}.{nm.replace('_conv_', '_dense_')}.bias", (co,)))
+                cin = co
+            return
         for nm, co in zip(names, chans):
             spec.append((f"{prefix}.{nm}.weight", (co, cin, 3, 3)))
             spec.append((f"{prefix}.{nm}.bias", (co,)))
@@ -105,18 +115,29 @@ def state_dict_spec(cfg: dict) -> List[Tuple[str, Tuple[int, ...]]]:
                  ("ctx_encoder.final_compression.bias", (L,))]
     lstm("decoder.mem", Lc + L, Hd)
     interaction("decoder", "dec", Hd)
-    spec += [("decoder.surface_decoder_input.weight", (sh[-1] * 25, Hd)),
-             ("decoder.surface_decoder_input.bias", (sh[-1] * 25,))]
-    # ConvTranspose2d weights are (in, out, kH, kW)
+    spec += [("decoder.surface_decoder_input.weight", (sh[-1] * per, Hd)),
+             ("decoder.surface_decoder_input.bias", (sh[-1] * per,))]
     cin = sh[-1]
-    for i, co in enumerate(reversed(sh[:-1])):
-        spec.append((f"decoder.surface_decoder.dec_deconv_{i}.weight", (cin, co, 3, 3)))
-        spec.append((f"decoder.surface_decoder.dec_deconv_{i}.bias", (co,)))
-        cin = co
-    spec.append(("decoder.surface_decoder.dec_final.weight", (cin, cin, 3, 3)))
-    spec.append(("decoder.surface_decoder.dec_final.bias", (cin,)))
-    spec.append(("decoder.surface_decoder.dec_output.weight", (Q, cin, 3, 3)))
-    spec.append(("decoder.surface_decoder.dec_output.bias", (Q,)))
+    if dense:
+        # Linear stack back to the 25 grid points, then Linear(25 -> 25 Q) (:394-407)
+        for i, co in enumerate(reversed(sh[:-1])):
+            spec.append((f"decoder.surface_decoder.dec_dense_{i}.weight", (co, cin)))
+            spec.append((f"decoder.surface_decoder.dec_dense_{i}.bias", (co,)))
+            cin = co
+        spec.append(("decoder.surface_decoder.dec_final.weight", (25, cin)))
+        spec.append(("decoder.surface_decoder.dec_final.bias", (25,)))
+        spec.append(("decoder.surface_decoder.dec_output.weight", (25 * Q, 25)))
+        spec.append(("decoder.surface_decoder.dec_output.bias", (25 * Q,)))
+    else:
+        # ConvTranspose2d weights are (in, out, kH, kW)
+        for i, co in enumerate(reversed(sh[:-1])):
+            spec.append((f"decoder.surface_decoder.dec_deconv_{i}.weight", (cin, co, 3, 3)))
+            spec.append((f"decoder.surface_decoder.dec_deconv_{i}.bias", (co,)))
+            cin = co
+        spec.append(("decoder.surface_decoder.dec_final.weight", (cin, cin, 3, 3)))
+        spec.append(("decoder.surface_decoder.dec_final.bias", (cin,)))
+        spec.append(("decoder.surface_decoder.dec_output.weight", (Q, cin, 3, 3)))
+        spec.append(("decoder.surface_decoder.dec_output.bias", (Q,)))
     if X > 0:
         spec += [("decoder.ex_feats_decoder_input.weight", (X, Hd)),
                  ("decoder.ex_feats_decoder_input.bias", (X,)),

@@ -2777,7 +2777,14 @@ constexpr int kPreMaxQ = 16;     // input quads (8 features each) of a layer: <=
 template <int NT>
 __global__ void __launch_bounds__(64 * NT) lstm_pre_kernel(const float* w, const float* b, int nq_in, const float* x,
                                                            long x_stride, float* gates, long g_stride, long n_inst, int ipw) {
+    // an instance's x (4 nq_in k-steps x 64 lanes, contiguous) is shared by the NT waves: the workgroup copies it
+    // into LDS once -- the NEXT instance's while this one's products run (double buffer, one barrier per instance) --
+    // and every wave reads its B operands from there.  (Read straight from global memory, quad by quad in front of
+    // the four products that use it, every quad exposed a full L2 round trip: 2.5 - 5 x the matrix time.)
+    __shared__ __attribute__((aligned(16))) float xs[2][4 * kPreMaxQ * 64];
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int tid = threadIdx.x;
+    const int n4 = nq_in * 64;                                    // float4s of one instance's x
     // this wave's gate tile of W_ih stays in registers for the workgroup's ipw consecutive instances: streamed per
     // instance the launch is bound by L2 (NT x 13-16 KB of fragments for 0.4 us of products per wave)
     float4 wr[kPreMaxQ];
@@ -2790,9 +2797,33 @@ __global__ void __launch_bounds__(64 * NT) lstm_pre_kernel(const float* w, const
     f32x16 bias[1];
     load_bias<1>(bias, b, toff1, lane >> 5);
     const long i0 = (long)blockIdx.x * ipw;
-    for (int k = 0; k < ipw && i0 + k < n_inst; ++k) {
+    const int n_here = (int)((n_inst - i0) < (long)ipw ? (n_inst - i0) : (long)ipw);
+    // (kPreMaxQ * 64 float4s over 64 NT >= 832 threads: at most two per thread)
+    float4 pf[2];
+    auto fetch = [&](int k) {
+        const float4* src = (const float4*)(x + (size_t)(i0 + k) * (size_t)x_stride);
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int e = tid + u * 64 * NT;
+            if (e < n4) pf[u] = src[e];
+        }
+    };
+    auto stash = [&](int buf) {
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int e = tid + u * 64 * NT;
+            if (e < n4) ((float4*)xs[buf])[e] = pf[u];
+        }
+    };
+    if (n_here > 0) {
+        fetch(0);
+        stash(0);
+    }
+    __syncthreads();
+    for (int k = 0; k < n_here; ++k) {
         const size_t inst = (size_t)(i0 + k);
-        const float* xb = x + inst * (size_t)x_stride + lane;
+        if (k + 1 < n_here) fetch(k + 1);                          // lands while the products run
+        const float* xb = xs[k & 1] + lane;
         f32x16 acc = bias[0];
 #pragma unroll
         for (int q = 0; q < kPreMaxQ; ++q) {
@@ -2807,6 +2838,8 @@ __global__ void __launch_bounds__(64 * NT) lstm_pre_kernel(const float* w, const
         float* o = gates + inst * (size_t)g_stride + (size_t)(16 * wave) * 64 + lane;
 #pragma unroll
         for (int r = 0; r < 16; ++r) o[r * 64] = acc[r];
+        if (k + 1 < n_here) stash((k + 1) & 1);                    // (that buffer's readers passed the last barrier)
+        __syncthreads();
     }
 }
 

@@ -56,7 +56,7 @@ def prior_generate(eng: Engine, surf_ctx: torch.Tensor, ex_ctx: Optional[torch.T
     return r["surf"], r["ex"], zm
 
 
-SPLIT_MAX_DAYS = 3500      # beyond: the fused three-segment schedule (see _context_prefix)
+SPLIT_MAX_DAYS = 6000      # beyond: the fused three-segment schedule (see _context_prefix)
 
 
 def _context_prefix(eng: Engine, sv: torch.Tensor, se: Optional[torch.Tensor], n_days: int, ctx_len: int,
@@ -70,11 +70,11 @@ def _context_prefix(eng: Engine, sv: torch.Tensor, se: Optional[torch.Tensor], n
         per layer -- layer 1's input product b + W_ih . h0 leaves the time loop for one GEMM over all steps -- and the
         recurrent launches on 16-day tiles (lstm_rec16_kernel: twice the CUs, half the matrix time per step, W_hh in
         registers), issued by the native vsv_context_prefix on two streams (posterior encoder + decoder on the
-        caller's, context encoder beside them).  Context 60: 1.32 / 1.52 / 1.88 / 2.56 ms at 500 / 1000 / 2000 / 3000
-        days;
+        caller's, context encoder beside them).  Context 60: 1.33 / 1.73 / 2.28 / 2.70 / 4.30 ms at 500 / 2000 / 3000 /
+        4000 / 6000 days;
       * fused stacks (one two-layer launch per stack and time segment) on three streams in three segments, the
-        encoders' segment i+1 beside the decoder's segment i: 2.5 - 2.6 ms up to 2000 days, 2.96 ms at 4000, where
-        all 256 CUs are busy either way and the stages' extra launches cost more than the smaller tiles gain.
+        encoders' segment i+1 beside the decoder's segment i: 2.5 - 2.6 ms up to 2000 days, 2.96 ms at 4000, 4.38 at
+        6000, 5.05 at 8000 (5.27 in layer stages: every launch then takes several rounds of workgroups either way).
     VSV_PREFIX_LAYERS = 0 / 1 / py forces the fused / layer-stage / layer-stage-driven-from-Python schedule,
     VSV_PREFIX_SEGMENTS the segment count, VSV_PREFIX_STREAMS = 2 / 3 / 4 / 6 the worker streams of the layer stages
     (with HIP's default of four hardware queues more than two busy streams may share a queue and serialise: 1.2 or

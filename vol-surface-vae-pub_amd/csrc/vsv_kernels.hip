@@ -2301,6 +2301,136 @@ __global__ void __launch_bounds__(256, 1) lstm_bwd_kernel(const LstmBwdArgs a) {
 }
 
 // ---------------------------------------------------------------------------
+// lstm_bwd16_kernel: the BPTT recurrence of ONE nn.LSTM layer on 16-ROW tiles (v_mfma_f32_16x16x4_f32), for
+// training batches of few row tiles (batch 64 = two 32-row tiles = two CUs in lstm_bwd_kernel, each bound by its
+// matrix pipe for every one of the T sequential steps): twice the CUs, half the matrix time per step.
+//   * D tile = (16 hidden units) x (16 rows): lane (n = l & 15, g4 = l >> 4) holds dh of units 16 To + 4 g4 + v
+//     (v = its four D registers) of row n, runs their cell backward and so owns their 16 gate gradients;
+//   * k-step (T, v, g) multiplies gate g of units 16 T + 4 k' + v (k' = 0..3): its B operand wants, in lane
+//     (n, k'), the gate gradient that very lane produced as owner of output tile T -- the gate gradients go
+//     through LDS as [k-step][lane], written and read without transposition or bank conflicts;
+//   * wave w owns output tile w; its W_hh^T fragments (one register per k-step, 112 - 128) are gathered once from
+//     the transposed blob's 32x32x2 'unit' section and stay in registers; dgates double-buffered in LDS, one
+//     barrier per step; saved gates / cell states of the step are requested before the products.
+// Reads and writes lstm_bwd_kernel's formats (sv_gates, sv_c, dh_top in unit-tile order, dgates).  Products are
+// summed four k at a time in another order: results agree with lstm_bwd_kernel's to rounding.
+// ---------------------------------------------------------------------------
+template <int NT>
+__global__ void __launch_bounds__(512) lstm_bwd16_kernel(const LstmBwdArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    constexpr int HP = 8 * NT;
+    constexpr int NTT = (HP + 15) / 16;                            // 16-unit tiles (waves with work)
+    constexpr int KS = 16 * NTT;                                   // k-steps: (unit tile T, v, gate g)
+    constexpr int GK = 16 * NT;
+    static_assert(NTT <= 8, "one output tile per wave");
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const long tile16 = (long)blockIdx.x;
+    const int n = lane & 15, g4 = lane >> 4;
+    const long row_raw = tile16 * 16 + n;
+    const bool row_ok = row_raw < a.n_rows;
+    const long rowtile = tile16 >> 1;
+    const int m = 16 * (int)(tile16 & 1) + n;
+    const int SL = a.sv_nl > 0 ? a.sv_nl : 1, L0 = a.sv_nl > 0 ? a.sv_l0 : 0;
+    const bool active = wave < NTT;                                // (wave-uniform)
+    const int To = active ? wave : NTT - 1;
+    const int t_outs = a.T - a.t_out0;
+
+    // this lane's four units and where their values live in the 32-row layouts
+    bool uok[4];
+    int gsl[4], l32[4], hsl[4], dsl[4];
+#pragma unroll
+    for (int v = 0; v < 4; ++v) {
+        const int u0 = 16 * To + 4 * g4 + v;
+        uok[v] = active && u0 < HP;
+        const int u = u0 < HP ? u0 : HP - 1;                       // (clamped: addresses stay inside the instance)
+        gsl[v] = 16 * (u >> 3) + 4 * ((u & 7) >> 1);               // + gate: slot of a gate value
+        l32[v] = (u & 1) * 32 + m;
+        hsl[v] = 4 * (u >> 3) + ((u & 7) >> 1);                    // slot of c / h
+        dsl[v] = 16 * ((u >> 3) & 3) + 4 * (u >> 5) + ((u & 7) >> 1);   // slot of dh_top (unit-tile order)
+    }
+    // W_hh^T fragments: A[i][k'] of k-step (T, v, g) = W_hh[gate g of unit 16 T + 4 k' + v][unit 16 To + i],
+    // lane = i + 16 k'; in the transposed blob (train.py transposed_map, kind 'unit', 4 output tiles) that element
+    // sits at quad s >> 2, tile (uk >> 3) & 3, lane (ua & 1) * 32 + i32, component s & 3 with s the gate's slot
+    float wreg[KS];
+    {
+        const int uk = 16 * To + n;
+        const int t8 = uk >> 3;
+        const int i32 = 8 * (t8 >> 2) + 4 * (uk & 1) + ((uk & 7) >> 1);
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            const int T = ks >> 4, v = (ks >> 2) & 3, g = ks & 3;
+            const int ua = 16 * T + 4 * g4 + v;
+            const bool ok = active && ua < HP && uk < HP;
+            const int uac = ua < HP ? ua : HP - 1;
+            const int sslot = 16 * (uac >> 3) + 4 * ((uac & 7) >> 1) + g;
+            const size_t pos = ((size_t)((sslot >> 2) * 4 + (t8 & 3)) * 64 + (uac & 1) * 32 + (i32 & 31)) * 4 + (sslot & 3);
+            const float w = a.wT_hh[0][uk < HP ? pos : 0];
+            wreg[ks] = ok ? w : 0.0f;
+        }
+    }
+    float dc[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+    float* const lbase = smem + lane;
+
+    for (int t = a.T - 1; t >= 0; --t) {
+        const size_t inst = (size_t)(rowtile * a.T + t);
+        // saved gates and cell states of the step: requested before the products, which do not depend on them
+        float gsv[4][4], cnv[4], cpv[4];
+        f32x4 acc = {0.0f, 0.0f, 0.0f, 0.0f};
+        {
+            const float* sg = a.sv_gates + (inst * SL + L0) * GK * 64;
+            const float* sc = a.sv_c + (inst * SL + L0) * (4 * NT) * 64;
+            const float* scp = (t > 0) ? a.sv_c + ((inst - 1) * SL + L0) * (4 * NT) * 64 : nullptr;
+#pragma unroll
+            for (int v = 0; v < 4; ++v) {
+#pragma unroll
+                for (int g = 0; g < 4; ++g) gsv[v][g] = sg[(size_t)(gsl[v] + g) * 64 + l32[v]];
+                cnv[v] = sc[(size_t)hsl[v] * 64 + l32[v]];
+                cpv[v] = scp ? scp[(size_t)hsl[v] * 64 + l32[v]] : 0.0f;
+            }
+            if (t >= a.t_out0 && a.dh_top) {
+                const float* p = a.dh_top + (size_t)(rowtile * t_outs + (t - a.t_out0)) * 64 * 64;
+#pragma unroll
+                for (int v = 0; v < 4; ++v) acc[v] = p[(size_t)dsl[v] * 64 + l32[v]];
+            }
+        }
+        if (t + 1 < a.T && active) {
+            const float* b = lbase + ((t + 1) & 1) * (KS * 64);
+            f32x4 acc2 = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+            for (int ks = 0; ks < KS; ks += 2) {
+                acc = mfma16(wreg[ks], b[ks * 64], acc);
+                acc2 = mfma16(wreg[ks + 1], b[(ks + 1) * 64], acc2);
+            }
+#pragma unroll
+            for (int v = 0; v < 4; ++v) acc[v] += acc2[v];
+        }
+        if (active) {
+            float* const lw = lbase + (t & 1) * (KS * 64) + (size_t)(To * 16) * 64;
+            float* const dgo = a.dgates + (inst * SL + L0) * GK * 64;
+#pragma unroll
+            for (int v = 0; v < 4; ++v) {
+                const float ig = gsv[v][0], fg = gsv[v][1], gg = gsv[v][2], og = gsv[v][3];
+                const float th = fast_tanh(cnv[v]);
+                const float dh = acc[v];
+                const float dct = dc[v] + dh * og * (1.0f - th * th);
+                const bool ok = uok[v] && row_ok;
+                const float dog = ok ? dh * th * og * (1.0f - og) : 0.0f;
+                const float di = ok ? dct * gg * ig * (1.0f - ig) : 0.0f;
+                const float df = ok ? dct * cpv[v] * fg * (1.0f - fg) : 0.0f;
+                const float dgg = ok ? dct * ig * (1.0f - gg * gg) : 0.0f;
+                dc[v] = dct * fg;
+                lw[(4 * v + 0) * 64] = di; lw[(4 * v + 1) * 64] = df; lw[(4 * v + 2) * 64] = dgg; lw[(4 * v + 3) * 64] = dog;
+                if (uok[v]) {
+                    float* o = dgo + (size_t)gsl[v] * 64 + l32[v];
+                    o[0] = di; o[64] = df; o[128] = dgg; o[192] = dog;
+                }
+            }
+        }
+        __syncthreads();                                           // dgates(t) published (the other buffer is free again)
+    }
+}
+
+// ---------------------------------------------------------------------------
 // tileb_gemm_kernel: Y(inst) = W^T-fragments . G(inst) for every (row tile, t) instance at once -- the
 // parts of BPTT that do not sit on the recurrence (d h_{l-1}(t) = W_in(l)^T . dgates(l, t) and
 // dx(t) = W_in(0)^T . dgates(0, t)), taken out of lstm_bwd_kernel's time loop so that they run on as
@@ -4193,6 +4323,22 @@ static int launch_lstm_bwd(const vsv_lstm_bwd& a, hipStream_t st) {
     return launch_check("lstm_bwd_kernel");
 }
 
+template <int NT>
+static int launch_lstm_bwd16(const vsv_lstm_bwd& a, hipStream_t st) {
+    constexpr int KS = 16 * ((8 * NT + 15) / 16);
+    const size_t lds = (size_t)2 * KS * 64 * sizeof(float);
+    int rc = set_lds(lstm_bwd16_kernel<NT>, lds);
+    if (rc) return rc;
+    hipLaunchKernelGGL((lstm_bwd16_kernel<NT>), dim3((unsigned)(2 * a.n_rowtiles)), dim3(512), lds, st, a);
+    return launch_check("lstm_bwd16_kernel");
+}
+
+// one nn.LSTM layer per launch, few row tiles: the 16-row schedule (VSV_BWD16=0: lstm_bwd_kernel's 32-row tiles)
+static bool lstm_bwd16_applies(const vsv_lstm_bwd& a, int layers) {
+    static const bool off = [] { const char* e = getenv("VSV_BWD16"); return e && e[0] == '0'; }();
+    return !off && layers == 1 && a.gru == 0 && a.nt_x == 0 && 2 * a.n_rowtiles <= 256;
+}
+
 extern "C" int vsv_lstm_backward(const vsv_lstm_bwd* d, int hidden, int layers, void* stream) {
     if (!d || !d->sv_gates || !d->sv_c || !d->dgates || !d->wT_hh[0]) { set_error("vsv_lstm_backward: null pointer"); return -1; }
     if (d->n_rows < 1 || d->T < 1 || d->t_out0 < 0 || d->t_out0 > d->T || d->n_rowtiles != (d->n_rows + 31) / 32 ||
@@ -4203,6 +4349,10 @@ extern "C" int vsv_lstm_backward(const vsv_lstm_bwd* d, int hidden, int layers, 
     if (d->sv_nl < 0 || (d->sv_nl > 0 && (d->sv_l0 < 0 || d->sv_l0 + layers > d->sv_nl))) { set_error("vsv_lstm_backward: bad sv_nl / sv_l0"); return -1; }
     const int NT = (hidden + 7) / 8;
     hipStream_t st = (hipStream_t)stream;
+    if (lstm_bwd16_applies(*d, layers)) {
+        if (NT == 13) return launch_lstm_bwd16<13>(*d, st);
+        if (NT == 16) return launch_lstm_bwd16<16>(*d, st);
+    }
     if (NT == 13) return layers == 2 ? launch_lstm_bwd<13, 2>(*d, st) : launch_lstm_bwd<13, 1>(*d, st);
     if (NT == 16) return layers == 2 ? launch_lstm_bwd<16, 2>(*d, st) : launch_lstm_bwd<16, 1>(*d, st);
     set_error("vsv_lstm_backward: unsupported hidden size %d", hidden);

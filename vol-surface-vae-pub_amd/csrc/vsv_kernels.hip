@@ -2438,20 +2438,65 @@ __global__ void __launch_bounds__(512) lstm_bwd16_kernel(const LstmBwdArgs a) {
 // ---------------------------------------------------------------------------
 typedef vsv_tileb_gemm TilebGemmArgs;
 
+// SPLIT (few instances: a training batch of 64 at T = 11 is 22): one workgroup per (instance, output tile), its four
+// waves take a quarter of K each and wave 0 adds the partial tiles in a fixed order -- the dependent chain of 16 NT
+// products per tile, 7 us of one CU's matrix pipe, becomes four chains of 4 NT on four SIMDs.
+template <bool SPLIT>
 __global__ void __launch_bounds__(256) tileb_gemm_kernel(const TilebGemmArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    if (wave >= a.ntT) return;
-    const size_t inst = blockIdx.x;
+    const size_t inst = SPLIT ? blockIdx.x / (unsigned)a.ntT : blockIdx.x;
+    const int tile = SPLIT ? (int)(blockIdx.x - inst * (unsigned)a.ntT) : wave;
+    // the instance's G (4 nqT k-steps x 64 lanes, contiguous) goes through LDS: every float4 of it is requested at
+    // once by the whole workgroup, one L2 round trip instead of one per K quad in front of the quad's products
+    {
+        const float4* src = (const float4*)(a.g + inst * (size_t)a.g_stride);
+        const int n4 = a.nqT * 64;
+        for (int e0 = 0; e0 < n4; e0 += 16 * 256) {
+            float4 tmp[16];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) {
+                const int e = e0 + u * 256 + (int)threadIdx.x;
+                if (e < n4) tmp[u] = src[e];
+            }
+#pragma unroll
+            for (int u = 0; u < 16; ++u) {
+                const int e = e0 + u * 256 + (int)threadIdx.x;
+                if (e < n4) ((float4*)smem)[e] = tmp[u];
+            }
+        }
+    }
+    __syncthreads();
+    if (!SPLIT && wave >= a.ntT) return;
     const long rowtile = (long)(inst / (size_t)a.T);
     const int t = (int)(inst - (size_t)rowtile * a.T);
     const int hh = lane >> 5, m = lane & 31;
     const long row_raw = rowtile * 32 + m;
     const bool row_ok = row_raw < a.n_rows;
-    const int toff1[1] = {wave * 64};
+    const int toff1[1] = {tile * 64};
     f32x16 acc[1];
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[0][r] = 0.0f;
-    gemm_seg<1>(acc, (const float4*)a.wT, lane, toff1, a.ntT * 64, a.g + inst * (size_t)a.g_stride + lane, a.nqT);
+    if (SPLIT) {
+        const int q0 = (wave * a.nqT) >> 2, q1 = ((wave + 1) * a.nqT) >> 2;
+        if (q1 > q0)
+            gemm_seg<1>(acc, (const float4*)a.wT + (size_t)q0 * a.ntT * 64, lane, toff1, a.ntT * 64,
+                        smem + (size_t)q0 * 4 * 64 + lane, q1 - q0);
+        __syncthreads();                                           // every wave has read its part of G
+        if (wave > 0) {
+            float* o = smem + (size_t)(wave - 1) * 16 * 64 + lane;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) o[r * 64] = acc[0][r];
+        }
+        __syncthreads();
+        if (wave > 0) return;
+#pragma unroll
+        for (int k = 0; k < 3; ++k)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[0][r] += smem[(size_t)(k * 16 + r) * 64 + lane];
+    } else {
+        gemm_seg<1>(acc, (const float4*)a.wT, lane, toff1, a.ntT * 64, smem + lane, a.nqT);
+    }
     if (a.drop_p > 0.0f) {
         // the consumer read the dropped copy of these units: same Philox factors as the forward
         const DropArgs da = resolve_drop(DropArgs{a.drop_p, 1.0f / (1.0f - a.drop_p), (uint32_t)a.drop_seed,
@@ -2461,13 +2506,13 @@ __global__ void __launch_bounds__(256) tileb_gemm_kernel(const TilebGemmArgs a) 
 #pragma unroll
         for (int jq = 0; jq < 4; ++jq) {
             float fct[4];
-            dropout_factors(da, rowc, (uint32_t)t, 4 * jq + wave, hh, a.drop_layer, fct);
+            dropout_factors(da, rowc, (uint32_t)t, 4 * jq + tile, hh, a.drop_layer, fct);
 #pragma unroll
             for (int r = 0; r < 4; ++r) acc[0][4 * jq + r] *= fct[r];
         }
     }
     if (a.out_tile) {
-        float* o = a.out_tile + (inst * 64 + 16 * wave) * 64 + lane;
+        float* o = a.out_tile + (inst * 64 + 16 * tile) * 64 + lane;
 #pragma unroll
         for (int r = 0; r < 16; ++r) o[r * 64] = acc[0][r];
     }
@@ -2475,7 +2520,7 @@ __global__ void __launch_bounds__(256) tileb_gemm_kernel(const TilebGemmArgs a) 
         float* o = a.out_rows + ((size_t)row_raw * a.T + t) * a.out_f;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            const int f = feat_of(wave, r, hh);
+            const int f = feat_of(tile, r, hh);
             if (f < a.out_f) o[f] = acc[0][r];
         }
     }
@@ -4368,7 +4413,17 @@ extern "C" int vsv_tileb_gemm_launch(const vsv_tileb_gemm* d, void* stream) {
     if (d->drop_p < 0.0f || d->drop_p >= 1.0f) { set_error("vsv_tileb_gemm_launch: dropout probability must be in [0,1)"); return -1; }
     const long insts = d->n_rowtiles * d->T;
     if (insts > 0x7fffffffL) { set_error("vsv_tileb_gemm_launch: too many instances"); return -2; }
-    hipLaunchKernelGGL(tileb_gemm_kernel, dim3((unsigned)insts), dim3(256), 0, (hipStream_t)stream, *d);
+    if (d->nqT > 64) { set_error("vsv_tileb_gemm_launch: more than 64 K quads"); return -4; }
+    size_t lds = (size_t)d->nqT * 4 * 64 * sizeof(float);
+    if (insts * d->ntT <= 1024) {
+        // few instances: one workgroup per (instance, output tile), K split over its four waves
+        if (lds < (size_t)3 * 16 * 64 * sizeof(float)) lds = (size_t)3 * 16 * 64 * sizeof(float);
+        if (int rc = set_lds(tileb_gemm_kernel<true>, lds)) return rc;
+        hipLaunchKernelGGL(tileb_gemm_kernel<true>, dim3((unsigned)(insts * d->ntT)), dim3(256), lds, (hipStream_t)stream, *d);
+    } else {
+        if (int rc = set_lds(tileb_gemm_kernel<false>, lds)) return rc;
+        hipLaunchKernelGGL(tileb_gemm_kernel<false>, dim3((unsigned)insts), dim3(256), lds, (hipStream_t)stream, *d);
+    }
     return launch_check("tileb_gemm_kernel");
 }
 

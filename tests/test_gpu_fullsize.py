@@ -61,6 +61,8 @@ def test_c3_full_size_prior_mc_backfill():
     record_margin(e)
     assert e <= TOL, e
     # all three decoder channels at once reduce to the same p50-channel numbers
+    # (a 64-day call runs its date-range prefix on 4-row tiles, the 4000-day call on 16-row tiles: the same products
+    # accumulated in the same k order, so even across tile shapes the numbers are bit-equal)
     qall = paths.prior_mc_windows(eng, vol, ex, C, 64, C, H, S, seed=seed, channel=None)
     assert torch.equal(qall[:, :, :, 1], q[:64])
 

@@ -1647,6 +1647,151 @@ __global__ void __launch_bounds__(512) lstm_rec16_kernel(const LstmSeqArgs a) {
     }
 }
 
+// ---------------------------------------------------------------------------
+// lstm_rec4_kernel: lstm_rec16_kernel's job on 4-ROW tiles with v_mfma_f32_4x4x1_16B_f32, for launches with very few
+// rows (a training batch of 64, a date range of a few hundred days): a recurrent step is a chain of dependent work
+// on the one CU a tile sits on, so with CUs to spare the tile should be as small as the matrix instruction allows.
+//   * the instruction multiplies 16 independent blocks of (4 x 1) . (1 x 4): block b = 4 gate rows of ONE hidden unit
+//     (A lane 4 b + gate), B = h[k] of the tile's 4 days replicated in every block (lane 4 b + day), so that lane
+//     (b, day) receives the four gates of unit 16 G + b for its day in its four D registers: the cell is lane-local;
+//   * wave w owns unit group G = w (16 units, 64 gate rows); its W_hh rows (one register per k: 104 - 128) stay in
+//     registers; h goes through LDS as [day][unit] (double-buffered, one barrier per step) and comes back as one
+//     broadcast float4 per four k.
+// Per step a workgroup issues 8 NT x NG / ... = 728 - 1024 two-pass products (1.5 - 2 k cycles per SIMD) against
+// lstm_rec16_kernel's 5.8 - 8.2 k for 16 rows.  Same formats in and out as lstm_rec16_kernel.
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ f32x4 mfma4(float a, float b, f32x4 c) { return __builtin_amdgcn_mfma_f32_4x4x1f32(a, b, c, 0, 0, 0); }
+
+template <int NT, bool SAVE>
+__global__ void __launch_bounds__(512) lstm_rec4_kernel(const LstmSeqArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    constexpr int HP = 8 * NT, HPK = 4 * NT;
+    constexpr int NG = (HP + 15) / 16;                             // unit groups (waves with work)
+    constexpr int HPAD = 144;                                      // LDS floats per day: >= HP, the 4 days 16 banks apart
+    static_assert(NG <= 8 && HP <= HPAD && HP % 4 == 0, "one unit group per wave");
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const long tile4 = (long)blockIdx.x;
+    const int j = lane & 3, b = lane >> 2;                         // day of the tile / unit of the group (B, D); A: gate / unit
+    const long row_raw = tile4 * 4 + j;
+    const bool row_ok = row_raw < a.n_rows;
+    const long row = row_ok ? row_raw : a.n_rows - 1;
+    const long rowtile = tile4 >> 3;                               // the 32-row tile of the other kernels' layouts
+    const int m = 4 * (int)(tile4 & 7) + j;                        // ... and this lane's row inside it
+    const int SNL = a.st_nl > 0 ? a.st_nl : 1;
+    const int SL = (SAVE && a.sv_nl > 0) ? a.sv_nl : 1;
+    const int L0 = (SAVE && a.sv_nl > 0) ? a.sv_l0 : 0;
+    const bool dropping = SAVE && L0 + 1 < SL && a.drop.p > 0.0f;
+    const DropArgs drop = dropping ? resolve_drop(a.drop) : a.drop;
+    const bool active = wave < NG;                                 // (wave-uniform)
+    const int G = active ? wave : NG - 1;
+    const int u0 = 16 * G + b;
+    const bool uok = active && u0 < HP;
+    const int u = u0 < HP ? u0 : HP - 1;                           // (clamped: addresses stay inside the layouts)
+    const int gslot = 16 * (u >> 3) + 4 * ((u & 7) >> 1);          // + gate: slot of the gate value
+    const int l32 = (u & 1) * 32 + m;                              // lane of the 32-row layouts
+    const int hslot = 4 * (u >> 3) + ((u & 7) >> 1);               // slot of h in tile-B
+    const int hpos = 8 * (u >> 3) + 4 * (u & 1) + ((u & 7) >> 1);  // position in the state arrays
+
+    // W_hh rows of (unit 16 G + b, gate lane & 3), one register per hidden input k, gathered from the blob's 32x32x2
+    // fragment layout (vsv_layout.h)
+    float wreg[HP];
+    {
+        const int n = 32 * (u >> 3) + 4 * (u & 7) + (lane & 3);
+#pragma unroll
+        for (int k = 0; k < HP; ++k) {
+            const int kk = 2 * a.kx + k;
+            const float w = a.w[0][((size_t)((kk >> 3) * NT + (n >> 5)) * 64 + ((kk & 1) * 32 + (n & 31))) * 4 + ((kk >> 1) & 3)];
+            wreg[k] = uok ? w : 0.0f;
+        }
+    }
+    auto load_pre = [&](int t) -> f32x4 {
+        if (SAVE) {
+            const float* p = a.sv_gates + (((size_t)(rowtile * a.T + t) * SL + L0) * (16 * NT) + gslot) * 64 + l32;
+            return f32x4{p[0], p[64], p[128], p[192]};
+        } else if (a.pre_t) {
+            const float* p = a.pre_t + (size_t)(2 * gslot + (l32 >> 5)) * a.pre_stride + row + (size_t)t * a.pre_tstride;
+            const size_t st = 2 * (size_t)a.pre_stride;
+            return f32x4{p[0], p[st], p[2 * st], p[3 * st]};
+        }
+        const float* p = a.pre_g + ((size_t)(rowtile * a.T + t) * (16 * NT) + gslot) * 64 + l32;
+        return f32x4{p[0], p[64], p[128], p[192]};
+    };
+    f32x4 pre = load_pre(0);
+
+    float c = 0.0f, h = 0.0f;
+    const bool has_state = a.din.state_in != nullptr;              // wave-uniform
+    if (has_state) {
+        const long srow = a.din.state_div == 1 ? row : row / a.din.state_div;
+        const float* ps = a.din.state_in + ((size_t)srow * SNL + a.st_l0) * 2 * HP + hpos;
+        h = ps[0];
+        c = ps[HP];
+    }
+    float* const hcol = smem + j * HPAD;                           // this lane's day
+    if (uok) hcol[u0] = h;
+    __syncthreads();
+    const int t_outs = a.T - a.t_out0;
+    auto products = [&](f32x4 acc, const float* hr) -> f32x4 {
+        // ONE chain in ascending k: the matrix pipe accumulates a product at a time in k order whatever the tile
+        // shape, so this is bit for bit what lstm_kernel / lstm_rec16_kernel compute (the two waves of a SIMD fill
+        // each other's issue gaps)
+#pragma unroll
+        for (int k = 0; k < HP; k += 4) {
+            const float4 hv = *(const float4*)(hr + k);
+            acc = mfma4(wreg[k + 0], hv.x, acc);
+            acc = mfma4(wreg[k + 1], hv.y, acc);
+            acc = mfma4(wreg[k + 2], hv.z, acc);
+            acc = mfma4(wreg[k + 3], hv.w, acc);
+        }
+        return acc;
+    };
+    for (int t = 0; t < a.T; ++t) {
+        const float* hr = hcol + (t & 1) * (4 * HPAD);
+        float* hw = hcol + ((t + 1) & 1) * (4 * HPAD);
+        f32x4 acc = pre;
+        if (t + 1 < a.T) pre = load_pre(t + 1);                    // lands while the products run
+        if ((t > 0 || has_state) && active) acc = products(acc, hr);
+        const float ig = fast_sigmoid(acc[0]);
+        const float fg = fast_sigmoid(acc[1]);
+        const float gg = fast_tanh(acc[2]);
+        const float og = fast_sigmoid(acc[3]);
+        c = __builtin_fmaf(fg, c, ig * gg);
+        h = og * fast_tanh(c);
+        if (uok) {
+            hw[u0] = h;
+            if (SAVE) {
+                // activated gates, cell and hidden state of the step, where the backward kernels read them
+                const size_t il = (size_t)(rowtile * a.T + t) * SL + L0;
+                float* sg = a.sv_gates + (il * (16 * NT) + gslot) * 64 + l32;
+                sg[0] = ig; sg[64] = fg; sg[128] = gg; sg[192] = og;
+                a.sv_c[(il * HPK + hslot) * 64 + l32] = c;
+                a.sv_h[(il * HPK + hslot) * 64 + l32] = h;
+                if (dropping) {
+                    float fct[4];
+                    dropout_factors(drop, (uint32_t)row, (uint32_t)t, u >> 3, u & 1, L0, fct);
+                    a.sv_hd[((size_t)(rowtile * a.T + t) * HPK + hslot) * 64 + l32] = h * fct[(u & 7) >> 1];
+                }
+            }
+            if (a.hout && t >= a.t_out0)                           // (padding rows too: the next stage reads whole tiles)
+                a.hout[((size_t)(rowtile * t_outs + (t - a.t_out0)) * HPK + hslot) * 64 + l32] = h;
+        }
+        __syncthreads();                                           // h(t) published (the other buffer is free again)
+    }
+    if (a.state_out && row_ok && uok) {
+        float* st = a.state_out + ((size_t)row_raw * SNL + a.st_l0) * 2 * HP;
+        st[hpos] = h;
+        st[HP + hpos] = c;
+    }
+    if (a.din.gate_out) {
+        // bias + W_hh . h_final: the part of the next step's gates shared by all rows continuing from this state
+        const float* hf = hcol + (a.T & 1) * (4 * HPAD);
+        const int bi = (gslot >> 4) * 32 + (l32 >> 5) * 16 + (gslot & 15);
+        f32x4 g = f32x4{a.b[0][bi], a.b[0][bi + 1], a.b[0][bi + 2], a.b[0][bi + 3]};
+        if (active) g = products(g, hf);
+        if (row_ok && uok)
+            *(float4*)(a.din.gate_out + ((size_t)row_raw * SNL + a.st_l0) * NT * 32 + bi) = make_float4(g[0], g[1], g[2], g[3]);
+    }
+}
+
 // The decoder memory's input [ctx_pad | z] of every (row, step) in the tile-B layout the training kernels save
 // (sv_x: [inst = rowtile*T + t][kx slots][64], slot s of lane hh*32 + r = feature 2s + hh of row 32*rowtile + r),
 // with the reparameterised z written to z_out: what lstm_kernel<.., XMODE 1> assembles on its time loop, as one
@@ -2923,9 +3068,26 @@ static int launch_lstm_rec16(const LstmSeqArgs& a, hipStream_t st) {
     return launch_check("lstm_rec16_kernel");
 }
 
+// 4-row tiles while eight of them per 32-row tile still find a CU each (VSV_REC4=0: 16-row tiles)
+template <int NT>
+static int launch_lstm_rec4(const LstmSeqArgs& a, hipStream_t st) {
+    const size_t lds = (size_t)2 * 4 * 144 * sizeof(float);
+    if (a.sv_gates) hipLaunchKernelGGL((lstm_rec4_kernel<NT, true>), dim3((unsigned)(8 * a.n_rowtiles)), dim3(512), lds, st, a);
+    else hipLaunchKernelGGL((lstm_rec4_kernel<NT, false>), dim3((unsigned)(8 * a.n_rowtiles)), dim3(512), lds, st, a);
+    return launch_check("lstm_rec4_kernel");
+}
+static bool lstm_rec4_applies(const LstmSeqArgs& a) {
+    static const int mode = [] { const char* e = getenv("VSV_REC4"); return e ? e[0] - '0' : 1; }();
+    return mode == 2 || (mode == 1 && 8 * a.n_rowtiles <= 256);
+}
+
 template <int XMODE>
 static int launch_lstm(const LstmSeqArgs& a, int NT, int NL, bool head, hipStream_t st) {
     if (a.n_rowtiles <= 0 || a.T <= 0) return 0;
+    if (XMODE == 0 && !head && lstm_rec16_applies(a, NL) && lstm_rec4_applies(a)) {
+        if (NT == 13) return launch_lstm_rec4<13>(a, st);
+        if (NT == 16) return launch_lstm_rec4<16>(a, st);
+    }
     if (XMODE == 0 && !head && lstm_rec16_applies(a, NL)) {
         if (NT == 13) return launch_lstm_rec16<13>(a, st);
         if (NT == 16) return launch_lstm_rec16<16>(a, st);
@@ -3023,9 +3185,11 @@ static int launch_lstm_pre(int NT, const float* w, const float* b, int nq_in, co
     if (insts > 0x7fffffffL) { set_error("lstm_pre_kernel: too many instances"); return -2; }
     if (nq_in < 1 || nq_in > kPreMaxQ) { set_error("lstm_pre_kernel: %d input quads (1..%d built)", nq_in, kPreMaxQ); return -4; }
     if (insts <= 0) return 0;
-    // instances per workgroup: as many as still leave four workgroups per CU
-    int ipw = (int)(insts / 1024);
-    ipw = ipw < 1 ? 1 : (ipw > 16 ? 16 : ipw);
+    // instances per workgroup: one workgroup of NT waves fills a CU (its registers), so at most one round of 256
+    // workgroups, each walking its share of the instances with the next one's x in flight (a workgroup per instance
+    // paid the W_ih tile load and an unpipelined x fetch for every instance: 82 us instead of 25 at 960 instances)
+    int ipw = (int)((insts + 255) / 256);
+    ipw = ipw < 1 ? 1 : (ipw > 64 ? 64 : ipw);
     const unsigned grid = (unsigned)((insts + ipw - 1) / ipw);
     if (NT == 13) hipLaunchKernelGGL(lstm_pre_kernel<13>, dim3(grid), dim3(64 * 13), 0, st, w, b, nq_in, x, x_stride, gates, g_stride, insts, ipw);
     else if (NT == 16) hipLaunchKernelGGL(lstm_pre_kernel<16>, dim3(grid), dim3(64 * 16), 0, st, w, b, nq_in, x, x_stride, gates, g_stride, insts, ipw);

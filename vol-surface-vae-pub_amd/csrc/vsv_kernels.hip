@@ -2576,6 +2576,124 @@ __global__ void __launch_bounds__(512) lstm_bwd16_kernel(const LstmBwdArgs a) {
 }
 
 // ---------------------------------------------------------------------------
+// lstm_bwd4_kernel: lstm_bwd16_kernel's job on 4-ROW tiles with v_mfma_f32_4x4x1_16B_f32 (see lstm_rec4_kernel), for
+// the smallest training batches: batch 64 becomes 16 tiles on 16 CUs instead of 4.
+//   * one instruction gives dh of 64 hidden units (block b = units 4 b .. 4 b + 3, D register i) for the tile's 4 rows
+//     from ONE gate row k: A lane (b, i) = W_hh[k][unit 64 Go + 4 b + i], B lane (b, j) = dgates[k][row j] in every block;
+//   * the 8 waves are (output group Go = w >> 2) x (K slice s = w & 3), slice s = gate s of every unit (HP products,
+//     W_hh^T rows in registers); the four partial tiles of a group meet in LDS, and thread (w, lane 4 b + j) finishes
+//     ONE (unit 64 Go + 4 b + s, row j): sum of the four partials' register s, cell backward, four gate gradients,
+//     which go to LDS as [gate][row][unit] -- the next step's B operands, read as broadcast float4s -- and to global
+//     memory in lstm_bwd_kernel's format.  Two barriers per step.
+// ---------------------------------------------------------------------------
+template <int NT>
+__global__ void __launch_bounds__(512) lstm_bwd4_kernel(const LstmBwdArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    constexpr int HP = 8 * NT;
+    constexpr int GK = 16 * NT;
+    constexpr int HPAD = 144;                                      // LDS floats per (gate, row): >= HP, rows 16 banks apart
+    static_assert(HP <= 128 && HP <= HPAD && HP % 4 == 0, "two output groups of 64 units");
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const long tile4 = (long)blockIdx.x;
+    const int j = lane & 3, b = lane >> 2;
+    const int Go = wave >> 2, s = wave & 3;
+    const long row_raw = tile4 * 4 + j;
+    const bool row_ok = row_raw < a.n_rows;
+    const long rowtile = tile4 >> 3;
+    const int m = 4 * (int)(tile4 & 7) + j;
+    const int SL = a.sv_nl > 0 ? a.sv_nl : 1, L0 = a.sv_nl > 0 ? a.sv_l0 : 0;
+    const int t_outs = a.T - a.t_out0;
+    float* const dgl = smem;                                       // [gate 4][row 4][HPAD]
+    float* const part = smem + 4 * 4 * HPAD;                       // [wave 8][register 4][lane 64]
+
+    // the (unit, row) this thread finishes, and where its values live in the 32-row layouts
+    const int u0 = 64 * Go + 4 * b + s;
+    const bool uok = u0 < HP;
+    const int u = uok ? u0 : HP - 1;                               // (clamped: addresses stay inside the instance)
+    const int gsl = 16 * (u >> 3) + 4 * ((u & 7) >> 1);            // + gate: slot of a gate value
+    const int l32 = (u & 1) * 32 + m;
+    const int hsl = 4 * (u >> 3) + ((u & 7) >> 1);                 // slot of c
+    const int dsl = 16 * ((u >> 3) & 3) + 4 * (u >> 5) + ((u & 7) >> 1);   // slot of dh_top (unit-tile order)
+
+    // W_hh[gate s of unit ua][unit uk = 64 Go + 4 b + (lane & 3)] for every ua, from the transposed blob
+    // (train.py transposed_map, kind 'unit': see lstm_bwd16_kernel)
+    float wreg[HP];
+    {
+        const int uk = 64 * Go + 4 * b + (lane & 3);
+        const bool kok = uk < HP;
+        const int ukc = kok ? uk : HP - 1;
+        const int t8 = ukc >> 3;
+        const int i32 = 8 * (t8 >> 2) + 4 * (ukc & 1) + ((ukc & 7) >> 1);
+#pragma unroll
+        for (int ua = 0; ua < HP; ++ua) {
+            const int sslot = 16 * (ua >> 3) + 4 * ((ua & 7) >> 1) + s;
+            const size_t pos = ((size_t)((sslot >> 2) * 4 + (t8 & 3)) * 64 + (ua & 1) * 32 + i32) * 4 + (sslot & 3);
+            const float w = a.wT_hh[0][pos];
+            wreg[ua] = kok ? w : 0.0f;
+        }
+    }
+    float dc = 0.0f;
+    const float* const hr = dgl + (size_t)(s * 4 + j) * HPAD;      // this wave's K slice (gate s), this lane's row
+
+    for (int t = a.T - 1; t >= 0; --t) {
+        const size_t inst = (size_t)(rowtile * a.T + t);
+        // saved gates and cell states of the step: requested before the products, which do not depend on them
+        float gsv[4], cn, cp, dht = 0.0f;
+        {
+            const float* sg = a.sv_gates + ((inst * SL + L0) * GK + gsl) * 64 + l32;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) gsv[g] = sg[(size_t)g * 64];
+            cn = a.sv_c[((inst * SL + L0) * (4 * NT) + hsl) * 64 + l32];
+            cp = (t > 0) ? a.sv_c[(((inst - 1) * SL + L0) * (4 * NT) + hsl) * 64 + l32] : 0.0f;
+            if (t >= a.t_out0 && a.dh_top)
+                dht = a.dh_top[((size_t)(rowtile * t_outs + (t - a.t_out0)) * 64 + dsl) * 64 + l32];
+        }
+        f32x4 acc = {0.0f, 0.0f, 0.0f, 0.0f};
+        if (t + 1 < a.T) {
+            f32x4 a1 = acc, a2 = acc, a3 = acc;
+#pragma unroll
+            for (int k = 0; k < HP; k += 4) {
+                const float4 gv = *(const float4*)(hr + k);
+                acc = mfma4(wreg[k + 0], gv.x, acc);
+                a1 = mfma4(wreg[k + 1], gv.y, a1);
+                a2 = mfma4(wreg[k + 2], gv.z, a2);
+                a3 = mfma4(wreg[k + 3], gv.w, a3);
+            }
+#pragma unroll
+            for (int v = 0; v < 4; ++v) acc[v] += (a1[v] + a2[v]) + a3[v];
+        }
+        {
+            float* o = part + (size_t)(wave * 4) * 64 + lane;
+            o[0] = acc[0]; o[64] = acc[1]; o[128] = acc[2]; o[192] = acc[3];
+        }
+        __syncthreads();                                           // partial tiles published; dgates(t+1) read by all
+        float dh = dht;
+        {
+            const float* pp = part + (size_t)(4 * Go * 4 + s) * 64 + lane;      // register s of the group's four waves
+            dh += (pp[0] + pp[4 * 64]) + (pp[8 * 64] + pp[12 * 64]);
+        }
+        {
+            const float ig = gsv[0], fg = gsv[1], gg = gsv[2], og = gsv[3];
+            const float th = fast_tanh(cn);
+            const float dct = dc + dh * og * (1.0f - th * th);
+            const bool ok = uok && row_ok;
+            const float dog = ok ? dh * th * og * (1.0f - og) : 0.0f;
+            const float di = ok ? dct * gg * ig * (1.0f - ig) : 0.0f;
+            const float df = ok ? dct * cp * fg * (1.0f - fg) : 0.0f;
+            const float dgg = ok ? dct * ig * (1.0f - gg * gg) : 0.0f;
+            dc = dct * fg;
+            if (uok) {
+                float* lw = dgl + (size_t)j * HPAD + u0;
+                lw[0] = di; lw[4 * HPAD] = df; lw[8 * HPAD] = dgg; lw[12 * HPAD] = dog;
+                float* o = a.dgates + ((inst * SL + L0) * GK + gsl) * 64 + l32;
+                o[0] = di; o[64] = df; o[128] = dgg; o[192] = dog;
+            }
+        }
+        __syncthreads();                                           // dgates(t) published
+    }
+}
+
+// ---------------------------------------------------------------------------
 // tileb_gemm_kernel: Y(inst) = W^T-fragments . G(inst) for every (row tile, t) instance at once -- the
 // parts of BPTT that do not sit on the recurrence (d h_{l-1}(t) = W_in(l)^T . dgates(l, t) and
 // dx(t) = W_in(0)^T . dgates(0, t)), taken out of lstm_bwd_kernel's time loop so that they run on as
@@ -4559,6 +4677,14 @@ extern "C" int vsv_lstm_backward(const vsv_lstm_bwd* d, int hidden, int layers, 
     const int NT = (hidden + 7) / 8;
     hipStream_t st = (hipStream_t)stream;
     if (lstm_bwd16_applies(*d, layers)) {
+        // 4-row tiles while eight of them per 32 rows still find a CU each (VSV_BWD4=0: 16-row tiles)
+        static const bool no4 = [] { const char* e = getenv("VSV_BWD4"); return e && e[0] == '0'; }();
+        if (!no4 && 8 * d->n_rowtiles <= 256) {
+            const size_t lds = (size_t)(4 * 4 * 144 + 8 * 4 * 64) * sizeof(float);
+            if (NT == 13) hipLaunchKernelGGL((lstm_bwd4_kernel<13>), dim3((unsigned)(8 * d->n_rowtiles)), dim3(512), lds, st, *d);
+            else if (NT == 16) hipLaunchKernelGGL((lstm_bwd4_kernel<16>), dim3((unsigned)(8 * d->n_rowtiles)), dim3(512), lds, st, *d);
+            if (NT == 13 || NT == 16) return launch_check("lstm_bwd4_kernel");
+        }
         if (NT == 13) return launch_lstm_bwd16<13>(*d, st);
         if (NT == 16) return launch_lstm_bwd16<16>(*d, st);
     }

@@ -1694,14 +1694,19 @@ __global__ void __launch_bounds__(512) lstm_rec4_kernel(const LstmSeqArgs a) {
 
     // W_hh rows of (unit 16 G + b, gate lane & 3), one register per hidden input k, gathered from the blob's 32x32x2
     // fragment layout (vsv_layout.h)
+    // (element (row n, input kk) sits at quad kk >> 3, tile n >> 5, lane (kk & 1) * 32 + (n & 31), component
+    // (kk >> 1) & 3: eight consecutive k of one row are two float4s, the even and the odd k; kx is a multiple of 4)
     float wreg[HP];
     {
         const int n = 32 * (u >> 3) + 4 * (u & 7) + (lane & 3);
+        const float4* wq = (const float4*)a.w[0] + (size_t)((a.kx >> 2) * NT + (n >> 5)) * 64 + (n & 31);
 #pragma unroll
-        for (int k = 0; k < HP; ++k) {
-            const int kk = 2 * a.kx + k;
-            const float w = a.w[0][((size_t)((kk >> 3) * NT + (n >> 5)) * 64 + ((kk & 1) * 32 + (n & 31))) * 4 + ((kk >> 1) & 3)];
-            wreg[k] = uok ? w : 0.0f;
+        for (int q = 0; q < HP / 8; ++q) {
+            const float4 we = wq[(size_t)q * NT * 64], wo = wq[(size_t)q * NT * 64 + 32];
+            wreg[8 * q + 0] = uok ? we.x : 0.0f; wreg[8 * q + 2] = uok ? we.y : 0.0f;
+            wreg[8 * q + 4] = uok ? we.z : 0.0f; wreg[8 * q + 6] = uok ? we.w : 0.0f;
+            wreg[8 * q + 1] = uok ? wo.x : 0.0f; wreg[8 * q + 3] = uok ? wo.y : 0.0f;
+            wreg[8 * q + 5] = uok ? wo.z : 0.0f; wreg[8 * q + 7] = uok ? wo.w : 0.0f;
         }
     }
     auto load_pre = [&](int t) -> f32x4 {

@@ -1662,21 +1662,23 @@ __global__ void __launch_bounds__(512) lstm_rec16_kernel(const LstmSeqArgs a) {
 // ---------------------------------------------------------------------------
 __device__ __forceinline__ f32x4 mfma4(float a, float b, f32x4 c) { return __builtin_amdgcn_mfma_f32_4x4x1f32(a, b, c, 0, 0, 0); }
 
-template <int NT, bool SAVE>
+// R tiles per workgroup (R = 1 or 2: 4 or 8 rows), their product chains interleaved, W_hh shared in registers: R = 2
+// serves launches of 257 - 512 tiles in one round of workgroups (1000 days: 0.97 ms against 1.12 with R = 1).  A step's
+// time grows with R (four tiles per workgroup measured no better than lstm_rec16_kernel), so larger launches stay on
+// that kernel.  Every tile's chain is the same ascending-k chain: results do not depend on R.
+template <int NT, bool SAVE, int R>
 __global__ void __launch_bounds__(512) lstm_rec4_kernel(const LstmSeqArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int HP = 8 * NT, HPK = 4 * NT;
     constexpr int NG = (HP + 15) / 16;                             // unit groups (waves with work)
     constexpr int HPAD = 144;                                      // LDS floats per day: >= HP, the 4 days 16 banks apart
-    static_assert(NG <= 8 && HP <= HPAD && HP % 4 == 0, "one unit group per wave");
+    static_assert(NG <= 8 && HP <= HPAD && HP % 8 == 0, "one unit group per wave");
+    static_assert(R == 1 || R == 2, "tiles of one workgroup stay inside a 32-row tile");
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const long tile4 = (long)blockIdx.x;
+    const long tile4 = (long)blockIdx.x * R;                       // first of this workgroup's tiles
     const int j = lane & 3, b = lane >> 2;                         // day of the tile / unit of the group (B, D); A: gate / unit
-    const long row_raw = tile4 * 4 + j;
-    const bool row_ok = row_raw < a.n_rows;
-    const long row = row_ok ? row_raw : a.n_rows - 1;
     const long rowtile = tile4 >> 3;                               // the 32-row tile of the other kernels' layouts
-    const int m = 4 * (int)(tile4 & 7) + j;                        // ... and this lane's row inside it
+    const int m0 = 4 * (int)(tile4 & 7) + j;                       // this lane's row inside it (tile r: + 4 r)
     const int SNL = a.st_nl > 0 ? a.st_nl : 1;
     const int SL = (SAVE && a.sv_nl > 0) ? a.sv_nl : 1;
     const int L0 = (SAVE && a.sv_nl > 0) ? a.sv_l0 : 0;
@@ -1688,9 +1690,17 @@ __global__ void __launch_bounds__(512) lstm_rec4_kernel(const LstmSeqArgs a) {
     const bool uok = active && u0 < HP;
     const int u = u0 < HP ? u0 : HP - 1;                           // (clamped: addresses stay inside the layouts)
     const int gslot = 16 * (u >> 3) + 4 * ((u & 7) >> 1);          // + gate: slot of the gate value
-    const int l32 = (u & 1) * 32 + m;                              // lane of the 32-row layouts
+    const int l32 = (u & 1) * 32 + m0;                             // lane of the 32-row layouts (tile r: + 4 r)
     const int hslot = 4 * (u >> 3) + ((u & 7) >> 1);               // slot of h in tile-B
     const int hpos = 8 * (u >> 3) + 4 * (u & 1) + ((u & 7) >> 1);  // position in the state arrays
+    long row[R];
+    bool row_ok[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const long rr = (tile4 + r) * 4 + j;
+        row_ok[r] = rr < a.n_rows;
+        row[r] = row_ok[r] ? rr : a.n_rows - 1;
+    }
 
     // W_hh rows of (unit 16 G + b, gate lane & 3), one register per hidden input k, gathered from the blob's 32x32x2
     // fragment layout (vsv_layout.h)
@@ -1709,91 +1719,117 @@ __global__ void __launch_bounds__(512) lstm_rec4_kernel(const LstmSeqArgs a) {
             wreg[8 * q + 5] = uok ? wo.z : 0.0f; wreg[8 * q + 7] = uok ? wo.w : 0.0f;
         }
     }
-    auto load_pre = [&](int t) -> f32x4 {
+    auto load_pre = [&](int r, int t) -> f32x4 {
         if (SAVE) {
-            const float* p = a.sv_gates + (((size_t)(rowtile * a.T + t) * SL + L0) * (16 * NT) + gslot) * 64 + l32;
+            const float* p = a.sv_gates + (((size_t)(rowtile * a.T + t) * SL + L0) * (16 * NT) + gslot) * 64 + l32 + 4 * r;
             return f32x4{p[0], p[64], p[128], p[192]};
         } else if (a.pre_t) {
-            const float* p = a.pre_t + (size_t)(2 * gslot + (l32 >> 5)) * a.pre_stride + row + (size_t)t * a.pre_tstride;
+            const float* p = a.pre_t + (size_t)(2 * gslot + (l32 >> 5)) * a.pre_stride + row[r] + (size_t)t * a.pre_tstride;
             const size_t st = 2 * (size_t)a.pre_stride;
             return f32x4{p[0], p[st], p[2 * st], p[3 * st]};
         }
-        const float* p = a.pre_g + ((size_t)(rowtile * a.T + t) * (16 * NT) + gslot) * 64 + l32;
+        const float* p = a.pre_g + ((size_t)(rowtile * a.T + t) * (16 * NT) + gslot) * 64 + l32 + 4 * r;
         return f32x4{p[0], p[64], p[128], p[192]};
     };
-    f32x4 pre = load_pre(0);
-
-    float c = 0.0f, h = 0.0f;
+    f32x4 pre[R];
+    float c[R], h[R];
     const bool has_state = a.din.state_in != nullptr;              // wave-uniform
-    if (has_state) {
-        const long srow = a.din.state_div == 1 ? row : row / a.din.state_div;
-        const float* ps = a.din.state_in + ((size_t)srow * SNL + a.st_l0) * 2 * HP + hpos;
-        h = ps[0];
-        c = ps[HP];
+    float* const hcol = smem + j * HPAD;                           // this lane's day: tile r, buffer p at (p * R + r) * 4 HPAD
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        pre[r] = load_pre(r, 0);
+        c[r] = 0.0f;
+        h[r] = 0.0f;
+        if (has_state) {
+            const long srow = a.din.state_div == 1 ? row[r] : row[r] / a.din.state_div;
+            const float* ps = a.din.state_in + ((size_t)srow * SNL + a.st_l0) * 2 * HP + hpos;
+            h[r] = ps[0];
+            c[r] = ps[HP];
+        }
+        if (uok) hcol[(size_t)r * (4 * HPAD) + u0] = h[r];
     }
-    float* const hcol = smem + j * HPAD;                           // this lane's day
-    if (uok) hcol[u0] = h;
     __syncthreads();
     const int t_outs = a.T - a.t_out0;
-    auto products = [&](f32x4 acc, const float* hr) -> f32x4 {
-        // ONE chain in ascending k: the matrix pipe accumulates a product at a time in k order whatever the tile
-        // shape, so this is bit for bit what lstm_kernel / lstm_rec16_kernel compute (the two waves of a SIMD fill
-        // each other's issue gaps)
+    // per tile ONE chain in ascending k: the matrix pipe accumulates a product at a time in k order whatever the
+    // tile shape, so this is bit for bit what lstm_kernel / lstm_rec16_kernel compute; the R chains (and the two
+    // waves of a SIMD) fill each other's issue gaps
+    auto products = [&](f32x4 (&acc)[R], const float* hr) {
 #pragma unroll
         for (int k = 0; k < HP; k += 4) {
-            const float4 hv = *(const float4*)(hr + k);
-            acc = mfma4(wreg[k + 0], hv.x, acc);
-            acc = mfma4(wreg[k + 1], hv.y, acc);
-            acc = mfma4(wreg[k + 2], hv.z, acc);
-            acc = mfma4(wreg[k + 3], hv.w, acc);
+            float4 hv[R];
+#pragma unroll
+            for (int r = 0; r < R; ++r) hv[r] = *(const float4*)(hr + (size_t)r * (4 * HPAD) + k);
+#pragma unroll
+            for (int r = 0; r < R; ++r) acc[r] = mfma4(wreg[k + 0], hv[r].x, acc[r]);
+#pragma unroll
+            for (int r = 0; r < R; ++r) acc[r] = mfma4(wreg[k + 1], hv[r].y, acc[r]);
+#pragma unroll
+            for (int r = 0; r < R; ++r) acc[r] = mfma4(wreg[k + 2], hv[r].z, acc[r]);
+#pragma unroll
+            for (int r = 0; r < R; ++r) acc[r] = mfma4(wreg[k + 3], hv[r].w, acc[r]);
         }
-        return acc;
     };
     for (int t = 0; t < a.T; ++t) {
-        const float* hr = hcol + (t & 1) * (4 * HPAD);
-        float* hw = hcol + ((t + 1) & 1) * (4 * HPAD);
-        f32x4 acc = pre;
-        if (t + 1 < a.T) pre = load_pre(t + 1);                    // lands while the products run
-        if ((t > 0 || has_state) && active) acc = products(acc, hr);
-        const float ig = fast_sigmoid(acc[0]);
-        const float fg = fast_sigmoid(acc[1]);
-        const float gg = fast_tanh(acc[2]);
-        const float og = fast_sigmoid(acc[3]);
-        c = __builtin_fmaf(fg, c, ig * gg);
-        h = og * fast_tanh(c);
-        if (uok) {
-            hw[u0] = h;
-            if (SAVE) {
-                // activated gates, cell and hidden state of the step, where the backward kernels read them
-                const size_t il = (size_t)(rowtile * a.T + t) * SL + L0;
-                float* sg = a.sv_gates + (il * (16 * NT) + gslot) * 64 + l32;
-                sg[0] = ig; sg[64] = fg; sg[128] = gg; sg[192] = og;
-                a.sv_c[(il * HPK + hslot) * 64 + l32] = c;
-                a.sv_h[(il * HPK + hslot) * 64 + l32] = h;
-                if (dropping) {
-                    float fct[4];
-                    dropout_factors(drop, (uint32_t)row, (uint32_t)t, u >> 3, u & 1, L0, fct);
-                    a.sv_hd[((size_t)(rowtile * a.T + t) * HPK + hslot) * 64 + l32] = h * fct[(u & 7) >> 1];
+        const float* hr = hcol + (size_t)((t & 1) * R) * (4 * HPAD);
+        float* hw = hcol + (size_t)(((t + 1) & 1) * R) * (4 * HPAD);
+        f32x4 acc[R];
+#pragma unroll
+        for (int r = 0; r < R; ++r) acc[r] = pre[r];
+        if (t + 1 < a.T) {
+#pragma unroll
+            for (int r = 0; r < R; ++r) pre[r] = load_pre(r, t + 1);   // lands while the products run
+        }
+        if ((t > 0 || has_state) && active) products(acc, hr);
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const float ig = fast_sigmoid(acc[r][0]);
+            const float fg = fast_sigmoid(acc[r][1]);
+            const float gg = fast_tanh(acc[r][2]);
+            const float og = fast_sigmoid(acc[r][3]);
+            c[r] = __builtin_fmaf(fg, c[r], ig * gg);
+            h[r] = og * fast_tanh(c[r]);
+            if (uok) {
+                hw[(size_t)r * (4 * HPAD) + u0] = h[r];
+                if (SAVE) {
+                    // activated gates, cell and hidden state of the step, where the backward kernels read them
+                    const size_t il = (size_t)(rowtile * a.T + t) * SL + L0;
+                    float* sg = a.sv_gates + (il * (16 * NT) + gslot) * 64 + l32 + 4 * r;
+                    sg[0] = ig; sg[64] = fg; sg[128] = gg; sg[192] = og;
+                    a.sv_c[(il * HPK + hslot) * 64 + l32 + 4 * r] = c[r];
+                    a.sv_h[(il * HPK + hslot) * 64 + l32 + 4 * r] = h[r];
+                    if (dropping) {
+                        float fct[4];
+                        dropout_factors(drop, (uint32_t)row[r], (uint32_t)t, u >> 3, u & 1, L0, fct);
+                        a.sv_hd[((size_t)(rowtile * a.T + t) * HPK + hslot) * 64 + l32 + 4 * r] = h[r] * fct[(u & 7) >> 1];
+                    }
                 }
+                if (a.hout && t >= a.t_out0)                       // (padding rows too: the next stage reads whole tiles)
+                    a.hout[((size_t)(rowtile * t_outs + (t - a.t_out0)) * HPK + hslot) * 64 + l32 + 4 * r] = h[r];
             }
-            if (a.hout && t >= a.t_out0)                           // (padding rows too: the next stage reads whole tiles)
-                a.hout[((size_t)(rowtile * t_outs + (t - a.t_out0)) * HPK + hslot) * 64 + l32] = h;
         }
         __syncthreads();                                           // h(t) published (the other buffer is free again)
     }
-    if (a.state_out && row_ok && uok) {
-        float* st = a.state_out + ((size_t)row_raw * SNL + a.st_l0) * 2 * HP;
-        st[hpos] = h;
-        st[HP + hpos] = c;
+    if (a.state_out && uok) {
+#pragma unroll
+        for (int r = 0; r < R; ++r)
+            if (row_ok[r]) {
+                float* st = a.state_out + ((size_t)row[r] * SNL + a.st_l0) * 2 * HP;
+                st[hpos] = h[r];
+                st[HP + hpos] = c[r];
+            }
     }
     if (a.din.gate_out) {
         // bias + W_hh . h_final: the part of the next step's gates shared by all rows continuing from this state
-        const float* hf = hcol + (a.T & 1) * (4 * HPAD);
+        const float* hf = hcol + (size_t)((a.T & 1) * R) * (4 * HPAD);
         const int bi = (gslot >> 4) * 32 + (l32 >> 5) * 16 + (gslot & 15);
-        f32x4 g = f32x4{a.b[0][bi], a.b[0][bi + 1], a.b[0][bi + 2], a.b[0][bi + 3]};
-        if (active) g = products(g, hf);
-        if (row_ok && uok)
-            *(float4*)(a.din.gate_out + ((size_t)row_raw * SNL + a.st_l0) * NT * 32 + bi) = make_float4(g[0], g[1], g[2], g[3]);
+        f32x4 g[R];
+#pragma unroll
+        for (int r = 0; r < R; ++r) g[r] = f32x4{a.b[0][bi], a.b[0][bi + 1], a.b[0][bi + 2], a.b[0][bi + 3]};
+        if (active) products(g, hf);
+#pragma unroll
+        for (int r = 0; r < R; ++r)
+            if (row_ok[r] && uok)
+                *(float4*)(a.din.gate_out + ((size_t)row[r] * SNL + a.st_l0) * NT * 32 + bi) = make_float4(g[r][0], g[r][1], g[r][2], g[r][3]);
     }
 }
 
@@ -3191,17 +3227,26 @@ static int launch_lstm_rec16(const LstmSeqArgs& a, hipStream_t st) {
     return launch_check("lstm_rec16_kernel");
 }
 
-// 4-row tiles while eight of them per 32-row tile still find a CU each (VSV_REC4=0: 16-row tiles)
-template <int NT>
-static int launch_lstm_rec4(const LstmSeqArgs& a, hipStream_t st) {
-    const size_t lds = (size_t)2 * 4 * 144 * sizeof(float);
-    if (a.sv_gates) hipLaunchKernelGGL((lstm_rec4_kernel<NT, true>), dim3((unsigned)(8 * a.n_rowtiles)), dim3(512), lds, st, a);
-    else hipLaunchKernelGGL((lstm_rec4_kernel<NT, false>), dim3((unsigned)(8 * a.n_rowtiles)), dim3(512), lds, st, a);
+// 4-row tiles, one or two per workgroup, while the launch stays one round of workgroups; beyond 512 tiles (2048 rows)
+// lstm_rec16_kernel is the faster one again (4000 days: 2.63 ms against 2.9).  VSV_REC4=0: always lstm_rec16_kernel;
+// VSV_REC4_R=1|2 forces R
+template <int NT, bool SAVE, int R>
+static int launch_lstm_rec4_r(const LstmSeqArgs& a, hipStream_t st) {
+    const size_t lds = (size_t)2 * R * 4 * 144 * sizeof(float);
+    hipLaunchKernelGGL((lstm_rec4_kernel<NT, SAVE, R>), dim3((unsigned)(8 * a.n_rowtiles / R)), dim3(512), lds, st, a);
     return launch_check("lstm_rec4_kernel");
 }
+template <int NT>
+static int launch_lstm_rec4(const LstmSeqArgs& a, hipStream_t st) {
+    static const int forced = [] { const char* e = getenv("VSV_REC4_R"); return e ? atoi(e) : 0; }();
+    int R = 8 * a.n_rowtiles <= 128 ? 1 : 2;                      // (two stacks usually run side by side: half the CUs each)
+    if (forced == 1 || forced == 2) R = forced;
+    if (a.sv_gates) return R == 1 ? launch_lstm_rec4_r<NT, true, 1>(a, st) : launch_lstm_rec4_r<NT, true, 2>(a, st);
+    return R == 1 ? launch_lstm_rec4_r<NT, false, 1>(a, st) : launch_lstm_rec4_r<NT, false, 2>(a, st);
+}
 static bool lstm_rec4_applies(const LstmSeqArgs& a) {
-    static const int mode = [] { const char* e = getenv("VSV_REC4"); return e ? e[0] - '0' : 1; }();
-    return mode == 2 || (mode == 1 && 8 * a.n_rowtiles <= 256);
+    static const bool off = [] { const char* e = getenv("VSV_REC4"); return e && e[0] == '0'; }();
+    return !off && 8 * a.n_rowtiles <= 512;
 }
 
 template <int XMODE>

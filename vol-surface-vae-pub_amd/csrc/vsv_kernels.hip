@@ -801,6 +801,47 @@ __device__ __forceinline__ void lstm_cell(f32x16 (&acc)[OWN], float (&c)[OWN][4]
     }
 }
 
+// The LSTM cell of lstm_cell<false, 4> (kind 0) on PACKED fp32 instructions (v_pk_mul_f32 / v_pk_add_f32 /
+// v_pk_fma_f32: two values per lane and issue slot).  The (i, f) and (g, o) gate pairs of a unit are neighbours in
+// the accumulator; from the cell update on, the units 2u and 2u + 1 of a tile are paired.  Every value goes through
+// the same IEEE operations in the same order as in lstm_cell (x * -log2e, exp2, 1 +, rcp, fma), so the results are
+// bit-equal; what changes is that 15 non-transcendental instructions per unit become 7.5.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f32x2 pk_sig_of_scaled(f32x2 t) {       // 1 / (1 + 2^t), per half
+    f32x2 e;
+    e.x = __builtin_amdgcn_exp2f(t.x);
+    e.y = __builtin_amdgcn_exp2f(t.y);
+    e = e + (f32x2){1.0f, 1.0f};
+    f32x2 r;
+    r.x = __builtin_amdgcn_rcpf(e.x);
+    r.y = __builtin_amdgcn_rcpf(e.y);
+    return r;
+}
+__device__ __forceinline__ void lstm_cell_pk(f32x16 (&acc)[4], float (&c)[4][4], float (&hn)[4][4]) {
+    constexpr float kS = -1.4426950408889634f, kT = -2.885390081777927f;   // sigmoid / tanh exponent scales
+    const f32x2 one = {1.0f, 1.0f}, two = {2.0f, 2.0f};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            f32x2 ig, fg, rg, og;
+#pragma unroll
+            for (int v = 0; v < 2; ++v) {
+                const int jj = 2 * u + v;
+                const f32x2 sif = pk_sig_of_scaled((f32x2){acc[i][4 * jj + 0], acc[i][4 * jj + 1]} * (f32x2){kS, kS});
+                const f32x2 sgo = pk_sig_of_scaled((f32x2){acc[i][4 * jj + 2], acc[i][4 * jj + 3]} * (f32x2){kT, kS});
+                ig[v] = sif.x; fg[v] = sif.y; rg[v] = sgo.x; og[v] = sgo.y;
+            }
+            const f32x2 gg = __builtin_elementwise_fma(rg, two, -one);            // tanh = 2 sigmoid(2x) - 1
+            const f32x2 cn = __builtin_elementwise_fma(fg, (f32x2){c[i][2 * u], c[i][2 * u + 1]}, ig * gg);
+            const f32x2 th = __builtin_elementwise_fma(pk_sig_of_scaled(cn * (f32x2){kT, kT}), two, -one);
+            const f32x2 h = og * th;
+            c[i][2 * u] = cn.x; c[i][2 * u + 1] = cn.y;
+            hn[i][2 * u] = h.x; hn[i][2 * u + 1] = h.y;
+        }
+    }
+}
+
 // Decoder head on the top-layer h of this step: layer li's output tile `wave` is computed by
 // wave `wave`; activations ping-pong between two LDS buffers (64 slots each) with one barrier
 // per layer; the next layer's weights are fetched before that barrier.  Every wave of the
@@ -1985,7 +2026,7 @@ __global__ void __launch_bounds__(256, 2) mc_decode1_kernel(const LstmSeqArgs a)
                 for (int j = 0; j < 4; ++j) bv[j] = bcol[(4 * q + j) * 64];
             });
             MC1_STAMP(2 * (l * NP + p) + 2);
-            lstm_cell<false, 4>(acc, c, hn, 0);
+            lstm_cell_pk(acc, c, hn);
             // (pinned: left to itself the compiler sinks the cell math of all four passes below the last
             // pass's GEMM and parks the earlier passes' accumulators in scratch meanwhile)
 #pragma unroll

@@ -263,6 +263,78 @@ __device__ __forceinline__ void tile_mfma_band(f32x16& acc, float4 (&a)[kHalfQ],
     }
 }
 
+// The same streams with BUFFER-addressed weight loads (mc_decode1_kernel): the fragment address is
+// descriptor base (SGPRs) + lane offset (one VGPR per phase) + a scalar byte offset that carries tile, quad and
+// band, so a load costs no vector instruction (the flat form above spends one 32-bit add and one 64-bit
+// shift-add per load: nine vector instructions per quad of sixteen products).  The descriptor has no stride and
+// no bound: offsets are plain byte offsets from the section's base, which the packer keeps below 4 GiB.
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef __amdgpu_buffer_rsrc_t wrsrc_t;
+__device__ __forceinline__ wrsrc_t make_wrsrc(const void* base) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, -1, 0x00020000);
+}
+__device__ __forceinline__ float4 bload(wrsrc_t r, unsigned voff, unsigned soff) {
+    const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff, (int)soff, 0);
+    // (the whole vector is reinterpreted: __builtin_bit_cast of ONE ELEMENT of a vector reads element 0 whatever
+    // the index with this compiler)
+    typedef float f32x4v __attribute__((ext_vector_type(4)));
+    const f32x4v g = __builtin_bit_cast(f32x4v, v);
+    float4 f;
+    f.x = g.x; f.y = g.y; f.z = g.z; f.w = g.w;
+    return f;
+}
+// NC consecutive tiles (1 KiB of fragments each) of the quad at scalar byte offset soff
+template <int NC>
+__device__ __forceinline__ void wload_buf(float4 (&a)[NC], wrsrc_t r, unsigned voff, unsigned soff) {
+#pragma unroll
+    for (int i = 0; i < NC; ++i) a[i] = bload(r, voff, soff + (unsigned)i * 1024u);
+}
+template <int NC, typename BL>
+__device__ __forceinline__ void gemm_stream_buf(f32x16 (&acc)[NC], float4 (&a0)[NC], wrsrc_t r, unsigned voff, unsigned sbase,
+                                                unsigned qsb, int nq, BL bl) {
+    float4 a1[NC];
+    float b0[4], b1[4];
+    bl(0, b0);
+    int q = 0;
+#pragma unroll 1
+    for (; q + 1 < nq; q += 2) {
+        wload_buf<NC>(a1, r, voff, sbase + (unsigned)(q + 1) * qsb);
+        bl(q + 1, b1);
+        __builtin_amdgcn_sched_barrier(0);
+        mfma_quad<NC>(acc, a0, b0);
+        __builtin_amdgcn_sched_barrier(0);
+        const int q2 = (q + 2 < nq) ? q + 2 : q + 1;
+        wload_buf<NC>(a0, r, voff, sbase + (unsigned)q2 * qsb);
+        bl(q2, b0);
+        __builtin_amdgcn_sched_barrier(0);
+        mfma_quad<NC>(acc, a1, b1);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    if (q < nq) mfma_quad<NC>(acc, a0, b0);
+}
+__device__ __forceinline__ void tile_load_band_buf(float4 (&a)[kHalfQ], wrsrc_t r, unsigned voff, unsigned sbase, unsigned qsb,
+                                                   int q0, int nqb) {
+#pragma unroll
+    for (int q = 0; q < kHalfQ; ++q) a[q] = bload(r, voff, sbase + (unsigned)(q0 + ((q < nqb) ? q : nqb - 1)) * qsb);
+}
+template <int NQ>
+__device__ __forceinline__ void tile_mfma_band_buf(f32x16& acc, float4 (&a)[kHalfQ], wrsrc_t r, unsigned voff, unsigned sbase,
+                                                   unsigned qsb, const float* b, int q0, int nqb) {
+    const unsigned sb = sbase + (unsigned)q0 * qsb;
+    const float* bb = b + (size_t)q0 * 4 * 64;
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+        if (q < nqb) {
+            const float4 cur = a[q % kHalfQ];
+            if (q + kHalfQ < nqb) a[q % kHalfQ] = bload(r, voff, sb + (unsigned)(q + kHalfQ) * qsb);
+            acc = mfma32(cur.x, bb[(4 * q + 0) * 64], acc);
+            acc = mfma32(cur.y, bb[(4 * q + 1) * 64], acc);
+            acc = mfma32(cur.z, bb[(4 * q + 2) * 64], acc);
+            acc = mfma32(cur.w, bb[(4 * q + 3) * 64], acc);
+        }
+    }
+}
+
 // acc[i] = bias of tile tile[i] (compact [nt][2][16] layout)
 template <int NC>
 __device__ __forceinline__ void load_bias(f32x16 (&acc)[NC], const float* __restrict__ b, const int (&toff)[NC], int hh) {
@@ -2003,11 +2075,10 @@ __global__ void __launch_bounds__(256, 2) mc_decode1_kernel(const LstmSeqArgs a)
             const int hh = lv >> 5;
             f32x16 acc[4];
             float c[4][4], hn[4][4];
-            unsigned wo[4];
             float4 a0[4];
-#pragma unroll
-            for (int i = 0; i < 4; ++i) wo[i] = (unsigned)lv + (unsigned)((4 * p + i) * 64);
-            wload<4>(a0, w, wo, 0u);
+            const wrsrc_t wr = make_wrsrc(w);
+            const unsigned voff = (unsigned)lv * 16u, sb = (unsigned)p * 4096u;      // tiles 4p .. 4p + 3
+            wload_buf<4>(a0, wr, voff, sb);
             // gate accumulators start from bias + W_hh . h_prefix of the day (gate_in); c from the day's state
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
@@ -2021,7 +2092,7 @@ __global__ void __launch_bounds__(256, 2) mc_decode1_kernel(const LstmSeqArgs a)
                 c[i][0] = cv.x; c[i][1] = cv.y; c[i][2] = cv.z; c[i][3] = cv.w;
             }
             const float* const bcol = col0 + lv + (size_t)bslot0 * 64;
-            gemm_stream<4>(acc, a0, w, wo, NT * 64, nq, [&](int q, float (&bv)[4]) {
+            gemm_stream_buf<4>(acc, a0, wr, voff, sb, NT * 1024u, nq, [&](int q, float (&bv)[4]) {
 #pragma unroll
                 for (int j = 0; j < 4; ++j) bv[j] = bcol[(4 * q + j) * 64];
             });
@@ -2120,12 +2191,11 @@ __global__ void __launch_bounds__(256, 2) mc_decode1_kernel(const LstmSeqArgs a)
         const float* const bcol = col0 + lv;
         f32x16 acc[4];
         bias_init(acc, ly, lv >> 5);
-        unsigned wo[4];
         float4 a0[4];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) wo[i] = (unsigned)lv + (unsigned)(i * 64);
-        wload<4>(a0, (const float4*)ly.w, wo, 0u);
-        gemm_stream<4>(acc, a0, (const float4*)ly.w, wo, 4 * 64, ly.nq, [&](int q, float (&bv)[4]) {
+        const wrsrc_t wr = make_wrsrc(ly.w);
+        const unsigned voff = (unsigned)lv * 16u;
+        wload_buf<4>(a0, wr, voff, 0u);
+        gemm_stream_buf<4>(acc, a0, wr, voff, 0u, 4 * 1024u, ly.nq, [&](int q, float (&bv)[4]) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) bv[j] = bcol[(4 * q + j) * 64];
         });

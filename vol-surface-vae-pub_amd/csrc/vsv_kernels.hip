@@ -3093,25 +3093,44 @@ __global__ void __launch_bounds__(256) percentile_wave_kernel(const float* __res
     for (int k = 2; k <= 64 * E; k <<= 1) {
 #pragma unroll
         for (int j = k >> 1; j > 0; j >>= 1) {
-            if (j < E) {
+            // min(a, b) = med3(a, b, -inf), max(a, b) = med3(a, b, +inf): where the direction depends on the lane, the
+            // third operand carries it (one register per stage) and a compare-exchange half is ONE instruction instead of
+            // min + max + select
+            if (j < E && k < E) {
                 // both elements in this lane; ascending block iff bit k of the element index is clear
 #pragma unroll
                 for (int e = 0; e < E; ++e) {
                     if ((e & j) == 0) {
                         const float lo = fminf(x[e], x[e | j]), hi = fmaxf(x[e], x[e | j]);
-                        const bool asc = (k < E) ? ((e & k) == 0) : ((lane & (k / E)) == 0);
+                        const bool asc = (e & k) == 0;
                         x[e] = asc ? lo : hi;
                         x[e | j] = asc ? hi : lo;
+                    }
+                }
+            } else if (j < E) {
+                const bool asc = (lane & (k / E)) == 0;
+                const float la = asc ? -INFINITY : INFINITY, lb = -la;
+#pragma unroll
+                for (int e = 0; e < E; ++e) {
+                    if ((e & j) == 0) {
+                        const float p = x[e], q = x[e | j];
+                        x[e] = __builtin_amdgcn_fmed3f(p, q, la);
+                        x[e | j] = __builtin_amdgcn_fmed3f(p, q, lb);
                     }
                 }
             } else {
                 const int lm = j / E;                            // partner lane = lane ^ lm, same register
                 const bool asc = (k >= 64 * E) ? true : ((lane & (k / E)) == 0);
                 const bool keep_min = asc == ((lane & lm) == 0);
+                const float lk = keep_min ? -INFINITY : INFINITY;
 #pragma unroll
                 for (int e = 0; e < E; ++e) {
-                    const float o = __shfl_xor(x[e], lm, 64);
-                    x[e] = keep_min ? fminf(x[e], o) : fmaxf(x[e], o);
+                    float o;
+                    // neighbours inside a quad of lanes come through the DPP crossbar (no LDS round trip)
+                    if (lm == 1) o = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x[e]), 0xB1, 0xF, 0xF, false));
+                    else if (lm == 2) o = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x[e]), 0x4E, 0xF, 0xF, false));
+                    else o = __shfl_xor(x[e], lm, 64);
+                    x[e] = __builtin_amdgcn_fmed3f(x[e], o, lk);
                 }
             }
         }

@@ -3433,27 +3433,29 @@ __global__ void __launch_bounds__(64 * NT) lstm_pre_kernel(const float* w, const
     load_bias<1>(bias, b, toff1, lane >> 5);
     const long i0 = (long)blockIdx.x * ipw;
     const int n_here = (int)((n_inst - i0) < (long)ipw ? (n_inst - i0) : (long)ipw);
-    // (kPreMaxQ * 64 float4s over 64 NT >= 832 threads: at most two per thread)
-    float4 pf[2];
+    // (kPreMaxQ * 64 float4s over 64 NT >= 832 threads: at most two per thread.  Two named registers, not an array:
+    // as `float4 pf[2]` indexed in an unrolled loop the pair stayed an alloca, which the compiler then placed in LDS --
+    // every fetch became load, s_waitcnt vmcnt(0), ds_write at the TOP of the iteration, exposing the load's round
+    // trip and the acknowledgement of the previous instance's sixteen stores before the products could start)
+    float4 pf0 = make_float4(0.0f, 0.0f, 0.0f, 0.0f), pf1 = pf0;
+    const int e0 = tid, e1 = tid + 64 * NT;
     auto fetch = [&](int k) {
         const float4* src = (const float4*)(x + (size_t)(i0 + k) * (size_t)x_stride);
-#pragma unroll
-        for (int u = 0; u < 2; ++u) {
-            const int e = tid + u * 64 * NT;
-            if (e < n4) pf[u] = src[e];
-        }
+        if (e0 < n4) pf0 = src[e0];
+        if (e1 < n4) pf1 = src[e1];
     };
-    auto stash = [&](int buf) {
-#pragma unroll
-        for (int u = 0; u < 2; ++u) {
-            const int e = tid + u * 64 * NT;
-            if (e < n4) ((float4*)xs[buf])[e] = pf[u];
-        }
+    auto stash = [&](int buf, int off) {
+        float4* dst = (float4*)xs[buf] + off;
+        if (e0 < n4) dst[e0] = pf0;
+        if (e1 < n4) dst[e1] = pf1;
     };
     if (n_here > 0) {
         fetch(0);
-        stash(0);
+        stash(0, 0);
     }
+    // every load so far (W_ih tile, bias, first x) has landed before the loop: with loads pending at its entry the
+    // waits for them are repeated inside every iteration, where they also cover the iteration's own prefetch
+    __builtin_amdgcn_s_waitcnt(0x0F70);                           // vmcnt(0)
     __syncthreads();
     for (int k = 0; k < n_here; ++k) {
         const size_t inst = (size_t)(i0 + k);
@@ -3473,7 +3475,10 @@ __global__ void __launch_bounds__(64 * NT) lstm_pre_kernel(const float* w, const
         float* o = gates + inst * (size_t)g_stride + (size_t)(16 * wave) * 64 + lane;
 #pragma unroll
         for (int r = 0; r < 16; ++r) o[r * 64] = acc[r];
-        if (k + 1 < n_here) stash((k + 1) & 1);                    // (that buffer's readers passed the last barrier)
+        // (the LDS copy's address is tied to the last product so that the copy stays behind the products)
+        int after = 0;                                             // a zero the compiler sees as made from acc[15]
+        asm volatile("" : "+v"(after) : "v"(acc[15]));
+        if (k + 1 < n_here) stash((k + 1) & 1, after);             // (that buffer's readers passed the last barrier)
         __syncthreads();
     }
 }

@@ -2866,19 +2866,20 @@ __global__ void __launch_bounds__(256) tileb_gemm_kernel(const TilebGemmArgs a) 
     // once by the whole workgroup, one L2 round trip instead of one per K quad in front of the quad's products
     {
         const float4* src = (const float4*)(a.g + inst * (size_t)a.g_stride);
-        const int n4 = a.nqT * 64;
-        for (int e0 = 0; e0 < n4; e0 += 16 * 256) {
-            float4 tmp[16];
+        const int n4 = a.nqT * 64;                                 // <= 64 quads (checked by the launcher): 16 per thread
+        // (straight-line code on purpose: inside a loop over e0 the sixteen registers stayed an array in scratch
+        // memory -- load, wait, scratch store sixteen times over, then scratch loads in front of the LDS writes)
+        float4 tmp[16];
 #pragma unroll
-            for (int u = 0; u < 16; ++u) {
-                const int e = e0 + u * 256 + (int)threadIdx.x;
-                if (e < n4) tmp[u] = src[e];
-            }
+        for (int u = 0; u < 16; ++u) {
+            const int e = u * 256 + (int)threadIdx.x;
+            tmp[u] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+            if (e < n4) tmp[u] = src[e];
+        }
 #pragma unroll
-            for (int u = 0; u < 16; ++u) {
-                const int e = e0 + u * 256 + (int)threadIdx.x;
-                if (e < n4) ((float4*)smem)[e] = tmp[u];
-            }
+        for (int u = 0; u < 16; ++u) {
+            const int e = u * 256 + (int)threadIdx.x;
+            if (e < n4) ((float4*)smem)[e] = tmp[u];
         }
     }
     __syncthreads();

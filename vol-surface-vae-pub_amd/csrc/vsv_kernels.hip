@@ -2257,6 +2257,50 @@ __device__ __forceinline__ void dense_bwd_layer(const DenseBwdLayer& ly, float* 
     for (int s = 16 * NT; s < kDenseSlots; ++s) col[s * 64] = 0.0f;
 }
 
+// Element-wise phase of a dense-chain backward layer for sixteen slots s0 .. s0 + 15 of tile `tile`:
+//   g = (col + add) * [forward output > 0 where the layer has a ReLU]  -> col, g_out
+// Every global load of the group is issued before the first store and none sits behind a per-value branch
+// (addresses are clamped instead, values selected afterwards): written value by value -- conditional load, use,
+// store -- the compiler emitted a load and an s_waitcnt vmcnt(0) per value, thirty-two dependent L2 round trips
+// per layer and wave.
+__device__ __forceinline__ void dense_bwd_elementwise(const DenseBwdLayer& ly, float* col, const float* act, const float* add,
+                                                      bool row_ok, float* go, int s0, int tile, int hh) {
+    float av[16], ad[16];
+    const bool has_add = ly.add != nullptr;                       // (uniform; `add` is valid for every lane: rows are clamped)
+    if (act) {
+#pragma unroll
+        for (int k = 0; k < 16; ++k) av[k] = act[(s0 + k) * 64];
+    } else {
+#pragma unroll
+        for (int k = 0; k < 16; ++k) av[k] = 1.0f;
+    }
+    if (has_add) {
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            const int f = feat_of(tile, k, hh);
+            const int fc = f < ly.add_f0 ? ly.add_f0 : (f >= ly.add_f0 + ly.add_n ? ly.add_f0 + ly.add_n - 1 : f);
+            ad[k] = add[fc];
+        }
+    } else {
+#pragma unroll
+        for (int k = 0; k < 16; ++k) ad[k] = 0.0f;
+    }
+    float g[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+        const int f = feat_of(tile, k, hh);
+        g[k] = col[(s0 + k) * 64];
+        if (has_add && row_ok && f >= ly.add_f0 && f < ly.add_f0 + ly.add_n) g[k] += ad[k];
+        if (act && f < ly.n_relu && !(av[k] > 0.0f)) g[k] = 0.0f;
+    }
+#pragma unroll
+    for (int k = 0; k < 16; ++k) col[(s0 + k) * 64] = g[k];
+    if (go) {
+#pragma unroll
+        for (int k = 0; k < 16; ++k) go[(s0 + k) * 64] = g[k];
+    }
+}
+
 __global__ void __launch_bounds__(256, 2) dense_bwd_kernel(const DenseBwdArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -2270,40 +2314,38 @@ __global__ void __launch_bounds__(256, 2) dense_bwd_kernel(const DenseBwdArgs a)
     if (!row_ok) row = a.n_rows - 1;
     float* col = smem + (size_t)wave * (kDenseSlots * 64) + lane;
     if (a.in_mode == 0) {
+        // (row and feature clamped, value selected: no load behind a per-lane branch)
         const float* src = a.in + ((size_t)row * a.T + t) * a.in_f;
-        for (int s = 0; s < kDenseSlots; ++s) {
-            const int f = feat_of(s >> 4, s & 15, hh);
-            col[s * 64] = (row_ok && f < a.in_f) ? src[f] : 0.0f;
+#pragma unroll 1
+        for (int s0 = 0; s0 < kDenseSlots; s0 += 16) {
+            float v[16];
+#pragma unroll
+            for (int k = 0; k < 16; ++k) {
+                const int f = feat_of(s0 >> 4, k, hh);
+                v[k] = src[f < a.in_f ? f : a.in_f - 1];
+            }
+#pragma unroll
+            for (int k = 0; k < 16; ++k) col[(s0 + k) * 64] = (row_ok && feat_of(s0 >> 4, k, hh) < a.in_f) ? v[k] : 0.0f;
         }
     } else {
         const float* src = a.in + (size_t)inst * kDenseSlots * 64 + lane;
-#pragma unroll 16
-        for (int s = 0; s < kDenseSlots; ++s) col[s * 64] = row_ok ? src[s * 64] : 0.0f;
+#pragma unroll 1
+        for (int s0 = 0; s0 < kDenseSlots; s0 += 16) {
+            float v[16];
+#pragma unroll
+            for (int k = 0; k < 16; ++k) v[k] = src[(s0 + k) * 64];
+#pragma unroll
+            for (int k = 0; k < 16; ++k) col[(s0 + k) * 64] = row_ok ? v[k] : 0.0f;
+        }
     }
 #pragma unroll 1
     for (int li = 0; li < a.n_layers; ++li) {
         const DenseBwdLayer& ly = a.layer[li];
         const float* act = ly.act_out ? ly.act_out + (size_t)inst * kDenseSlots * 64 + lane : nullptr;
-        const float* add = (ly.add && row_ok) ? ly.add + ((size_t)row * a.T + t) * ly.add_n - ly.add_f0 : nullptr;
+        const float* add = ly.add ? ly.add + ((size_t)row * a.T + t) * ly.add_n - ly.add_f0 : nullptr;
         float* go = ly.g_out ? ly.g_out + (size_t)inst * kDenseSlots * 64 + lane : nullptr;
-        // 16 slots at a time with the global loads of the group issued together: one at a time, each
-        // iteration waited a full memory latency (25 us per layer at two instances)
 #pragma unroll 1
-        for (int s0 = 0; s0 < kDenseSlots; s0 += 16) {
-            float av[16];
-#pragma unroll
-            for (int k = 0; k < 16; ++k) av[k] = act ? act[(s0 + k) * 64] : 1.0f;
-#pragma unroll
-            for (int k = 0; k < 16; ++k) {
-                const int s = s0 + k;
-                const int f = feat_of(s >> 4, s & 15, hh);
-                float g = col[s * 64];
-                if (add && f >= ly.add_f0 && f < ly.add_f0 + ly.add_n) g += add[f];
-                if (act && f < ly.n_relu && !(av[k] > 0.0f)) g = 0.0f;
-                col[s * 64] = g;
-                if (go) go[s * 64] = g;
-            }
-        }
+        for (int s0 = 0; s0 < kDenseSlots; s0 += 16) dense_bwd_elementwise(ly, col, act, add, row_ok, go, s0, s0 >> 4, hh);
         switch (ly.ntT) {
             case 0: break;
             case 1: dense_bwd_layer<1>(ly, col, lane); break;
@@ -2335,40 +2377,34 @@ __global__ void __launch_bounds__(256) dense_bwd_wg_kernel(const DenseBwdArgs a)
     if (!row_ok) row = a.n_rows - 1;
     float* col = smem + lane;
     const int s_lo = 16 * wave;
-    if (a.in_mode == 0) {
-        const float* src = a.in + ((size_t)row * a.T + t) * a.in_f;
+    {
+        float v[16];
+        if (a.in_mode == 0) {
+            // (row and feature clamped, value selected: no load behind a per-lane branch)
+            const float* src = a.in + ((size_t)row * a.T + t) * a.in_f;
 #pragma unroll
-        for (int k = 0; k < 16; ++k) {
-            const int f = feat_of(wave, k, hh);
-            col[(s_lo + k) * 64] = (row_ok && f < a.in_f) ? src[f] : 0.0f;
+            for (int k = 0; k < 16; ++k) {
+                const int f = feat_of(wave, k, hh);
+                v[k] = src[f < a.in_f ? f : a.in_f - 1];
+            }
+#pragma unroll
+            for (int k = 0; k < 16; ++k) col[(s_lo + k) * 64] = (row_ok && feat_of(wave, k, hh) < a.in_f) ? v[k] : 0.0f;
+        } else {
+            const float* src = a.in + (size_t)inst * kDenseSlots * 64 + lane;
+#pragma unroll
+            for (int k = 0; k < 16; ++k) v[k] = src[(s_lo + k) * 64];
+#pragma unroll
+            for (int k = 0; k < 16; ++k) col[(s_lo + k) * 64] = row_ok ? v[k] : 0.0f;
         }
-    } else {
-        const float* src = a.in + (size_t)inst * kDenseSlots * 64 + lane;
-#pragma unroll
-        for (int k = 0; k < 16; ++k) col[(s_lo + k) * 64] = row_ok ? src[(s_lo + k) * 64] : 0.0f;
     }
 #pragma unroll 1
     for (int li = 0; li < a.n_layers; ++li) {
         const DenseBwdLayer& ly = a.layer[li];
         const float* act = ly.act_out ? ly.act_out + (size_t)inst * kDenseSlots * 64 + lane : nullptr;
-        const float* add = (ly.add && row_ok) ? ly.add + ((size_t)row * a.T + t) * ly.add_n - ly.add_f0 : nullptr;
+        const float* add = ly.add ? ly.add + ((size_t)row * a.T + t) * ly.add_n - ly.add_f0 : nullptr;
         float* go = ly.g_out ? ly.g_out + (size_t)inst * kDenseSlots * 64 + lane : nullptr;
-        {
-            // this wave's sixteen slots (it wrote them itself: no barrier needed before)
-            float av[16];
-#pragma unroll
-            for (int k = 0; k < 16; ++k) av[k] = act ? act[(s_lo + k) * 64] : 1.0f;
-#pragma unroll
-            for (int k = 0; k < 16; ++k) {
-                const int s = s_lo + k;
-                const int f = feat_of(wave, k, hh);
-                float g = col[s * 64];
-                if (add && f >= ly.add_f0 && f < ly.add_f0 + ly.add_n) g += add[f];
-                if (act && f < ly.n_relu && !(av[k] > 0.0f)) g = 0.0f;
-                col[s * 64] = g;
-                if (go) go[s * 64] = g;
-            }
-        }
+        // this wave's sixteen slots (it wrote them itself: no barrier needed before)
+        dense_bwd_elementwise(ly, col, act, add, row_ok, go, s_lo, wave, hh);
         if (ly.ntT > 0) {                                          // (block-uniform)
             __syncthreads();                                       // g complete
             f32x16 acc[1];
@@ -4637,6 +4673,10 @@ extern "C" int vsv_dense_backward(const vsv_dense_bwd* d, void* stream) {
     if (!d || !d->in) { set_error("vsv_dense_backward: null pointer"); return -1; }
     if (d->n_layers < 1 || d->n_layers > VSV_MAX_CHAIN) { set_error("vsv_dense_backward: 1..%d layers", VSV_MAX_CHAIN); return -1; }
     if (d->n_rows < 1 || d->T < 1 || d->n_rowtiles != (d->n_rows + 31) / 32) { set_error("vsv_dense_backward: bad sizes"); return -1; }
+    // (the kernels clamp feature indices into [0, in_f) and [add_f0, add_f0 + add_n) instead of branching around loads)
+    if (d->in_mode == 0 && d->in_f < 1) { set_error("vsv_dense_backward: in_f must be >= 1"); return -1; }
+    for (int i = 0; i < d->n_layers; ++i)
+        if (d->layer[i].add && d->layer[i].add_n < 1) { set_error("vsv_dense_backward: layer %d adds an empty range", i); return -1; }
     for (int i = 0; i < d->n_layers; ++i) {
         const vsv_dense_bwd_layer& ly = d->layer[i];
         if (ly.ntT < 0 || ly.ntT > kHeadTiles || (ly.ntT > 0 && (!ly.wT || ly.nqT < 1 || ly.nqT > 4 * kHeadTiles))) {

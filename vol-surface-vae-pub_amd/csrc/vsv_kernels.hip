@@ -529,12 +529,24 @@ __device__ __forceinline__ void dense_epilogue(const DenseChainArgs& a, const Ro
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[tt][r] = (feat_of(tt, r, hh) < n_relu) ? fmaxf(acc[tt][r], 0.0f) : acc[tt][r];
     const bool do_inj = (li == a.inj_layer) && io.inj != nullptr, do_aux = (li == a.aux_layer) && io.aux != nullptr;
-    if (do_inj || do_aux) {
+    if (do_inj) {
+        float iv[16];                                              // (clamped addresses: the loads go out together)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int f = feat_of(NT - 1, r, hh);
-            if (do_inj && f >= a.inj_f0 && f < a.inj_f0 + a.inj_n) acc[NT - 1][r] = io.inj[f];
-            if (do_aux && f >= a.aux_f0 && f < a.aux_f0 + a.aux_n) io.aux[f] = acc[NT - 1][r];
+            iv[r] = io.inj[f < a.inj_f0 ? a.inj_f0 : (f >= a.inj_f0 + a.inj_n ? a.inj_f0 + a.inj_n - 1 : f)];
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int f = feat_of(NT - 1, r, hh);
+            if (f >= a.inj_f0 && f < a.inj_f0 + a.inj_n) acc[NT - 1][r] = iv[r];
+        }
+    }
+    if (do_aux) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int f = feat_of(NT - 1, r, hh);
+            if (f >= a.aux_f0 && f < a.aux_f0 + a.aux_n) io.aux[f] = acc[NT - 1][r];
         }
     }
 }
@@ -603,22 +615,48 @@ __global__ void __launch_bounds__(256, 2) dense_chain_kernel(const DenseChainArg
     if (!row_ok) row = a.n_rows - 1;
     float* col = smem + (size_t)wave * (kDenseSlots * 64) + lane;
 
+    // input column, sixteen k-steps at a time: the group's loads are issued together from clamped addresses and the
+    // values selected afterwards (one conditional load per k-step meant one exposed L2 round trip per k-step)
     if (a.in_mode == 0) {
         const float* src = a.in + row * a.in_rs + (long)t * a.in_ts;
-        for (int s = 0; s < a.in_ks; ++s) {
-            const int f = 2 * s + hh;
-            col[s * 64] = (f < a.in_f) ? src[f] : 0.0f;
+#pragma unroll 1
+        for (int s0 = 0; s0 < kDenseSlots; s0 += 16) {
+            if (s0 < a.in_ks) {
+                float v[16];
+#pragma unroll
+                for (int k = 0; k < 16; ++k) {
+                    const int f = 2 * (s0 + k) + hh;
+                    v[k] = src[f < a.in_f ? f : a.in_f - 1];
+                }
+#pragma unroll
+                for (int k = 0; k < 16; ++k)
+                    col[(s0 + k) * 64] = (s0 + k < a.in_ks && 2 * (s0 + k) + hh < a.in_f) ? v[k] : 0.0f;
+            } else {
+#pragma unroll
+                for (int k = 0; k < 16; ++k) col[(s0 + k) * 64] = 0.0f;
+            }
         }
-        for (int s = a.in_ks; s < kDenseSlots; ++s) col[s * 64] = 0.0f;
     } else {
         const float* src = a.in + (size_t)inst * a.in_ks * 64 + lane;
-        for (int s = 0; s < a.in_ks; ++s) col[s * 64] = src[s * 64];
-        for (int s = a.in_ks; s < kDenseSlots; ++s) col[s * 64] = 0.0f;
+#pragma unroll 1
+        for (int s0 = 0; s0 < kDenseSlots; s0 += 16) {
+            if (s0 < a.in_ks) {
+                float v[16];
+#pragma unroll
+                for (int k = 0; k < 16; ++k) v[k] = src[(s0 + k < a.in_ks ? s0 + k : a.in_ks - 1) * 64];
+#pragma unroll
+                for (int k = 0; k < 16; ++k) col[(s0 + k) * 64] = (s0 + k < a.in_ks) ? v[k] : 0.0f;
+            } else {
+#pragma unroll
+                for (int k = 0; k < 16; ++k) col[(s0 + k) * 64] = 0.0f;
+            }
+        }
     }
 #pragma unroll 1
     for (int li = 0; li < a.n_layers; ++li) {
         if (a.save) {
             float* sv = a.save + ((size_t)li * (a.n_rowtiles * a.T) + inst) * kDenseSlots * 64 + lane;
+#pragma unroll 16
             for (int s = 0; s < kDenseSlots; ++s) sv[s * 64] = col[s * 64];
         }
         const DenseLayerArg ly = chain_layer_of_kernarg(li);
@@ -647,17 +685,26 @@ __global__ void __launch_bounds__(256) dense_chain_wg_kernel(const DenseChainArg
     if (!row_ok) row = a.n_rows - 1;
     float* col = smem + lane;
     const int s_lo = 16 * wave;
-    if (a.in_mode == 0) {
-        const float* src = a.in + row * a.in_rs + (long)t * a.in_ts;
+    {
+        // (loads from clamped addresses, values selected afterwards: see dense_chain_kernel)
+        float v[16];
+        if (a.in_mode == 0) {
+            const float* src = a.in + row * a.in_rs + (long)t * a.in_ts;
 #pragma unroll
-        for (int k = 0; k < 16; ++k) {
-            const int sl = s_lo + k, f = 2 * sl + hh;
-            col[sl * 64] = (sl < a.in_ks && f < a.in_f) ? src[f] : 0.0f;
+            for (int k = 0; k < 16; ++k) {
+                const int f = 2 * (s_lo + k) + hh;
+                v[k] = src[f < a.in_f ? f : a.in_f - 1];
+            }
+#pragma unroll
+            for (int k = 0; k < 16; ++k)
+                col[(s_lo + k) * 64] = (s_lo + k < a.in_ks && 2 * (s_lo + k) + hh < a.in_f) ? v[k] : 0.0f;
+        } else {
+            const float* src = a.in + (size_t)inst * a.in_ks * 64 + lane;
+#pragma unroll
+            for (int k = 0; k < 16; ++k) v[k] = src[(s_lo + k < a.in_ks ? s_lo + k : a.in_ks - 1) * 64];
+#pragma unroll
+            for (int k = 0; k < 16; ++k) col[(s_lo + k) * 64] = (s_lo + k < a.in_ks) ? v[k] : 0.0f;
         }
-    } else {
-        const float* src = a.in + (size_t)inst * a.in_ks * 64 + lane;
-#pragma unroll
-        for (int k = 0; k < 16; ++k) col[(s_lo + k) * 64] = (s_lo + k < a.in_ks) ? src[(s_lo + k) * 64] : 0.0f;
     }
     __syncthreads();
 #pragma unroll 1
@@ -685,12 +732,24 @@ __global__ void __launch_bounds__(256) dense_chain_wg_kernel(const DenseChainArg
             if ((last && a.out_mode != 0) || (li == a.inj_layer && a.inj != nullptr) || li == a.aux_layer)
                 io = make_rowio(a, row, row_ok, t);
             const bool do_inj = (li == a.inj_layer) && io.inj != nullptr, do_aux = (li == a.aux_layer) && io.aux != nullptr;
-            if ((do_inj || do_aux) && wave == ly.nt - 1) {
+            if (do_inj && wave == ly.nt - 1) {
+                float iv[16];                                      // (clamped addresses: the loads go out together)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int f = feat_of(wave, r, hh);
-                    if (do_inj && f >= a.inj_f0 && f < a.inj_f0 + a.inj_n) acc[0][r] = io.inj[f];
-                    if (do_aux && f >= a.aux_f0 && f < a.aux_f0 + a.aux_n) io.aux[f] = acc[0][r];
+                    iv[r] = io.inj[f < a.inj_f0 ? a.inj_f0 : (f >= a.inj_f0 + a.inj_n ? a.inj_f0 + a.inj_n - 1 : f)];
+                }
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int f = feat_of(wave, r, hh);
+                    if (f >= a.inj_f0 && f < a.inj_f0 + a.inj_n) acc[0][r] = iv[r];
+                }
+            }
+            if (do_aux && wave == ly.nt - 1) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int f = feat_of(wave, r, hh);
+                    if (f >= a.aux_f0 && f < a.aux_f0 + a.aux_n) io.aux[f] = acc[0][r];
                 }
             }
             if (last) {
@@ -3311,6 +3370,10 @@ static int launch_dense_chain(const DenseChainArgs& a, hipStream_t st) {
         }
     }
     if (a.in_ks > kDenseSlots) { set_error("dense_chain: input wider than %d k-steps", kDenseSlots); return -4; }
+    // (the kernels clamp indices into these ranges instead of branching around loads)
+    if (a.in_ks < 1 || (a.in_mode == 0 && a.in_f < 1) || (a.inj != nullptr && a.inj_n < 1)) {
+        set_error("dense_chain: empty input (in_ks %d, in_f %d) or injection range (%d)", a.in_ks, a.in_f, a.inj_n); return -1;
+    }
     const size_t lds = (size_t)4 * kDenseSlots * 64 * sizeof(float);
     const long blocks = (insts + 3) / 4;
     if (blocks > 0x7fffffffL) { set_error("dense_chain: too many tiles"); return -2; }

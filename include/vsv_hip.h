@@ -361,7 +361,9 @@ int vsv_train_decode(const vsv_dims *dims, const float *packed, const vsv_decode
  * layer per entry, LAST forward layer first.  Per layer: g = (incoming + add) masked by the
  * forward output's ReLU -> g_out (tile-B, slot order; dW = g^T . layer input); then
  * incoming = W^T . g through the transposed fragments wT (built by the caller from the
- * packed blob; their output order is the previous layer's slot order). */
+ * packed blob; their output order is the previous layer's slot order).  in_mode 0 needs in_f >= 1 and
+ * a layer with `add` needs add_n >= 1 (error -1 otherwise: the kernels clamp feature indices into those
+ * ranges instead of branching around each load). */
 typedef struct vsv_dense_bwd_layer {
     const float *wT; int nqT, ntT;          /* ntT = 0: stop, no input gradient wanted */
     const float *act_out; int n_relu;       /* forward output of the layer (tile-B [inst][64][64]) or NULL */

@@ -133,8 +133,10 @@ def test_percentile_matches_numpy():
     cfg = vo.make_config(5, 0)
     eng, _ = _engine(cfg, 0, 1.0)
     rng = np.random.default_rng(1)
-    # S <= 1024: wavefront-level register sort (every lane-count class and its edges); above: LDS sort
-    for S in (1000, 10000, 37, 1, 2, 3, 63, 64, 65, 128, 200, 256, 300, 512, 513, 1023, 1024, 1025, 2048):
+    # S <= 1024: wavefront-level register sort (every lane-count class and its edges); above: workgroup-level
+    # register sort on 1, 2, 4 or 8 waves (2048 elements each) with its edges and lengths that are not multiples of 4
+    for S in (1000, 10000, 37, 1, 2, 3, 63, 64, 65, 128, 200, 256, 300, 512, 513, 1023, 1024, 1025, 2048,
+              2049, 3001, 4096, 4097, 7777, 8192, 8193, 12345, 16383, 16384):
         x = rng.standard_normal((4, 25, S)).astype(np.float32)
         got = _n(eng.percentile(_t(x), (5, 50, 95), inner=25))          # (4, 3, 25)
         want = np.percentile(x.astype(np.float64), [5, 50, 95], axis=-1).transpose(1, 0, 2)
@@ -153,6 +155,13 @@ def test_percentile_matches_numpy():
             got = _n(eng.percentile(_t(x).view(6, 75, S), (5, 50, 95), inner=25, channel=ch, n_channels=3))
             want = np.percentile(x[:, ch].astype(np.float64), [5, 50, 95], axis=-1).transpose(1, 0, 2)
             assert got.shape == want.shape and err(got, want) <= 1e-6, (S, ch)
+    # the extremes and ties on the workgroup-level kernel
+    x = rng.standard_normal((2, 25, 9000)).astype(np.float32)
+    x[..., 4000:4600] = x[..., :1]
+    qs = (0, 0.01, 50, 99.99, 100)
+    got = _n(eng.percentile(_t(x), qs, inner=25))
+    want = np.percentile(x.astype(np.float64), list(qs), axis=-1).transpose(1, 0, 2)
+    assert err(got, want) <= 1e-6
     # other percentile sets, including the extremes
     x = rng.standard_normal((2, 25, 777)).astype(np.float32)
     qs = (0, 1, 25, 33.3, 75, 99, 100)

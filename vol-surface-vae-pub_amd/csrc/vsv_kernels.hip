@@ -3251,6 +3251,110 @@ __global__ void __launch_bounds__(256) percentile_wave_kernel(const float* __res
     if (lane < pa.nq) out[(size_t)(v / inner) * pa.nq * inner + (size_t)lane * inner + (v % inner)] = res;
 }
 
+// Workgroup-level selection for 1024 < S <= 16384 (the autoregressive stress case reduces 10 000 rollouts): the
+// same bitonic network as percentile_wave_kernel over P2 = 2048 W elements (W = 1, 2, 4 or 8 waves of one
+// workgroup, 32 registers per lane; element index = (wave * 64 + lane) * 32 + register).  Compare-exchanges at
+// distance < 32 are register-to-register, below 2048 one cross-lane exchange (DPP / ds_bpermute), and only the
+// 1 + 2 + 3 stages at distance >= 2048 go through LDS (partner = same lane and register of wave w ^ d): 6 of the 105
+// stages instead of all of them (percentile_kernel: 105 stages of LDS traffic with a barrier each).  A
+// compare-exchange half is one v_med3_f32 whose third operand (-inf / +inf) carries the direction.
+constexpr int kPwgE = 32;
+__global__ void __launch_bounds__(512) percentile_wg_kernel(const float* __restrict__ in, long n_vec, int S, int W, PercArgs pa,
+                                                            int inner, long group_stride, float* __restrict__ out) {
+    extern __shared__ __attribute__((aligned(16))) float buf[];   // [wave][register][lane]: W * 2048 floats
+    constexpr int E = kPwgE;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const long v = (long)blockIdx.x;
+    const float* src = in + ((size_t)(v / inner) * group_stride + (size_t)(v % inner)) * S;
+    const int i0 = (wave * 64 + lane) * E;
+    float x[E];
+    if ((S & 3) == 0) {
+#pragma unroll
+        for (int e = 0; e < E; e += 4) {
+            float4 q = make_float4(INFINITY, INFINITY, INFINITY, INFINITY);
+            if (i0 + e < S) q = *(const float4*)(src + i0 + e);
+            x[e] = q.x; x[e + 1] = q.y; x[e + 2] = q.z; x[e + 3] = q.w;
+        }
+    } else {
+#pragma unroll
+        for (int e = 0; e < E; ++e) x[e] = (i0 + e < S) ? src[i0 + e] : INFINITY;
+    }
+    const int P2 = 64 * E * W;
+    float* const mine = buf + (size_t)wave * (E * 64) + lane;
+#pragma unroll
+    for (int k = 2; k <= 64 * E * 8; k <<= 1) {
+        if (k <= P2) {                                             // (uniform)
+            // ascending block iff bit k of the element index is clear; the last merge (k == P2) is ascending everywhere
+            const bool asc = (k == P2) ? true
+                           : (k < E) ? true /* per register, below */
+                           : (k < 64 * E) ? ((lane & (k / E)) == 0) : ((wave & (k / (64 * E))) == 0);
+#pragma unroll
+            for (int j = k >> 1; j > 0; j >>= 1) {
+                if (j >= 64 * E) {
+                    // partner: the same lane and register of wave ^ (j / 2048), through LDS
+                    const int wm = j / (64 * E);
+                    const bool keep_min = asc == ((wave & wm) == 0);
+                    const float lk = keep_min ? -INFINITY : INFINITY;
+                    __syncthreads();                               // (the previous exchange's readers are done)
+#pragma unroll
+                    for (int e = 0; e < E; ++e) mine[e * 64] = x[e];
+                    __syncthreads();
+                    const float* theirs = buf + (size_t)(wave ^ wm) * (E * 64) + lane;
+#pragma unroll
+                    for (int e = 0; e < E; ++e) x[e] = __builtin_amdgcn_fmed3f(x[e], theirs[e * 64], lk);
+                } else if (j >= E) {
+                    const int lm = j / E;                          // partner lane = lane ^ lm, same register
+                    const bool keep_min = asc == ((lane & lm) == 0);
+                    const float lk = keep_min ? -INFINITY : INFINITY;
+#pragma unroll
+                    for (int e = 0; e < E; ++e) {
+                        float o;
+                        if (lm == 1) o = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x[e]), 0xB1, 0xF, 0xF, false));
+                        else if (lm == 2) o = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x[e]), 0x4E, 0xF, 0xF, false));
+                        else o = __shfl_xor(x[e], lm, 64);
+                        x[e] = __builtin_amdgcn_fmed3f(x[e], o, lk);
+                    }
+                } else if (k < E) {
+#pragma unroll
+                    for (int e = 0; e < E; ++e) {
+                        if ((e & j) == 0) {
+                            const float lo = fminf(x[e], x[e | j]), hi = fmaxf(x[e], x[e | j]);
+                            const bool up = (k == P2) || (e & k) == 0;
+                            x[e] = up ? lo : hi;
+                            x[e | j] = up ? hi : lo;
+                        }
+                    }
+                } else {
+                    const float la = asc ? -INFINITY : INFINITY, lb = -la;
+#pragma unroll
+                    for (int e = 0; e < E; ++e) {
+                        if ((e & j) == 0) {
+                            const float p = x[e], q = x[e | j];
+                            x[e] = __builtin_amdgcn_fmed3f(p, q, la);
+                            x[e | j] = __builtin_amdgcn_fmed3f(p, q, lb);
+                        }
+                    }
+                }
+            }
+        }
+    }
+    // sorted element i lives in wave i / 2048, lane (i / 32) % 64, register i % 32: everything goes to LDS once and
+    // thread k picks the two order statistics of percentile k
+    __syncthreads();
+#pragma unroll
+    for (int e = 0; e < E; ++e) mine[e * 64] = x[e];
+    __syncthreads();
+    if ((int)threadIdx.x < pa.nq) {
+        const int k = threadIdx.x;
+        const int lo = pa.lo[k];
+        const int hi = (lo + 1 < S) ? lo + 1 : S - 1;
+        auto at = [&](int i) { return buf[(size_t)(i / (64 * E)) * (E * 64) + (size_t)(i % E) * 64 + (i / E) % 64]; };
+        const float a = at(lo), b = at(hi), d = b - a, fr = pa.fr[k];
+        const float r = (fr >= 0.5f) ? b - d * (1.0f - fr) : a + d * fr;
+        out[(size_t)(v / inner) * pa.nq * inner + (size_t)k * inner + (v % inner)] = r;
+    }
+}
+
 __global__ void __launch_bounds__(256) philox_normal_kernel(uint64_t seed, long day0, long S, int step0, int n_steps,
                                                             int L, long n_total, float* __restrict__ out) {
     const long i = (long)blockIdx.x * 256 + threadIdx.x;
@@ -4520,6 +4624,17 @@ extern "C" int vsv_percentile(const float* in, long n_vec, int S, const double* 
     }
     int P2 = 2;
     while (P2 < S) P2 <<= 1;
+    static const bool wg_off = [] { const char* e = getenv("VSV_PERCENTILE_WG"); return e && e[0] == '0'; }();
+    if (!wg_off && n_vec <= 0x7fffffffL) {
+        // workgroup-level selection: P2 / 2048 waves per vector, sorted in registers, six LDS exchanges at most
+        const int W = P2 / (64 * kPwgE);
+        const size_t ldsw = (size_t)P2 * sizeof(float);
+        if (int rcw = set_lds(percentile_wg_kernel, ldsw)) return rcw;
+        if (n_vec > 0)
+            hipLaunchKernelGGL(percentile_wg_kernel, dim3((unsigned)n_vec), dim3(64 * W), ldsw, st, in, n_vec, S, W, pa, inner,
+                               group_stride, out);
+        return launch_check("percentile_wg_kernel");
+    }
     const size_t lds = (size_t)P2 * sizeof(float);
     int rc = set_lds(percentile_kernel, lds);
     if (rc) return rc;

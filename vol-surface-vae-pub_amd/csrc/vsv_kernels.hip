@@ -335,6 +335,31 @@ __device__ __forceinline__ void tile_mfma_band_buf(f32x16& acc, float4 (&a)[kHal
     }
 }
 
+// A banded tile with ALL of its K quads requested up front (mc_decode1_kernel; a band has at most NQ = 16 quads):
+// the refill scheme above keeps eight quads in flight and re-requests a register when its quad has been multiplied,
+// but a refill under a scalar branch makes the compiler load into a spare tuple, wait for it with vmcnt(0) after
+// the quad's four products and copy it over -- every refill exposed most of an L2 round trip.  Here the loads are
+// unconditional (quads past the band re-request its last quad: the compiler can count them, so the products wait
+// quad by quad with vmcnt(15), vmcnt(14), ...) and only the products are guarded.
+template <int NQ>
+__device__ __forceinline__ void tile_band_all_buf(f32x16& acc, wrsrc_t r, unsigned voff, unsigned sbase, unsigned qsb,
+                                                  const float* b, int q0, int nqb) {
+    const unsigned sb = sbase + (unsigned)q0 * qsb;
+    const float* bb = b + (size_t)q0 * 4 * 64;
+    float4 a[NQ];
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) a[q] = bload(r, voff, sb + (unsigned)(q < nqb ? q : nqb - 1) * qsb);
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+        if (q < nqb) {
+            acc = mfma32(a[q].x, bb[(4 * q + 0) * 64], acc);
+            acc = mfma32(a[q].y, bb[(4 * q + 1) * 64], acc);
+            acc = mfma32(a[q].z, bb[(4 * q + 2) * 64], acc);
+            acc = mfma32(a[q].w, bb[(4 * q + 3) * 64], acc);
+        }
+    }
+}
+
 // acc[i] = bias of tile tile[i] (compact [nt][2][16] layout)
 template <int NC>
 __device__ __forceinline__ void load_bias(f32x16 (&acc)[NC], const float* __restrict__ b, const int (&toff)[NC], int hh) {
@@ -2272,13 +2297,13 @@ __global__ void __launch_bounds__(256, 2) mc_decode1_kernel(const LstmSeqArgs a)
         const float* const bcol = col0 + lv;
         f32x16 acc[4];
         bias_init(acc, ly, lv >> 5);
-        float4 wq[kHalfQ];
+        const wrsrc_t wr = make_wrsrc(ly.w);
+        const unsigned voff = (unsigned)lv * 16u;
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
             if (t < ly.nt) {
                 const int q0 = pick4(ly.q0, t), nqb = pick4(ly.nqb, t);
-                tile_load_band(wq, (const float4*)ly.w, t * 64 + lv, ly.nt * 64, q0, nqb);
-                tile_mfma_band<4 * kHeadTiles>(acc[t], wq, (const float4*)ly.w, t * 64 + lv, ly.nt * 64, bcol, q0, nqb);
+                tile_band_all_buf<4 * kHeadTiles>(acc[t], wr, voff, t * 1024u, (unsigned)ly.nt * 1024u, bcol, q0, nqb);
             }
         }
         MC1_STAMP(18 + 2 * li);

@@ -252,9 +252,14 @@ __device__ __forceinline__ void tile_mfma_band(f32x16& acc, float4 (&a)[kHalfQ],
     const float* bb = b + (size_t)q0 * 4 * 64;
 #pragma unroll
     for (int q = 0; q < NQ; ++q) {
+        const float4 cur = a[q % kHalfQ];
+        // (the refill is unconditional and clamped to the band's last quad: under the scalar branch it was loaded
+        // into a spare tuple, waited for with vmcnt(0) right after the quad's products and copied over)
+        if (q + kHalfQ < NQ) {
+            const int qn = (q + kHalfQ < nqb) ? q + kHalfQ : nqb - 1;
+            a[q % kHalfQ] = wb[off + (unsigned)(qn * qstride)];
+        }
         if (q < nqb) {
-            const float4 cur = a[q % kHalfQ];
-            if (q + kHalfQ < nqb) a[q % kHalfQ] = wb[off + (unsigned)((q + kHalfQ) * qstride)];
             acc = mfma32(cur.x, bb[(4 * q + 0) * 64], acc);
             acc = mfma32(cur.y, bb[(4 * q + 1) * 64], acc);
             acc = mfma32(cur.z, bb[(4 * q + 2) * 64], acc);

@@ -45,9 +45,19 @@ __device__ unsigned long long g_stamps[(size_t)kStampWgs * 4 * 32];
             g_stamps[((size_t)blockIdx.x * 4 + wave) * 32 + (i)] = __builtin_amdgcn_s_memtime();               \
         __builtin_amdgcn_sched_barrier(0);                                                                    \
     } while (0)
+// (dec_seq_kernel, tools/stamps_dseq.py: the phases of time step 1 -- 0 start, 1 + 2s / 2 + 2s GEMM / cell of pass s,
+// 17 columns written, 18 + 2li / 19 + 2li matrix part / epilogue of head layer li, 26 end of step)
+#define DSQ_STAMP(i)                                                                                          \
+    do {                                                                                                      \
+        __builtin_amdgcn_sched_barrier(0);                                                                    \
+        if (dsq_t == 1 && lane == 0 && blockIdx.x < kStampWgs)                                                \
+            g_stamps[((size_t)blockIdx.x * 4 + wave) * 32 + (i)] = __builtin_amdgcn_s_memtime();               \
+        __builtin_amdgcn_sched_barrier(0);                                                                    \
+    } while (0)
 #else
 #define VSV_STAMP(i) do {} while (0)
 #define MC1_STAMP(i) do {} while (0)
+#define DSQ_STAMP(i) do {} while (0)
 #endif
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -317,6 +327,47 @@ __device__ __forceinline__ void gemm_stream_buf(f32x16 (&acc)[NC], float4 (&a0)[
     }
     if (q < nq) mfma_quad<NC>(acc, a0, b0);
 }
+// gemm_stream_buf for ONE wave per SIMD (dec_seq_kernel): nobody else fills the gap between two quads of products,
+// where the fenced form issues the next quad's four fragment loads and LDS reads back to back (~100 of a quad's 1024
+// cycles).  Here they go out one by one in the shadow of the quad's first products (memory and LDS instructions issue
+// while a product executes; vector instructions do not).
+template <int NC, typename BL>
+__device__ __forceinline__ void gemm_stream_buf1(f32x16 (&acc)[NC], float4 (&a0)[NC], wrsrc_t r, unsigned voff, unsigned sbase,
+                                                 unsigned qsb, int nq, BL bl) {
+    static_assert(NC == 4, "interleave pattern written for four tiles");
+    float4 a1[NC];
+    float b0[4], b1[4];
+    bl(0, b0);
+    auto pattern = [] {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);    // one product
+            __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);    // one fragment load
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);    // one LDS read
+        }
+        __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);
+    };
+    int q = 0;
+#pragma unroll 1
+    for (; q + 1 < nq; q += 2) {
+        wload_buf<NC>(a1, r, voff, sbase + (unsigned)(q + 1) * qsb);
+        bl(q + 1, b1);
+        mfma_quad<NC>(acc, a0, b0);
+        pattern();
+        __builtin_amdgcn_sched_barrier(0);
+        const int q2 = (q + 2 < nq) ? q + 2 : q + 1;
+        wload_buf<NC>(a0, r, voff, sbase + (unsigned)q2 * qsb);
+        bl(q2, b0);
+        mfma_quad<NC>(acc, a1, b1);
+        pattern();
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    if (q < nq) mfma_quad<NC>(acc, a0, b0);
+}
 __device__ __forceinline__ void tile_load_band_buf(float4 (&a)[kHalfQ], wrsrc_t r, unsigned voff, unsigned sbase, unsigned qsb,
                                                    int q0, int nqb) {
 #pragma unroll
@@ -363,6 +414,54 @@ __device__ __forceinline__ void tile_band_all_buf(f32x16& acc, wrsrc_t r, unsign
             acc = mfma32(a[q].w, bb[(4 * q + 3) * 64], acc);
         }
     }
+}
+
+// The two halves of tile_band_all_buf, for callers that request a tile's fragments while the tile before it is
+// multiplied (dec_seq_kernel: one wave per SIMD, nobody else covers the fetch)
+template <int NQ>
+__device__ __forceinline__ void band_load_all(float4 (&a)[NQ], wrsrc_t r, unsigned voff, unsigned sbase, unsigned qsb, int q0,
+                                              int nqb) {
+    const unsigned sb = sbase + (unsigned)q0 * qsb;
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) a[q] = bload(r, voff, sb + (unsigned)(q < nqb ? q : nqb - 1) * qsb);
+}
+// (the B values of quad q + 1 are read from LDS -- unconditionally, clamped to the band -- in front of quad q's
+// products: read inside the band's scalar guards they were waited for quad by quad)
+template <int NQ>
+__device__ __forceinline__ void band_mfma_all(f32x16& acc, const float4 (&a)[NQ], const float* b, int q0, int nqb) {
+    const float* bb = b + (size_t)q0 * 4 * 64;
+    float bv[2][4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) bv[0][j] = bb[j * 64];
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+        if (q + 1 < NQ) {
+            const int qn = (q + 1 < nqb) ? q + 1 : nqb - 1;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) bv[(q + 1) & 1][j] = bb[(4 * qn + j) * 64];
+        }
+        if (q < nqb) {
+            acc = mfma32(a[q].x, bv[q & 1][0], acc);
+            acc = mfma32(a[q].y, bv[q & 1][1], acc);
+            acc = mfma32(a[q].z, bv[q & 1][2], acc);
+            acc = mfma32(a[q].w, bv[q & 1][3], acc);
+        }
+    }
+}
+
+// The bias of output tile `tile` (compact [nt][2][16] layout) as an A fragment: lane l < 32 holds the bias of tile row l,
+// the upper lanes zero.  One product with a B operand of ones turns it into the tile's initial accumulator, exactly
+// (0 + b * 1): one register per lane and tile to fetch ahead instead of sixteen (dec_seq_kernel).
+__device__ __forceinline__ float bias_frag(const float* __restrict__ b, int tile, int lane) {
+    const int i = lane & 31;
+    const float v = b[tile * 32 + ((i >> 2) & 1) * 16 + 4 * (i >> 3) + (i & 3)];
+    return lane < 32 ? v : 0.0f;
+}
+__device__ __forceinline__ f32x16 bias_acc(float bf) {
+    f32x16 z;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) z[r] = 0.0f;
+    return mfma32(bf, 1.0f, z);
 }
 
 // acc[i] = bias of tile tile[i] (compact [nt][2][16] layout)
@@ -2314,6 +2413,381 @@ __global__ void __launch_bounds__(256, 2) mc_decode1_kernel(const LstmSeqArgs a)
         MC1_STAMP(18 + 2 * li);
         epilogue(acc, ly, li, lv);
         MC1_STAMP(19 + 2 * li);
+    }
+}
+
+// ---------------------------------------------------------------------------
+// dec_seq_kernel (round 3): the decoder over T steps for MANY rows -- horizon > 1 prior draws, the oracle
+// (posterior) decode of all C + H positions, the C + 1 steps of an autoregressive rollout step -- on
+// mc_decode1_kernel's schedule: ONE WAVE per 32-row tile runs both memory layers (16 gate tiles in four passes
+// of four), the step's input assembly (context embedding, z = base + scale * Philox / injected eps) and the
+// head, with no workgroup barrier.  What a sequence adds to the one-day draw is state: the cell state of both
+// layers (2 x 16 x 4 = 128 registers per lane) stays in REGISTERS for the whole time loop, so the kernel runs
+// one wave per SIMD on the 512-register budget (the fp32 matrix and vector instructions of a SIMD's two waves
+// serialise anyway, DESIGN.md "The bound that is left"); h of both layers lives in the wave's own LDS columns
+// (x: kx slots, h0 and h1: 64 slots each; 35 KB per wave at kx = 12), a layer's new h is held in registers
+// until the last pass has read the old one, and the head runs from those registers without touching LDS (a
+// layer's accumulators are the next layer's B operands as they stand).  Same products in the same k order as
+// lstm_kernel: results are bit-equal.
+// ---------------------------------------------------------------------------
+// One banded head tile of dec_seq_kernel: the chain of its K quads on one accumulator, the B operands taken straight
+// from REGISTERS (the D layout of a layer is the B layout of the next: k-step 16 t + r of a layer's input is register r
+// of the previous layer's tile t), indexed by the ABSOLUTE quad, so that the index is static; the band is a bit mask
+// (bit q set: quad q is multiplied) tested by scalar guards.  The NEXT tile's fragments are requested quad by quad from
+// inside the chain (a fetch issues in the shadow of the product before it; in front of the chain sixteen fetches cost
+// ~1000 cycles of a lone wave's time), unconditionally, all sixteen quads of its K range.
+template <int NQ>
+__device__ __forceinline__ void band_tile_reg(f32x16& acc, const float4 (&cur)[NQ], float4 (&nxt)[NQ], wrsrc_t rn, unsigned voff,
+                                              unsigned sbn, unsigned qsbn, const float (&b)[4 * NQ], unsigned qmask) {
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+        nxt[q] = bload(rn, voff, sbn + (unsigned)q * qsbn);
+        if ((qmask >> q) & 1u) {
+            acc = mfma32(cur[q].x, b[4 * q + 0], acc);
+            acc = mfma32(cur[q].y, b[4 * q + 1], acc);
+            acc = mfma32(cur[q].z, b[4 * q + 2], acc);
+            acc = mfma32(cur[q].w, b[4 * q + 3], acc);
+        }
+    }
+}
+
+// The decoder head of dec_seq_kernel, entirely in registers: act holds the head's input on entry (the top layer's new
+// h, k-step order) and every layer's activations in turn; nothing goes through LDS, so the h columns stay as the
+// memory left them.  All layers, the full-K first one included, run as banded tiles through ONE rolled loop (the
+// kernel's instruction footprint is what eight out-of-phase waves share an instruction cache for).  fa / fb: the
+// fragment buffers, ping-pong by tile parity; on entry fa holds layer 0's tile 0 and bf layer 0's bias fragments
+// (dec_seq_kernel requests them in front of the memory's last cell).  Layers before the last must have four tiles.
+template <int NT>
+__device__ __forceinline__ void dec_seq_head(const LstmSeqArgs& a, float (&act)[16 * kHeadTiles], const int lane,
+                                             const long rowtile, const int to, const uint32_t day_rel, const uint32_t sample,
+                                             float4 (&fa)[4 * kHeadTiles], float4 (&fb)[4 * kHeadTiles], float (&bf)[4],
+                                             const int dsq_t, const int wave) {
+    constexpr int NQB = 4 * kHeadTiles;                           // K quads of a head layer (16)
+    const DenseChainArgs& hd = a.head;
+    const int n_layers = hd.n_layers;                             // 4: [Linear . ConvT] ConvT ConvT Conv
+#pragma unroll 1
+    for (int li = 0; li < n_layers; ++li) {
+        const DenseLayerArg ly = chain_layer_of(li);
+        const DenseLayerArg lyn = chain_layer_of(li + 1 < n_layers ? li + 1 : li);
+        const int lv = opaque(lane);
+        const int hh = lv >> 5;
+        const wrsrc_t wr = make_wrsrc(ly.w), wrn = make_wrsrc(lyn.w);
+        const unsigned voff = (unsigned)lv * 16u;
+        float bfn[4];                                             // the next layer's bias fragments
+#pragma unroll
+        for (int i = 0; i < 4; ++i) bfn[i] = bias_frag(lyn.b, i < lyn.nt ? i : lyn.nt - 1, lv);
+        f32x16 acc[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            if (t < ly.nt) {
+                // what follows this tile: the layer's next tile, or the next layer's first
+                const bool wrap = t + 1 >= ly.nt;
+                const unsigned sbn = wrap ? 0u : (unsigned)(t + 1) * 1024u, qsbn = (unsigned)(wrap ? lyn.nt : ly.nt) * 1024u;
+                const unsigned qmask = ((1u << pick4(ly.nqb, t)) - 1u) << pick4(ly.q0, t);
+                acc[t] = bias_acc(bf[t]);
+                if (t & 1) band_tile_reg<NQB>(acc[t], fb, fa, wrap ? wrn : wr, voff, sbn, qsbn, act, qmask);
+                else band_tile_reg<NQB>(acc[t], fa, fb, wrap ? wrn : wr, voff, sbn, qsbn, act, qmask);
+            }
+        }
+        DSQ_STAMP(18 + 2 * li);
+        // ---- epilogue: ReLU; the activations take the layer's outputs; ex-features / surfaces leave from the layers
+        // that produce them
+        const bool last = (li == n_layers - 1);
+        const bool do_aux = (li == hd.aux_layer) && hd.aux != nullptr;
+        const long rr = rowtile * 32 + (lv & 31);
+        const bool row_ok = rr < hd.n_rows;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            if (t < ly.nt) {
+                const int f_lo = 32 * t;
+                float v[16];
+                if (ly.n_relu >= f_lo + 32) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) v[r] = relu1(acc[t][r]);
+                } else if (ly.n_relu > f_lo) {
+                    // register r holds feature f_lo + 4 hh + 8 (r >> 2) + (r & 3): max(x, 0) below n_relu, max(x, -inf)
+                    // from there on (a select and a max per value, no branches)
+                    const int thr = ly.n_relu - f_lo - 4 * hh;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const float lo = (8 * (r >> 2) + (r & 3) < thr) ? 0.0f : -__builtin_inff();
+                        float y;
+                        asm("v_max_f32 %0, %1, %2" : "=v"(y) : "v"(lo), "v"(acc[t][r]));
+                        v[r] = y;
+                    }
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) v[r] = acc[t][r];
+                }
+                if (do_aux && row_ok && f_lo + 32 > hd.aux_f0 && f_lo < hd.aux_f0 + hd.aux_n) {
+                    float* const ax = hd.aux + ((size_t)rr * hd.T + to) * hd.aux_n - hd.aux_f0;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int f = feat_of(t, r, hh);
+                        if (f >= hd.aux_f0 && f < hd.aux_f0 + hd.aux_n) ax[f] = v[r];
+                    }
+                }
+                if (last && hd.out && row_ok && f_lo < hd.out_f) {
+                    // feature f of this (row, step) lives at po0 + f * fs: sample-minor (day, step, f, sample) or
+                    // row-major (row, step, f)
+                    const bool smin = hd.out_mode == 2;
+                    const long fs = smin ? hd.S : 1;
+                    float* po = smin ? hd.out + ((size_t)day_rel * hd.T + to) * hd.out_f * hd.S + sample
+                                     : hd.out + ((size_t)rr * hd.T + to) * hd.out_f;
+                    po += (size_t)(f_lo + 4 * hh) * fs;
+                    if (f_lo + 32 <= hd.out_f) {
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) po[(size_t)(8 * (r >> 2) + (r & 3)) * fs] = v[r];
+                    } else {
+#pragma unroll
+                        for (int r = 0; r < 16; ++r)
+                            if (feat_of(t, r, hh) < hd.out_f) po[(size_t)(8 * (r >> 2) + (r & 3)) * fs] = v[r];
+                    }
+                }
+#pragma unroll
+                for (int r = 0; r < 16; ++r) act[16 * t + r] = v[r];
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) bf[i] = bfn[i];
+        DSQ_STAMP(19 + 2 * li);
+    }
+}
+
+template <int NT>
+__global__ void __launch_bounds__(256, 1) dec_seq_kernel(const LstmSeqArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    static_assert(NT == 16, "built for 16 gate tiles (decoder hidden 121..128)");
+    constexpr int HP = 8 * NT, HPK = 4 * NT, NP = NT / 4;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const long rowtile = (long)blockIdx.x * (blockDim.x >> 6) + wave;
+    if (rowtile >= a.n_rowtiles) return;                          // (no barriers below: a wave may leave alone)
+    const vsv_decode_in& d = a.din;
+    const int kx = a.kx, L = a.L, Lc = a.Lc, T = a.T;
+    // this wave's columns, without the lane: [h of layer 1 (and the head's activations) | h of layer 0 | x]
+    float* const hc1 = smem + (size_t)wave * (size_t)(kx + 2 * HPK) * 64;
+    float* const hc0 = hc1 + (size_t)HPK * 64;
+    float* const xs0 = hc0 + (size_t)HPK * 64;
+    auto hcol = [&](int l) { return l == 0 ? hc0 : hc1; };
+
+    // ---- per-row constants
+    const int hh0 = lane >> 5;
+    const long row_raw = rowtile * 32 + (lane & 31);
+    const uint32_t row32 = (uint32_t)(row_raw < a.n_rows ? row_raw : a.n_rows - 1);
+    auto div32 = [](long dv) { return (uint32_t)(dv > 0x7fffffffL ? 0x7fffffffL : dv); };
+    const uint32_t day_rel = row32 / div32(d.S);
+    const uint32_t sample = row32 - day_rel * div32(d.S);
+    const uint32_t day = (uint32_t)d.day0 + day_rel;
+    const float* const ctxp = d.ctx ? d.ctx + (long)(d.ctx_div == 1 ? row32 : row32 / div32(d.ctx_div)) * d.ctx_rs : nullptr;
+    const long z_idx = d.zb ? (long)(d.z_div == 1 ? row32 : row32 / div32(d.z_div)) * d.z_rs : 0;
+    const float* const epsp = d.eps_in ? d.eps_in + (size_t)row32 * d.eps_T * L : nullptr;
+    const bool has_state = d.state_in != nullptr;                 // wave-uniform
+    const bool shared0 = d.gate_in != nullptr;                    // first step from a shared state with its gates given
+    const uint32_t state_row = has_state ? ((d.state_div == d.S) ? day_rel : row32 / div32(d.state_div)) : 0u;
+    const float* const gate_in = shared0 ? d.gate_in + (size_t)state_row * 2 * NT * 32 : nullptr;
+    // a shared first step without context: of layer 0's input quads only those that hold z are multiplied
+    const int qx0 = Lc >> 3, qxn = ((Lc + L + 7) >> 3) - qx0;
+    const bool zfast = shared0 && d.ctx_T <= 0;
+
+    // x part of layer 0 at step t: [ctx | z | alignment padding]; k-step s, half hh <-> feature 2s + hh
+    auto assemble_x = [&](int t, int lv) {
+        const int hh = lv >> 5;
+        float* const xs = xs0 + lv;
+        const bool given = t < d.z_T;                             // z_t = zb (+ exp(lv / 2) eps); else mu0 + std0 eps
+        const bool noisy = given ? (d.lv != nullptr) : (d.std0 != 0.0f);
+        const bool has_ctx = t < d.ctx_T;
+        for (int s = 0; s < kx; ++s) {
+            const int f = 2 * s + hh, j = f - Lc;
+            float v = 0.0f;
+            if (f < Lc) {
+                if (has_ctx) v = ctxp[(long)t * Lc + f];
+            } else if (j < L) {
+                v = given ? d.zb[z_idx + (long)t * L + j] : d.mu0;
+            }
+            xs[s * 64] = v;
+        }
+        if (noisy) {
+            const int te = t - d.eps_t0;
+            // one Philox block gives the latents 4b .. 4b+3 (philox_normal_elem: word pair j & 2, cos / sin by j & 1);
+            // this lane holds the two of them with its parity
+            const int par = (hh - Lc) & 1;
+            const uint32_t k0 = (uint32_t)d.seed, k1 = (uint32_t)(d.seed >> 32);
+            for (int b = 0; 4 * b < L; ++b) {
+                uint32_t c0 = (uint32_t)opaque((int)sample), c1 = day, c2 = (uint32_t)(d.step0 + te), c3 = (uint32_t)b;
+                if (!epsp) philox4x32_10(k0, k1, c0, c1, c2, c3);
+#pragma unroll
+                for (int p = 0; p < 2; ++p) {
+                    const int j = 4 * b + 2 * p + par;
+                    if (j < L) {
+                        float e;
+                        if (epsp) {
+                            e = epsp[(size_t)te * L + j];
+                        } else {
+                            const uint32_t xa = p ? c2 : c0, xb = p ? c3 : c1;
+                            const float u1 = ((float)(xa >> 9) + 0.5f) * 1.1920928955078125e-07f;
+                            const float u2 = ((float)(xb >> 9) + 0.5f) * 1.1920928955078125e-07f;
+                            const float r = __builtin_amdgcn_sqrtf(-1.3862943611198906f * __builtin_amdgcn_logf(u1));
+                            e = r * (par ? __builtin_amdgcn_sinf(u2) : __builtin_amdgcn_cosf(u2));
+                        }
+                        float base, scale;
+                        if (given) {
+                            const long idx = z_idx + (long)t * L + j;
+                            base = d.zb[idx];
+                            scale = expf(0.5f * d.lv[idx]);
+                        } else {
+                            base = d.mu0;
+                            scale = d.std0;
+                        }
+                        xs[((j + Lc - hh) >> 1) * 64] = base + scale * e;
+                    }
+                }
+            }
+        }
+    };
+
+    // ---- state: c in registers, h in the LDS columns (a shared first step never reads the old h)
+    float c[2][NT][4];
+    {
+        const float* const st = has_state ? d.state_in + (size_t)state_row * 2 * 2 * HP : nullptr;
+#pragma unroll
+        for (int l = 0; l < 2; ++l) {
+            float* const hb = hcol(l) + lane;
+#pragma unroll
+            for (int i = 0; i < NT; ++i) {
+                float4 hv = make_float4(0.0f, 0.0f, 0.0f, 0.0f), cv = hv;
+                if (has_state) {
+                    const float* ps = st + (size_t)l * 2 * HP + 8 * i + 4 * hh0;
+                    if (!shared0) hv = *(const float4*)ps;
+                    cv = *(const float4*)(ps + HP);
+                }
+                c[l][i][0] = cv.x; c[l][i][1] = cv.y; c[l][i][2] = cv.z; c[l][i][3] = cv.w;
+                if (!shared0) {
+                    hb[(4 * i + 0) * 64] = hv.x; hb[(4 * i + 1) * 64] = hv.y;
+                    hb[(4 * i + 2) * 64] = hv.z; hb[(4 * i + 3) * 64] = hv.w;
+                }
+            }
+        }
+    }
+    assemble_x(0, lane);
+
+    // A pass's first fetches -- the gate accumulators' initial values (bias, or a shared first step's given gates)
+    // and quad 0 of its weight stream -- are requested one pass early, in front of the previous pass's cell math
+    // (and the head's first layer in front of the memory's last cell): with one wave per SIMD nothing else covers
+    // an L2 round trip.
+    auto pass_w = [&](int l, bool shared) {                       // layer l's stream: [input quads from q0 | recurrent quads]
+        const bool zq = (l == 0) && shared && zfast;
+        return (const float4*)a.w[l] + (size_t)(zq ? qx0 : 0) * NT * 64;
+    };
+    // (the bias as ONE register per tile, see bias_frag; a shared first step's gates are per row: sixteen registers
+    // per tile, loaded where the pass starts)
+    auto pass_fetch = [&](int l, int p, bool shared, float (&bf)[4], float4 (&a0)[4]) {
+        const int lv = opaque(lane);
+        wload_buf<4>(a0, make_wrsrc(pass_w(l, shared)), (unsigned)lv * 16u, (unsigned)p * 4096u);     // tiles 4p .. 4p + 3
+#pragma unroll
+        for (int i = 0; i < 4; ++i) bf[i] = bias_frag(a.b[l], 4 * p + i, lv);
+    };
+    float4 fa[4 * kHeadTiles], fb[4 * kHeadTiles];                // the head's fragment buffers (dec_seq_head)
+    auto head_fetch = [&](float (&bf)[4]) {
+        const DenseLayerArg& ly = a.head.layer[0];
+        const int lv = opaque(lane);
+        band_load_all<4 * kHeadTiles>(fa, make_wrsrc(ly.w), (unsigned)lv * 16u, 0u, (unsigned)ly.nt * 1024u, 0, 4 * kHeadTiles);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) bf[i] = bias_frag(ly.b, i, lv);
+    };
+
+    float bf[4];
+    float4 a0[4];
+    pass_fetch(0, 0, shared0, bf, a0);
+#pragma unroll 1
+    for (int t = 0; t < T; ++t) {
+        const bool shared = shared0 && t == 0;                    // wave-uniform
+        const bool head_now = t >= a.t_out0;
+        float hold[NT][4];                                        // the layer's new h, unit 8*tile + 2*jj + hh
+        const int dsq_t = t;                                      // (stamps)
+        DSQ_STAMP(0);
+#pragma unroll
+        for (int l = 0; l < 2; ++l) {
+            const int nq_in = (l == 0) ? (kx >> 2) : NT;
+            const bool zq = (l == 0) && shared && zfast;
+            const int q0 = zq ? qx0 : 0;
+            const int nqi = nq_in - q0;                           // input quads from q0 on
+            const int nqs = shared ? (zq ? qxn : nqi) : nqi + NT; // quads streamed: [input part | recurrent part]
+            const float4* const w = pass_w(l, shared);
+#pragma unroll
+            for (int p = 0; p < NP; ++p) {
+                const int lv = opaque(lane);
+                float hn[4][4];
+                const wrsrc_t wr = make_wrsrc(w);
+                const unsigned voff = (unsigned)lv * 16u, sb = (unsigned)p * 4096u;      // tiles 4p .. 4p + 3
+                const float* const bin = ((l == 0) ? xs0 : hc0) + lv + (size_t)(4 * q0) * 64;   // layer 1 reads h0
+                const float* const hl = hcol(l) + lv;
+                f32x16 acc[4];
+                if (shared) {
+                    const int hh = lv >> 5;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const float4* gp = (const float4*)(gate_in + (size_t)l * NT * 32 + (4 * p + i) * 32 + hh * 16);
+#pragma unroll
+                        for (int v = 0; v < 4; ++v) {
+                            const float4 x = gp[v];
+                            acc[i][4 * v + 0] = x.x; acc[i][4 * v + 1] = x.y; acc[i][4 * v + 2] = x.z; acc[i][4 * v + 3] = x.w;
+                        }
+                    }
+                } else {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) acc[i] = bias_acc(bf[i]);
+                }
+                gemm_stream_buf1<4>(acc, a0, wr, voff, sb, NT * 1024u, nqs, [&](int q, float (&bv)[4]) {
+                    const float* bp = (q < nqi) ? bin + (size_t)(4 * q) * 64 : hl + (size_t)(4 * (q - nqi)) * 64;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) bv[j] = bp[j * 64];
+                });
+                DSQ_STAMP(1 + 2 * (NP * l + p));
+                // the next stage's first fetches, in front of this pass's cell
+                float bfn[4];
+                float4 a0n[4];
+                if (p + 1 < NP) pass_fetch(l, p + 1, shared, bfn, a0n);
+                else if (l == 0) pass_fetch(1, 0, shared, bfn, a0n);
+                else if (head_now) head_fetch(bfn);
+                else pass_fetch(0, 0, false, bfn, a0n);           // (t + 1 == T: fetched and dropped)
+                __builtin_amdgcn_sched_barrier(0);
+                lstm_cell_pk(acc, reinterpret_cast<float(&)[4][4]>(c[l][4 * p]), hn);
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int jj = 0; jj < 4; ++jj) {
+                        asm volatile("" : "+v"(hn[i][jj]));
+                        hold[4 * p + i][jj] = hn[i][jj];
+                    }
+                __builtin_amdgcn_sched_barrier(0);
+                DSQ_STAMP(2 + 2 * (NP * l + p));
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    bf[i] = bfn[i];
+                    a0[i] = a0n[i];
+                }
+            }
+            // every pass has read the layer's old h: the column takes the new one (natural k-step order)
+            float* const colw = hcol(l) + opaque(lane);
+#pragma unroll
+            for (int i = 0; i < NT; ++i)
+#pragma unroll
+                for (int jj = 0; jj < 4; ++jj) colw[(4 * i + jj) * 64] = hold[i][jj];
+            // x of the next step: layer 0 has read this step's
+            if (l == 0 && t + 1 < T) assemble_x(t + 1, opaque(lane));
+            if (l == 1) DSQ_STAMP(17);
+        }
+        if (head_now) {
+            // the head's input is the top layer's new h, still in registers (k-step 4 i + jj <-> hold[i][jj])
+            float act[16 * kHeadTiles];
+#pragma unroll
+            for (int i = 0; i < NT; ++i)
+#pragma unroll
+                for (int jj = 0; jj < 4; ++jj) act[4 * i + jj] = hold[i][jj];
+            dec_seq_head<NT>(a, act, lane, rowtile, t - a.t_out0, day_rel, sample, fa, fb, bf, t, wave);
+            if (t + 1 < T) pass_fetch(0, 0, false, bf, a0);
+        }
+        DSQ_STAMP(26);
     }
 }
 
@@ -4516,6 +4990,27 @@ static bool mc_decode1_applies(const LstmSeqArgs& l, const Layout& lay, int T, i
     return true;
 }
 
+// dec_seq_kernel: the same one-wave schedule over T steps, for launches with enough row tiles to give every SIMD of
+// the chip a wave of its own (VSV_DSEQ_MIN, default 1024 tiles = 32768 rows; below that lstm_kernel's four or
+// sixteen waves per row tile finish a short launch sooner).  VSV_DSEQ=0 keeps lstm_kernel (A/B runs).
+static bool dec_seq_applies(const LstmSeqArgs& l, const Layout& lay, int T, int t_out0, const float* state_out,
+                            const float* z_out) {
+    static const bool off = [] { const char* e = getenv("VSV_DSEQ"); return e && e[0] == '0'; }();
+    static const long min_tiles = [] { const char* e = getenv("VSV_DSEQ_MIN"); return e ? atol(e) : 1024L; }();
+    if (off || l.n_rowtiles < min_tiles) return false;
+    const vsv_decode_in& d = l.din;
+    const DenseChainArgs& hd = l.head;
+    if (T < 1 || t_out0 >= T || state_out || z_out || d.gate_out || l.sv_gates) return false;
+    if (lay.NL != 2 || lay.NTd != 16 || lay.gru || l.kx > 32 || (l.kx & 3)) return false;
+    if (hd.n_layers != 4 || hd.layer[0].nt != 4 || hd.layer[0].nq != 16) return false;
+    for (int i = 1; i < 4; ++i)
+        if (hd.layer[i].nt < 1 || hd.layer[i].nt > 4 || hd.layer[i].nq != 16 || (i < 3 && hd.layer[i].nt != 4)) return false;
+    for (int i = 0; i < 4; ++i)
+        for (int t = 0; t < hd.layer[i].nt; ++t)                   // (band_tile clamps into non-empty bands)
+            if (hd.layer[i].nqb[t] < 1 || hd.layer[i].q0[t] < 0 || hd.layer[i].q0[t] + hd.layer[i].nqb[t] > 16) return false;
+    return true;
+}
+
 extern "C" size_t vsv_decode_ws_bytes(const vsv_dims* dims, long n_rows, int T, int t_out0) {
     Layout lay;
     const char* msg = nullptr;
@@ -4596,6 +5091,15 @@ extern "C" int vsv_decode(const vsv_dims* dims, const float* packed, const vsv_d
         if (!rc) {
             hipLaunchKernelGGL(mc_decode1_kernel<16>, dim3((unsigned)((rt + wpb - 1) / wpb)), dim3(64 * wpb), lds, st, l);
             rc = launch_check("mc_decode1_kernel");
+        }
+    } else if (dec_seq_applies(l, lay, T, t_out0, state_out, z_out)) {
+        // many rows, T steps: one wave per 32 rows and SIMD, cell state in registers, no barriers (dec_seq_kernel)
+        static const int wpb = [] { const char* e = getenv("VSV_DSEQ_WPB"); const int v = e ? atoi(e) : 4; return (v == 1 || v == 2) ? v : 4; }();
+        const size_t lds = (size_t)wpb * (size_t)(l.kx + 8 * 16) * 64 * sizeof(float);
+        rc = set_lds(dec_seq_kernel<16>, lds);
+        if (!rc) {
+            hipLaunchKernelGGL(dec_seq_kernel<16>, dim3((unsigned)((rt + wpb - 1) / wpb)), dim3(64 * wpb), lds, st, l);
+            rc = launch_check("dec_seq_kernel");
         }
     } else {
         rc = launch_lstm<1>(l, lay.NTd, lay.NL, touts > 0, st);

@@ -13,12 +13,43 @@ from vsv.drivers import generate_quantile_products  # noqa: F401
 MODELS = (("no_ex", False), ("ex_no_loss", False), ("ex_loss", True))      # (name, check_ex_feats), reference :45-64
 
 
-def _load_checkpoint(path):
-    """The caller's own checkpoint ({"model", "model_config", ...}, vae/base.py save_weights): tensors-only load
-    first; checkpoints that pickle other objects (a torch.device in model_config, RNG states) need the full load."""
+def _safe_globals():
+    """What a checkpoint written by vae/base.py save_weights holds besides tensors: the numpy RNG state (an ndarray) and
+    possibly a torch.device in model_config.  Allow-listed for the weights-only unpickler; nothing else is."""
+    out = [torch.device, np.ndarray, np.dtype]
     try:
-        return torch.load(path, weights_only=True)
+        from numpy.core.multiarray import _reconstruct          # numpy < 2 pickles
+        out.append(_reconstruct)
     except Exception:
+        pass
+    try:
+        from numpy._core.multiarray import _reconstruct as _reconstruct2
+        out.append(_reconstruct2)
+    except Exception:
+        pass
+    out += [type(np.dtype(t)) for t in ("uint32", "int64", "float64")]
+    return out
+
+
+def _load_checkpoint(path, allow_full_pickle=None):
+    """The caller's own checkpoint ({"model", "model_config", ...}, vae/base.py save_weights), loaded with the
+    weights-only unpickler (which executes nothing from the file) and an allow-list for the few non-tensor types such
+    a checkpoint holds.  The full pickle loader -- the reference's own `weights_only=False` -- runs code from the file,
+    so it is used only when the caller asks for it (allow_full_pickle=True or VSV_ALLOW_FULL_PICKLE=1), only after the
+    safe loader has refused to unpickle the file (I/O errors are not retried), and with a warning."""
+    import os
+    import pickle
+    import warnings
+    if allow_full_pickle is None:
+        allow_full_pickle = os.environ.get("VSV_ALLOW_FULL_PICKLE", "") == "1"
+    try:
+        with torch.serialization.safe_globals(_safe_globals()):
+            return torch.load(path, weights_only=True)
+    except pickle.UnpicklingError as exc:
+        if not allow_full_pickle:
+            raise RuntimeError(f"{path}: the weights-only loader refused this checkpoint ({exc}); if the file is your own "
+                               "and trusted, pass allow_full_pickle=True or set VSV_ALLOW_FULL_PICKLE=1") from exc
+        warnings.warn(f"{path}: loading with the full pickle loader (executes code from the file) at the caller's request")
         return torch.load(path, weights_only=False)
 
 

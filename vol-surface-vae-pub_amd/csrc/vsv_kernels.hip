@@ -449,19 +449,35 @@ __device__ __forceinline__ void band_mfma_all(f32x16& acc, const float4 (&a)[NQ]
     }
 }
 
-// The bias of output tile `tile` (compact [nt][2][16] layout) as an A fragment: lane l < 32 holds the bias of tile row l,
-// the upper lanes zero.  One product with a B operand of ones turns it into the tile's initial accumulator, exactly
-// (0 + b * 1): one register per lane and tile to fetch ahead instead of sixteen (dec_seq_kernel).
+// A value parked in the accumulator half of the register file (gfx950: one 512-entry file per SIMD, split into
+// vector and accumulator registers).  dec_seq_kernel keeps the cell state of both memory layers there for the
+// whole time loop and takes sixteen values at a time into vector registers for a pass's cell math: left to the
+// register allocator the state occupied half of the vector registers and everything else spilled around it.
+__device__ __forceinline__ float agpr_put(float v) {
+    float a;
+    asm("v_accvgpr_write_b32 %0, %1" : "=a"(a) : "v"(v));
+    return a;
+}
+__device__ __forceinline__ float agpr_get(float a) {
+    float v;
+    asm("v_accvgpr_read_b32 %0, %1" : "=v"(v) : "a"(a));
+    return v;
+}
+
+// The bias of output tile `tile` (compact [nt][2][16] layout) as an A fragment: lane l holds the bias of tile row
+// l & 31 (both lane halves, i.e. both k-steps, the same value).  One product with a B operand that is 1 in the lower
+// lanes (k-step 0) and 0 in the upper turns it into the tile's initial accumulator, exactly (0 + b * 1 + b * 0): one
+// register per lane and tile to fetch ahead instead of sixteen, and nothing to do to the value once it has landed
+// (dec_seq_kernel).
 __device__ __forceinline__ float bias_frag(const float* __restrict__ b, int tile, int lane) {
     const int i = lane & 31;
-    const float v = b[tile * 32 + ((i >> 2) & 1) * 16 + 4 * (i >> 3) + (i & 3)];
-    return lane < 32 ? v : 0.0f;
+    return b[tile * 32 + ((i >> 2) & 1) * 16 + 4 * (i >> 3) + (i & 3)];
 }
-__device__ __forceinline__ f32x16 bias_acc(float bf) {
+__device__ __forceinline__ f32x16 bias_acc(float bf, float one_lo) {
     f32x16 z;
 #pragma unroll
     for (int r = 0; r < 16; ++r) z[r] = 0.0f;
-    return mfma32(bf, 1.0f, z);
+    return mfma32(bf, one_lo, z);
 }
 
 // acc[i] = bias of tile tile[i] (compact [nt][2][16] layout)
@@ -2434,34 +2450,34 @@ __global__ void __launch_bounds__(256, 2) mc_decode1_kernel(const LstmSeqArgs a)
 // from REGISTERS (the D layout of a layer is the B layout of the next: k-step 16 t + r of a layer's input is register r
 // of the previous layer's tile t), indexed by the ABSOLUTE quad, so that the index is static; the band is a bit mask
 // (bit q set: quad q is multiplied) tested by scalar guards.  The NEXT tile's fragments are requested quad by quad from
-// inside the chain (a fetch issues in the shadow of the product before it; in front of the chain sixteen fetches cost
-// ~1000 cycles of a lone wave's time), unconditionally, all sixteen quads of its K range.
+// inside the chain, each into the slot whose quad has just been multiplied (a fetch issues in the shadow of the product
+// before it -- in front of the chain sixteen fetches cost ~1000 cycles of a lone wave's time -- and has the rest of
+// this tile's band to land), unconditionally, all sixteen quads of its K range.
 template <int NQ>
-__device__ __forceinline__ void band_tile_reg(f32x16& acc, const float4 (&cur)[NQ], float4 (&nxt)[NQ], wrsrc_t rn, unsigned voff,
-                                              unsigned sbn, unsigned qsbn, const float (&b)[4 * NQ], unsigned qmask) {
+__device__ __forceinline__ void band_tile_reg(f32x16& acc, float4 (&f)[NQ], wrsrc_t rn, unsigned voff, unsigned sbn, unsigned qsbn,
+                                              const float (&b)[4 * NQ], unsigned qmask) {
 #pragma unroll
     for (int q = 0; q < NQ; ++q) {
-        nxt[q] = bload(rn, voff, sbn + (unsigned)q * qsbn);
         if ((qmask >> q) & 1u) {
-            acc = mfma32(cur[q].x, b[4 * q + 0], acc);
-            acc = mfma32(cur[q].y, b[4 * q + 1], acc);
-            acc = mfma32(cur[q].z, b[4 * q + 2], acc);
-            acc = mfma32(cur[q].w, b[4 * q + 3], acc);
+            acc = mfma32(f[q].x, b[4 * q + 0], acc);
+            acc = mfma32(f[q].y, b[4 * q + 1], acc);
+            acc = mfma32(f[q].z, b[4 * q + 2], acc);
+            acc = mfma32(f[q].w, b[4 * q + 3], acc);
         }
+        f[q] = bload(rn, voff, sbn + (unsigned)q * qsbn);      // the next tile's quad q takes the slot
     }
 }
 
 // The decoder head of dec_seq_kernel, entirely in registers: act holds the head's input on entry (the top layer's new
 // h, k-step order) and every layer's activations in turn; nothing goes through LDS, so the h columns stay as the
 // memory left them.  All layers, the full-K first one included, run as banded tiles through ONE rolled loop (the
-// kernel's instruction footprint is what eight out-of-phase waves share an instruction cache for).  fa / fb: the
-// fragment buffers, ping-pong by tile parity; on entry fa holds layer 0's tile 0 and bf layer 0's bias fragments
-// (dec_seq_kernel requests them in front of the memory's last cell).  Layers before the last must have four tiles.
+// kernel's instruction footprint is what eight out-of-phase waves share an instruction cache for).  fa: the fragment
+// buffer; on entry it holds layer 0's tile 0 and bf layer 0's bias fragments (dec_seq_kernel requests them behind the
+// memory's last cell, in front of the column write).
 template <int NT>
 __device__ __forceinline__ void dec_seq_head(const LstmSeqArgs& a, float (&act)[16 * kHeadTiles], const int lane,
                                              const long rowtile, const int to, const uint32_t day_rel, const uint32_t sample,
-                                             float4 (&fa)[4 * kHeadTiles], float4 (&fb)[4 * kHeadTiles], float (&bf)[4],
-                                             const int dsq_t, const int wave) {
+                                             float4 (&fa)[4 * kHeadTiles], float (&bf)[4], const int dsq_t, const int wave) {
     constexpr int NQB = 4 * kHeadTiles;                           // K quads of a head layer (16)
     const DenseChainArgs& hd = a.head;
     const int n_layers = hd.n_layers;                             // 4: [Linear . ConvT] ConvT ConvT Conv
@@ -2484,9 +2500,8 @@ __device__ __forceinline__ void dec_seq_head(const LstmSeqArgs& a, float (&act)[
                 const bool wrap = t + 1 >= ly.nt;
                 const unsigned sbn = wrap ? 0u : (unsigned)(t + 1) * 1024u, qsbn = (unsigned)(wrap ? lyn.nt : ly.nt) * 1024u;
                 const unsigned qmask = ((1u << pick4(ly.nqb, t)) - 1u) << pick4(ly.q0, t);
-                acc[t] = bias_acc(bf[t]);
-                if (t & 1) band_tile_reg<NQB>(acc[t], fb, fa, wrap ? wrn : wr, voff, sbn, qsbn, act, qmask);
-                else band_tile_reg<NQB>(acc[t], fa, fb, wrap ? wrn : wr, voff, sbn, qsbn, act, qmask);
+                acc[t] = bias_acc(bf[t], lv < 32 ? 1.0f : 0.0f);
+                band_tile_reg<NQB>(acc[t], fa, wrap ? wrn : wr, voff, sbn, qsbn, act, qmask);
             }
         }
         DSQ_STAMP(18 + 2 * li);
@@ -2589,39 +2604,79 @@ __global__ void __launch_bounds__(256, 1) dec_seq_kernel(const LstmSeqArgs a) {
     const int qx0 = Lc >> 3, qxn = ((Lc + L + 7) >> 3) - qx0;
     const bool zfast = shared0 && d.ctx_T <= 0;
 
-    // x part of layer 0 at step t: [ctx | z | alignment padding]; k-step s, half hh <-> feature 2s + hh
+    // x part of layer 0 at step t: [ctx | z | alignment padding]; k-step s, half hh <-> feature 2s + hh.  A lone wave
+    // pays every load's round trip it waits for, so all of a step's loads go out together, from clamped addresses
+    // (kx <= 16 slots, L <= 16 latents: checked by the launcher), and the values are selected afterwards.
     auto assemble_x = [&](int t, int lv) {
+        constexpr int KXM = 16, NB = 4;
         const int hh = lv >> 5;
         float* const xs = xs0 + lv;
         const bool given = t < d.z_T;                             // z_t = zb (+ exp(lv / 2) eps); else mu0 + std0 eps
         const bool noisy = given ? (d.lv != nullptr) : (d.std0 != 0.0f);
         const bool has_ctx = t < d.ctx_T;
-        for (int s = 0; s < kx; ++s) {
-            const int f = 2 * s + hh, j = f - Lc;
-            float v = 0.0f;
-            if (f < Lc) {
-                if (has_ctx) v = ctxp[(long)t * Lc + f];
-            } else if (j < L) {
-                v = given ? d.zb[z_idx + (long)t * L + j] : d.mu0;
-            }
-            xs[s * 64] = v;
-        }
-        if (noisy) {
-            const int te = t - d.eps_t0;
-            // one Philox block gives the latents 4b .. 4b+3 (philox_normal_elem: word pair j & 2, cos / sin by j & 1);
-            // this lane holds the two of them with its parity
-            const int par = (hh - Lc) & 1;
-            const uint32_t k0 = (uint32_t)d.seed, k1 = (uint32_t)(d.seed >> 32);
-            for (int b = 0; 4 * b < L; ++b) {
-                uint32_t c0 = (uint32_t)opaque((int)sample), c1 = day, c2 = (uint32_t)(d.step0 + te), c3 = (uint32_t)b;
-                if (!epsp) philox4x32_10(k0, k1, c0, c1, c2, c3);
+        const int par = (hh - Lc) & 1;                            // parity of this lane's latent indices
+        const int te = t - d.eps_t0;
+        // ---- loads
+        float cv[KXM], zv[KXM], zn[2 * NB], lvv[2 * NB], ev[2 * NB];
+        if (has_ctx) {
+            const float* const cp = ctxp + (long)t * Lc;
 #pragma unroll
-                for (int p = 0; p < 2; ++p) {
-                    const int j = 4 * b + 2 * p + par;
-                    if (j < L) {
+            for (int s = 0; s < KXM; ++s) {
+                const int f = 2 * s + hh;
+                cv[s] = cp[f < Lc ? f : Lc - 1];
+            }
+        }
+        if (given) {
+            const float* const zp = d.zb + z_idx + (long)t * L;
+#pragma unroll
+            for (int s = 0; s < KXM; ++s) {
+                const int j = 2 * s + hh - Lc;
+                zv[s] = zp[j < 0 ? 0 : (j < L ? j : L - 1)];
+            }
+            if (noisy) {
+                const float* const lp = d.lv + z_idx + (long)t * L;
+#pragma unroll
+                for (int i = 0; i < 2 * NB; ++i) {
+                    const int j = 2 * i + par;
+                    zn[i] = zp[j < L ? j : L - 1];
+                    lvv[i] = lp[j < L ? j : L - 1];
+                }
+            }
+        }
+        if (noisy && epsp) {
+            const float* const ep = epsp + (size_t)te * L;
+#pragma unroll
+            for (int i = 0; i < 2 * NB; ++i) {
+                const int j = 2 * i + par;
+                ev[i] = ep[j < L ? j : L - 1];
+            }
+        }
+        // ---- the noiseless vector
+#pragma unroll
+        for (int s = 0; s < KXM; ++s) {
+            if (s < kx) {
+                const int f = 2 * s + hh, j = f - Lc;
+                float v = 0.0f;
+                if (f < Lc) v = has_ctx ? cv[s] : 0.0f;
+                else if (j < L) v = given ? zv[s] : d.mu0;
+                xs[s * 64] = v;
+            }
+        }
+        // ---- noise: one Philox block gives the latents 4b .. 4b+3 (philox_normal_elem: word pair j & 2, cos / sin by
+        // j & 1); this lane holds the two of them with its parity
+        if (noisy) {
+            const uint32_t k0 = (uint32_t)d.seed, k1 = (uint32_t)(d.seed >> 32);
+#pragma unroll
+            for (int b = 0; b < NB; ++b) {
+                if (4 * b < L) {
+                    uint32_t c0 = (uint32_t)opaque((int)sample), c1 = day, c2 = (uint32_t)(d.step0 + te), c3 = (uint32_t)b;
+                    if (!epsp) philox4x32_10(k0, k1, c0, c1, c2, c3);
+#pragma unroll
+                    for (int p = 0; p < 2; ++p) {
+                        const int j = 4 * b + 2 * p + par;
                         float e;
                         if (epsp) {
-                            e = epsp[(size_t)te * L + j];
+                            e = ev[2 * b + p];
                         } else {
                             const uint32_t xa = p ? c2 : c0, xb = p ? c3 : c1;
                             const float u1 = ((float)(xa >> 9) + 0.5f) * 1.1920928955078125e-07f;
@@ -2631,22 +2686,22 @@ __global__ void __launch_bounds__(256, 1) dec_seq_kernel(const LstmSeqArgs a) {
                         }
                         float base, scale;
                         if (given) {
-                            const long idx = z_idx + (long)t * L + j;
-                            base = d.zb[idx];
-                            scale = expf(0.5f * d.lv[idx]);
+                            base = zn[2 * b + p];
+                            scale = expf(0.5f * lvv[2 * b + p]);
                         } else {
                             base = d.mu0;
                             scale = d.std0;
                         }
-                        xs[((j + Lc - hh) >> 1) * 64] = base + scale * e;
+                        // (this lane's latent j sits in slot (j + Lc - hh) / 2)
+                        if (j < L) xs[((j + Lc - hh) >> 1) * 64] = base + scale * e;
                     }
                 }
             }
         }
     };
 
-    // ---- state: c in registers, h in the LDS columns (a shared first step never reads the old h)
-    float c[2][NT][4];
+    // ---- state: c in (accumulator) registers, h in the LDS columns (a shared first step never reads the old h)
+    float c[2][NT][4];                                            // (values live in AGPRs: agpr_put / agpr_get)
     {
         const float* const st = has_state ? d.state_in + (size_t)state_row * 2 * 2 * HP : nullptr;
 #pragma unroll
@@ -2660,7 +2715,7 @@ __global__ void __launch_bounds__(256, 1) dec_seq_kernel(const LstmSeqArgs a) {
                     if (!shared0) hv = *(const float4*)ps;
                     cv = *(const float4*)(ps + HP);
                 }
-                c[l][i][0] = cv.x; c[l][i][1] = cv.y; c[l][i][2] = cv.z; c[l][i][3] = cv.w;
+                c[l][i][0] = agpr_put(cv.x); c[l][i][1] = agpr_put(cv.y); c[l][i][2] = agpr_put(cv.z); c[l][i][3] = agpr_put(cv.w);
                 if (!shared0) {
                     hb[(4 * i + 0) * 64] = hv.x; hb[(4 * i + 1) * 64] = hv.y;
                     hb[(4 * i + 2) * 64] = hv.z; hb[(4 * i + 3) * 64] = hv.w;
@@ -2686,7 +2741,7 @@ __global__ void __launch_bounds__(256, 1) dec_seq_kernel(const LstmSeqArgs a) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) bf[i] = bias_frag(a.b[l], 4 * p + i, lv);
     };
-    float4 fa[4 * kHeadTiles], fb[4 * kHeadTiles];                // the head's fragment buffers (dec_seq_head)
+    float4 fa[4 * kHeadTiles];                                    // the head's fragment buffer (dec_seq_head)
     auto head_fetch = [&](float (&bf)[4]) {
         const DenseLayerArg& ly = a.head.layer[0];
         const int lv = opaque(lane);
@@ -2735,7 +2790,7 @@ __global__ void __launch_bounds__(256, 1) dec_seq_kernel(const LstmSeqArgs a) {
                     }
                 } else {
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) acc[i] = bias_acc(bf[i]);
+                    for (int i = 0; i < 4; ++i) acc[i] = bias_acc(bf[i], lv < 32 ? 1.0f : 0.0f);
                 }
                 gemm_stream_buf1<4>(acc, a0, wr, voff, sb, NT * 1024u, nqs, [&](int q, float (&bv)[4]) {
                     const float* bp = (q < nqi) ? bin + (size_t)(4 * q) * 64 : hl + (size_t)(4 * (q - nqi)) * 64;
@@ -2748,10 +2803,25 @@ __global__ void __launch_bounds__(256, 1) dec_seq_kernel(const LstmSeqArgs a) {
                 float4 a0n[4];
                 if (p + 1 < NP) pass_fetch(l, p + 1, shared, bfn, a0n);
                 else if (l == 0) pass_fetch(1, 0, shared, bfn, a0n);
-                else if (head_now) head_fetch(bfn);
-                else pass_fetch(0, 0, false, bfn, a0n);           // (t + 1 == T: fetched and dropped)
+                else if (!head_now) pass_fetch(0, 0, false, bfn, a0n);       // (t + 1 == T: fetched and dropped)
+                else {                                            // (the head fetches for itself, behind this cell)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        bfn[i] = bf[i];
+                        a0n[i] = a0[i];
+                    }
+                }
                 __builtin_amdgcn_sched_barrier(0);
-                lstm_cell_pk(acc, reinterpret_cast<float(&)[4][4]>(c[l][4 * p]), hn);
+                float cc[4][4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int jj = 0; jj < 4; ++jj) cc[i][jj] = agpr_get(c[l][4 * p + i][jj]);
+                lstm_cell_pk(acc, cc, hn);
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int jj = 0; jj < 4; ++jj) c[l][4 * p + i][jj] = agpr_put(cc[i][jj]);
 #pragma unroll
                 for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -2767,6 +2837,8 @@ __global__ void __launch_bounds__(256, 1) dec_seq_kernel(const LstmSeqArgs a) {
                     a0[i] = a0n[i];
                 }
             }
+            // (the head's first fetches: in flight while the column is written)
+            if (l == 1 && head_now) head_fetch(bf);
             // every pass has read the layer's old h: the column takes the new one (natural k-step order)
             float* const colw = hcol(l) + opaque(lane);
 #pragma unroll
@@ -2784,7 +2856,7 @@ __global__ void __launch_bounds__(256, 1) dec_seq_kernel(const LstmSeqArgs a) {
             for (int i = 0; i < NT; ++i)
 #pragma unroll
                 for (int jj = 0; jj < 4; ++jj) act[4 * i + jj] = hold[i][jj];
-            dec_seq_head<NT>(a, act, lane, rowtile, t - a.t_out0, day_rel, sample, fa, fb, bf, t, wave);
+            dec_seq_head<NT>(a, act, lane, rowtile, t - a.t_out0, day_rel, sample, fa, bf, t, wave);
             if (t + 1 < T) pass_fetch(0, 0, false, bf, a0);
         }
         DSQ_STAMP(26);
@@ -5001,10 +5073,10 @@ static bool dec_seq_applies(const LstmSeqArgs& l, const Layout& lay, int T, int 
     const vsv_decode_in& d = l.din;
     const DenseChainArgs& hd = l.head;
     if (T < 1 || t_out0 >= T || state_out || z_out || d.gate_out || l.sv_gates) return false;
-    if (lay.NL != 2 || lay.NTd != 16 || lay.gru || l.kx > 32 || (l.kx & 3)) return false;
+    if (lay.NL != 2 || lay.NTd != 16 || lay.gru || l.kx > 16 || (l.kx & 3) || lay.L > 16) return false;
     if (hd.n_layers != 4 || hd.layer[0].nt != 4 || hd.layer[0].nq != 16) return false;
     for (int i = 1; i < 4; ++i)
-        if (hd.layer[i].nt < 1 || hd.layer[i].nt > 4 || hd.layer[i].nq != 16 || (i < 3 && hd.layer[i].nt != 4)) return false;
+        if (hd.layer[i].nt < 1 || hd.layer[i].nt > 4 || hd.layer[i].nq != 16) return false;
     for (int i = 0; i < 4; ++i)
         for (int t = 0; t < hd.layer[i].nt; ++t)                   // (band_tile clamps into non-empty bands)
             if (hd.layer[i].nqb[t] < 1 || hd.layer[i].q0[t] < 0 || hd.layer[i].q0[t] + hd.layer[i].nqb[t] > 16) return false;

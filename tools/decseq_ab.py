@@ -38,7 +38,8 @@ if "oracle" in which:
         dt = timed(lambda: paths.oracle_mc_windows(eng, v, e, C, n, C, H, S, seed=1, chunk_days=chunk))
         print(f"{tag} c3 oracle {n} days chunk {chunk}: {dt*1e3:.1f} ms  {n*S*H/dt:.3e} surf/s", flush=True)
 if "ar" in which:
-    n, H, Sa, Ca, chunk = 16, 30, 10000, 20, 8
-    va, ea = cal(n, 0, Ca, X, 78)
-    dt = timed(lambda: paths.ar_mc_windows(eng, va, ea, Ca, n, Ca, H, Sa, seed=1, chunk_days=chunk), n=1)
-    print(f"{tag} c4 AR {n} days x {Sa} x {H}: {dt*1e3:.1f} ms  {n*Sa*H/dt:.3e} surf/s", flush=True)
+    H, Sa, Ca = 30, 10000, 20
+    for n, chunk in ((16, 8), (26, 13), (32, 16)):
+        va, ea = cal(n, 0, Ca, X, 78)
+        dt = timed(lambda: paths.ar_mc_windows(eng, va, ea, Ca, n, Ca, H, Sa, seed=1, chunk_days=chunk), n=1)
+        print(f"{tag} c4 AR {n} days x {Sa} x {H} chunk {chunk}: {dt*1e3:.1f} ms  {n*Sa*H/dt:.3e} surf/s  ({dt/n*64:.2f} s per 64 days)", flush=True)

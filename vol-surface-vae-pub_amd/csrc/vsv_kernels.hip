@@ -21,6 +21,7 @@
 #include <cstdint>
 #include <cstdio>
 #include <mutex>
+#include <type_traits>
 
 #include "vsv_layout.h"
 
@@ -367,6 +368,59 @@ __device__ __forceinline__ void gemm_stream_buf1(f32x16 (&acc)[NC], float4 (&a0)
         __builtin_amdgcn_sched_barrier(0);
     }
     if (q < nq) mfma_quad<NC>(acc, a0, b0);
+}
+// The same with the fragments and B values requested TWO quads ahead (three buffers, loop unrolled by three): one quad
+// of products (1024 cycles, 0.43 us) does not cover an L2 round trip under load.  a0 holds quad 0 on entry.
+template <int NC, typename BL>
+__device__ __forceinline__ void gemm_stream_buf2(f32x16 (&acc)[NC], float4 (&a0)[NC], wrsrc_t r, unsigned voff, unsigned sbase,
+                                                 unsigned qsb, int nq, BL bl) {
+    static_assert(NC >= 2 && NC <= 5, "interleave pattern written for 2 - 5 tiles");
+    float4 a1[NC], a2[NC];
+    float b0[4], b1[4], b2[4];
+    auto pattern = [] {
+#pragma unroll
+        for (int i = 0; i < NC; ++i) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);    // one product
+            __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);    // one fragment load
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);    // one LDS read
+        }
+        __builtin_amdgcn_sched_group_barrier(0x008, 3 * NC - 4, 0);
+    };
+    const int last = nq - 1;
+    bl(0, b0);
+    {
+        const int q1 = last < 1 ? last : 1;
+        wload_buf<NC>(a1, r, voff, sbase + (unsigned)q1 * qsb);
+        bl(q1, b1);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    int q = 0;
+#pragma unroll 1
+    for (; q + 2 < nq; q += 3) {
+        wload_buf<NC>(a2, r, voff, sbase + (unsigned)(q + 2) * qsb);
+        bl(q + 2, b2);
+        mfma_quad<NC>(acc, a0, b0);
+        pattern();
+        __builtin_amdgcn_sched_barrier(0);
+        const int q3 = (q + 3 < last) ? q + 3 : last;
+        wload_buf<NC>(a0, r, voff, sbase + (unsigned)q3 * qsb);
+        bl(q3, b0);
+        mfma_quad<NC>(acc, a1, b1);
+        pattern();
+        __builtin_amdgcn_sched_barrier(0);
+        const int q4 = (q + 4 < last) ? q + 4 : last;
+        wload_buf<NC>(a1, r, voff, sbase + (unsigned)q4 * qsb);
+        bl(q4, b1);
+        mfma_quad<NC>(acc, a2, b2);
+        pattern();
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    if (q < nq) mfma_quad<NC>(acc, a0, b0);
+    if (q + 1 < nq) mfma_quad<NC>(acc, a1, b1);
 }
 __device__ __forceinline__ void tile_load_band_buf(float4 (&a)[kHalfQ], wrsrc_t r, unsigned voff, unsigned sbase, unsigned qsb,
                                                    int q0, int nqb) {
@@ -1093,11 +1147,12 @@ __device__ __forceinline__ f32x2 pk_sig_of_scaled(f32x2 t) {       // 1 / (1 + 2
     r.y = __builtin_amdgcn_rcpf(e.y);
     return r;
 }
-__device__ __forceinline__ void lstm_cell_pk(f32x16 (&acc)[4], float (&c)[4][4], float (&hn)[4][4]) {
+template <int NC = 4>
+__device__ __forceinline__ void lstm_cell_pk(f32x16 (&acc)[NC], float (&c)[NC][4], float (&hn)[NC][4]) {
     constexpr float kS = -1.4426950408889634f, kT = -2.885390081777927f;   // sigmoid / tanh exponent scales
     const f32x2 one = {1.0f, 1.0f}, two = {2.0f, 2.0f};
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < NC; ++i) {
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
             f32x2 ig, fg, rg, og;
@@ -2569,6 +2624,9 @@ __device__ __forceinline__ void dec_seq_head(const LstmSeqArgs& a, float (&act)[
     }
 }
 
+#ifndef VSV_DSEQ_STREAM
+#define VSV_DSEQ_STREAM gemm_stream_buf2
+#endif
 template <int NT>
 __global__ void __launch_bounds__(256, 1) dec_seq_kernel(const LstmSeqArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -2579,10 +2637,11 @@ __global__ void __launch_bounds__(256, 1) dec_seq_kernel(const LstmSeqArgs a) {
     if (rowtile >= a.n_rowtiles) return;                          // (no barriers below: a wave may leave alone)
     const vsv_decode_in& d = a.din;
     const int kx = a.kx, L = a.L, Lc = a.Lc, T = a.T;
-    // this wave's columns, without the lane: [h of layer 1 (and the head's activations) | h of layer 0 | x]
-    float* const hc1 = smem + (size_t)wave * (size_t)(kx + 2 * HPK) * 64;
-    float* const hc0 = hc1 + (size_t)HPK * 64;
-    float* const xs0 = hc0 + (size_t)HPK * 64;
+    // this wave's columns, without the lane: [x | h of layer 0 | h of layer 1] -- the B operands of a layer's stream,
+    // [input part | recurrent part], are then ONE run of k-steps (layer 0: x, h0; layer 1: h0, h1)
+    float* const xs0 = smem + (size_t)wave * (size_t)(kx + 2 * HPK) * 64;
+    float* const hc0 = xs0 + (size_t)kx * 64;
+    float* const hc1 = hc0 + (size_t)HPK * 64;
     auto hcol = [&](int l) { return l == 0 ? hc0 : hc1; };
 
     // ---- per-row constants
@@ -2759,6 +2818,7 @@ __global__ void __launch_bounds__(256, 1) dec_seq_kernel(const LstmSeqArgs a) {
         const bool head_now = t >= a.t_out0;
         float hold[NT][4];                                        // the layer's new h, unit 8*tile + 2*jj + hh
         const int dsq_t = t;                                      // (stamps)
+        (void)dsq_t;
         DSQ_STAMP(0);
 #pragma unroll
         for (int l = 0; l < 2; ++l) {
@@ -2775,7 +2835,6 @@ __global__ void __launch_bounds__(256, 1) dec_seq_kernel(const LstmSeqArgs a) {
                 const wrsrc_t wr = make_wrsrc(w);
                 const unsigned voff = (unsigned)lv * 16u, sb = (unsigned)p * 4096u;      // tiles 4p .. 4p + 3
                 const float* const bin = ((l == 0) ? xs0 : hc0) + lv + (size_t)(4 * q0) * 64;   // layer 1 reads h0
-                const float* const hl = hcol(l) + lv;
                 f32x16 acc[4];
                 if (shared) {
                     const int hh = lv >> 5;
@@ -2792,10 +2851,9 @@ __global__ void __launch_bounds__(256, 1) dec_seq_kernel(const LstmSeqArgs a) {
 #pragma unroll
                     for (int i = 0; i < 4; ++i) acc[i] = bias_acc(bf[i], lv < 32 ? 1.0f : 0.0f);
                 }
-                gemm_stream_buf1<4>(acc, a0, wr, voff, sb, NT * 1024u, nqs, [&](int q, float (&bv)[4]) {
-                    const float* bp = (q < nqi) ? bin + (size_t)(4 * q) * 64 : hl + (size_t)(4 * (q - nqi)) * 64;
+                VSV_DSEQ_STREAM<4>(acc, a0, wr, voff, sb, NT * 1024u, nqs, [&](int q, float (&bv)[4]) {
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) bv[j] = bp[j * 64];
+                    for (int j = 0; j < 4; ++j) bv[j] = bin[(size_t)(4 * q + j) * 64];
                 });
                 DSQ_STAMP(1 + 2 * (NP * l + p));
                 // the next stage's first fetches, in front of this pass's cell
@@ -2860,6 +2918,258 @@ __global__ void __launch_bounds__(256, 1) dec_seq_kernel(const LstmSeqArgs a) {
             if (t + 1 < T) pass_fetch(0, 0, false, bf, a0);
         }
         DSQ_STAMP(26);
+    }
+}
+
+// ---------------------------------------------------------------------------
+// enc_seq_kernel (round 3): an encoder's two memory layers and its latent head over T steps for MANY rows whose
+// first-layer input products come from a per-day table (pre_t: the per-row encoder steps of an autoregressive rollout,
+// vsv_encode_from_pre), on dec_seq_kernel's schedule: ONE WAVE per 32-row tile and SIMD, no workgroup barrier, the
+// cell state of both layers (2 x 13 x 4 registers) parked in accumulator registers, h of both layers in the wave's
+// own LDS columns [h0 | h1] (26 KB per wave), a layer's new h held in registers until the last pass has read the old
+// one.  The 13 gate tiles of a layer run in passes of 4 + 3 + 3 + 3; layer 0's accumulators start from the table
+// (requested one pass ahead), layer 1's from the bias fragment.  The head (one tile: z_mean | z_log_var, or the
+// context compression) multiplies the top layer's new h straight from registers with fragments that stay resident
+// for the whole launch, and stores (row, step, feature) as the dense chain behind lstm_kernel did.  Same products in
+// the same k order as lstm_kernel + dense_chain_kernel: results are bit-equal.
+// ---------------------------------------------------------------------------
+template <int NC, typename BL>
+__device__ __forceinline__ void enc_stream(f32x16 (&acc)[4], float4 (&a0)[4], wrsrc_t r, unsigned voff, unsigned sbase,
+                                           unsigned qsb, int nq, BL bl) {
+    float4 a1[4];
+    float b0[4], b1[4];
+    auto quad = [&](const float4 (&aa)[4], const float (&bb)[4]) {
+#pragma unroll
+        for (int i = 0; i < NC; ++i) acc[i] = mfma32(aa[i].x, bb[0], acc[i]);
+#pragma unroll
+        for (int i = 0; i < NC; ++i) acc[i] = mfma32(aa[i].y, bb[1], acc[i]);
+#pragma unroll
+        for (int i = 0; i < NC; ++i) acc[i] = mfma32(aa[i].z, bb[2], acc[i]);
+#pragma unroll
+        for (int i = 0; i < NC; ++i) acc[i] = mfma32(aa[i].w, bb[3], acc[i]);
+    };
+    auto pattern = [] {
+#pragma unroll
+        for (int i = 0; i < NC; ++i) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);    // one product
+            __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);    // one fragment load
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);    // one LDS read
+        }
+        __builtin_amdgcn_sched_group_barrier(0x008, 3 * NC - 4, 0);
+    };
+    bl(0, b0);
+    int q = 0;
+#pragma unroll 1
+    for (; q + 1 < nq; q += 2) {
+#pragma unroll
+        for (int i = 0; i < NC; ++i) a1[i] = bload(r, voff, sbase + (unsigned)(q + 1) * qsb + (unsigned)i * 1024u);
+        bl(q + 1, b1);
+        quad(a0, b0);
+        pattern();
+        __builtin_amdgcn_sched_barrier(0);
+        const int q2 = (q + 2 < nq) ? q + 2 : q + 1;
+#pragma unroll
+        for (int i = 0; i < NC; ++i) a0[i] = bload(r, voff, sbase + (unsigned)q2 * qsb + (unsigned)i * 1024u);
+        bl(q2, b0);
+        quad(a1, b1);
+        pattern();
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    if (q < nq) quad(a0, b0);
+}
+
+template <int NT>
+__global__ void __launch_bounds__(256, 1) enc_seq_kernel(const LstmSeqArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    static_assert(NT == 13, "built for 13 gate tiles (memory hidden 97..104)");
+    constexpr int HP = 8 * NT, HPK = 4 * NT;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const long rowtile = (long)blockIdx.x * (blockDim.x >> 6) + wave;
+    if (rowtile >= a.n_rowtiles) return;                          // (no barriers below: a wave may leave alone)
+    const int T = a.T;
+    float* const hc0 = smem + (size_t)wave * (size_t)(2 * HPK) * 64;   // this wave's columns, without the lane: [h0 | h1]
+    float* const hc1 = hc0 + (size_t)HPK * 64;
+    auto hcol = [&](int l) { return l == 0 ? hc0 : hc1; };
+    const long row_raw = rowtile * 32 + (lane & 31);
+    const bool row_ok = row_raw < a.n_rows;
+    const uint32_t row32 = (uint32_t)(row_ok ? row_raw : a.n_rows - 1);
+    const bool has_state = a.din.state_in != nullptr;             // wave-uniform
+    const uint32_t state_row = has_state ? (a.din.state_div == 1 ? row32 : row32 / (uint32_t)(a.din.state_div > 0x7fffffffL ? 0x7fffffffL : a.din.state_div)) : 0u;
+    // layer 0 streams its recurrent quads only: its input product comes from the table
+    const float4* const w0 = (const float4*)a.w[0] + (size_t)(a.kx >> 2) * NT * 64;
+    const float4* const w1 = (const float4*)a.w[1];
+    const DenseLayerArg& hd = a.head.layer[0];
+
+    // ---- state: c in accumulator registers, h in the LDS columns
+    float c[2][NT][4];
+    {
+        const float* const st = has_state ? a.din.state_in + (size_t)state_row * 2 * 2 * HP : nullptr;
+        const int hh0 = lane >> 5;
+#pragma unroll
+        for (int l = 0; l < 2; ++l) {
+            float* const hb = hcol(l) + lane;
+#pragma unroll
+            for (int i = 0; i < NT; ++i) {
+                float4 hv = make_float4(0.0f, 0.0f, 0.0f, 0.0f), cv = hv;
+                if (has_state) {
+                    const float* ps = st + (size_t)l * 2 * HP + 8 * i + 4 * hh0;
+                    hv = *(const float4*)ps;
+                    cv = *(const float4*)(ps + HP);
+                }
+                c[l][i][0] = agpr_put(cv.x); c[l][i][1] = agpr_put(cv.y); c[l][i][2] = agpr_put(cv.z); c[l][i][3] = agpr_put(cv.w);
+                hb[(4 * i + 0) * 64] = hv.x; hb[(4 * i + 1) * 64] = hv.y; hb[(4 * i + 2) * 64] = hv.z; hb[(4 * i + 3) * 64] = hv.w;
+            }
+        }
+    }
+    // the head's fragments (one output tile, NT quads) and bias fragment stay in registers
+    float4 hw[NT];
+#pragma unroll
+    for (int q = 0; q < NT; ++q) hw[q] = ((const float4*)hd.w)[q * 64 + lane];
+    const float hbf = bias_frag(hd.b, 0, lane);
+
+    // first fetches of a pass, requested one pass ahead: quad 0 of its weight stream and its accumulators' initial
+    // values -- layer 0: the table's gate values of step t (value j = 2 (16 tile + r) + lane half, column row + t *
+    // pre_tstride), layer 1: the bias fragments
+    auto fetch_w = [&](const float4* w, int tile0, int nc, float4 (&a0)[4]) {
+        const wrsrc_t wr = make_wrsrc(w);
+        const unsigned voff = (unsigned)opaque(lane) * 16u;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            if (i < nc) a0[i] = bload(wr, voff, (unsigned)(tile0 + i) * 1024u);
+    };
+    auto fetch_tab = [&](int t, int tile0, int nc, f32x16 (&acc)[4]) {
+        const int lv = opaque(lane);
+        const float* const p = a.pre_t + (size_t)(lv >> 5) * a.pre_stride + row32 + (size_t)t * a.pre_tstride;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            if (i < nc) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][r] = p[(size_t)(2 * (16 * (tile0 + i) + r)) * a.pre_stride];
+            }
+    };
+    auto fetch_bias = [&](int tile0, int nc, float (&bf)[4]) {
+        const int lv = opaque(lane);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            if (i < nc) bf[i] = bias_frag(a.b[1], tile0 + i, lv);
+    };
+
+    f32x16 acc[4];
+    float4 a0[4];
+    float bf[4];
+    fetch_w(w0, 0, 4, a0);
+    fetch_tab(0, 0, 4, acc);
+#pragma unroll 1
+    for (int t = 0; t < T; ++t) {
+        float hold[NT][4];                                        // the layer's new h, unit 8*tile + 2*jj + hh
+        // one pass: tiles tile0 .. tile0 + NC - 1 of layer l; then the next pass's first fetches, the cell, the hold
+        auto pass = [&](auto l_, auto tile0_, auto nc_, auto nl_, auto ntile0_, auto nnc_) {
+            constexpr int l = decltype(l_)::value, tile0 = decltype(tile0_)::value, NC = decltype(nc_)::value;
+            constexpr int nl = decltype(nl_)::value, ntile0 = decltype(ntile0_)::value, nnc = decltype(nnc_)::value;
+            const int lv = opaque(lane);
+            const wrsrc_t wr = make_wrsrc(l == 0 ? w0 : w1);
+            const unsigned voff = (unsigned)lv * 16u, sb = (unsigned)tile0 * 1024u;
+            if (l == 1) {
+#pragma unroll
+                for (int i = 0; i < NC; ++i) acc[i] = bias_acc(bf[i], lv < 32 ? 1.0f : 0.0f);
+            }
+            // layer 0: the recurrent quads (h0); layer 1: [h0 | h1], one run of k-steps
+            const float* const bin = hc0 + lv;
+            enc_stream<NC>(acc, a0, wr, voff, sb, NT * 1024u, l == 0 ? NT : 2 * NT, [&](int q, float (&bv)[4]) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) bv[j] = bin[(size_t)(4 * q + j) * 64];
+            });
+            f32x16 accn[4];
+            float4 a0n[4];
+            float bfn[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                a0n[i] = a0[i];
+                bfn[i] = bf[i];
+            }
+            if (nl == 0) {
+                if (l == 0 || t + 1 < T) {                        // (l == 1: the next step's first pass)
+                    fetch_w(w0, ntile0, nnc, a0n);
+                    fetch_tab(l == 0 ? t : t + 1, ntile0, nnc, accn);
+                }
+            } else {
+                fetch_w(w1, ntile0, nnc, a0n);
+                fetch_bias(ntile0, nnc, bfn);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            float cc[NC][4], hn[NC][4];
+#pragma unroll
+            for (int i = 0; i < NC; ++i)
+#pragma unroll
+                for (int jj = 0; jj < 4; ++jj) cc[i][jj] = agpr_get(c[l][tile0 + i][jj]);
+            {
+                f32x16 (&accv)[NC] = reinterpret_cast<f32x16 (&)[NC]>(acc);
+                lstm_cell_pk<NC>(accv, cc, hn);
+            }
+#pragma unroll
+            for (int i = 0; i < NC; ++i)
+#pragma unroll
+                for (int jj = 0; jj < 4; ++jj) {
+                    c[l][tile0 + i][jj] = agpr_put(cc[i][jj]);
+                    asm volatile("" : "+v"(hn[i][jj]));
+                    hold[tile0 + i][jj] = hn[i][jj];
+                }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                a0[i] = a0n[i];
+                bf[i] = bfn[i];
+                if (nl == 0) acc[i] = accn[i];
+            }
+        };
+        auto write_col = [&](int l) {
+            // every pass has read the layer's old h: the column takes the new one (natural k-step order)
+            float* const colw = hcol(l) + opaque(lane);
+#pragma unroll
+            for (int i = 0; i < NT; ++i)
+#pragma unroll
+                for (int jj = 0; jj < 4; ++jj) colw[(4 * i + jj) * 64] = hold[i][jj];
+        };
+        using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>;
+        using I3 = std::integral_constant<int, 3>; using I4 = std::integral_constant<int, 4>;
+        using I7 = std::integral_constant<int, 7>; using I10 = std::integral_constant<int, 10>;
+        pass(I0{}, I0{}, I4{}, I0{}, I4{}, I3{});
+        pass(I0{}, I4{}, I3{}, I0{}, I7{}, I3{});
+        pass(I0{}, I7{}, I3{}, I0{}, I10{}, I3{});
+        pass(I0{}, I10{}, I3{}, I1{}, I0{}, I4{});
+        write_col(0);
+        pass(I1{}, I0{}, I4{}, I1{}, I4{}, I3{});
+        pass(I1{}, I4{}, I3{}, I1{}, I7{}, I3{});
+        pass(I1{}, I7{}, I3{}, I1{}, I10{}, I3{});
+        pass(I1{}, I10{}, I3{}, I0{}, I0{}, I4{});
+        write_col(1);
+        // ---- head: one output tile on the top layer's new h, straight from registers (k-step 4 q + j <-> hold[q][j])
+        {
+            const int lv = opaque(lane);
+            const int hh = lv >> 5;
+            f32x16 hacc = bias_acc(hbf, lv < 32 ? 1.0f : 0.0f);
+#pragma unroll
+            for (int q = 0; q < NT; ++q) {
+                hacc = mfma32(hw[q].x, hold[q][0], hacc);
+                hacc = mfma32(hw[q].y, hold[q][1], hacc);
+                hacc = mfma32(hw[q].z, hold[q][2], hacc);
+                hacc = mfma32(hw[q].w, hold[q][3], hacc);
+            }
+            const long rr = rowtile * 32 + (lv & 31);
+            if (rr < a.n_rows) {
+                const int nh = a.head.out_f;
+                float* const po = a.head.out + ((size_t)rr * T + t) * nh + 4 * hh;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int fo = 8 * (r >> 2) + (r & 3);              // feature fo + 4 hh
+                    if (fo + 4 * hh < nh) po[fo] = hacc[r];
+                }
+            }
+        }
     }
 }
 
@@ -4958,6 +5268,22 @@ extern "C" int vsv_encode_from_pre(const vsv_dims* dims, const float* packed, in
     l.hout = hbuf; l.t_out0 = 0;
     l.din.state_in = state_in; l.din.state_div = state_in ? state_div : 1;
     l.state_out = state_out;
+    // many rows: both layers and the head in one launch on the one-wave-per-row-tile schedule (enc_seq_kernel;
+    // VSV_ESEQ=0 keeps lstm_kernel + the dense chain, VSV_ESEQ_MIN the row-tile threshold)
+    static const bool eseq_off = [] { const char* v = getenv("VSV_ESEQ"); return v && v[0] == '0'; }();
+    static const long eseq_min = [] { const char* v = getenv("VSV_ESEQ_MIN"); return v ? atol(v) : 1024L; }();
+    if (!eseq_off && rt >= eseq_min && lay.NL == 2 && lay.NTm == 13 && !lay.gru && !state_out && e.head.nq == 13 &&
+        e.head.nt == 1 && e.head.n_relu == 0 && e.nh <= 32) {
+        fill_dense(l.head, 0, packed, e.head);
+        l.head.n_layers = 1; l.head.out = out; l.head.out_f = e.nh; l.head.n_rows = n_rows; l.head.T = T;
+        l.hout = nullptr;
+        constexpr int wpb = 4;
+        const size_t lds = (size_t)wpb * (size_t)(8 * 13) * 64 * sizeof(float);
+        int rc = set_lds(enc_seq_kernel<13>, lds);
+        if (rc) return rc;
+        hipLaunchKernelGGL(enc_seq_kernel<13>, dim3((unsigned)((rt + wpb - 1) / wpb)), dim3(64 * wpb), lds, st, l);
+        return launch_check("enc_seq_kernel");
+    }
     int rc = launch_lstm<0>(l, lay.NTm, lay.NL, false, st);
     if (rc) return rc;
     DenseChainArgs h = {};

@@ -66,37 +66,77 @@ from vsv.synth import init_weights, make_config, synthetic_calendar  # noqa: E40
 
 
 def cpu_baseline(cfg, W, vol, ex, C, H, S, budget_s: float):
-    """The CPU port (oracle/torch_port.py: the torch CPU ops the reference calls,
-    float32, all host threads torch was given) in the reference's strongest loop
-    shape: one get_surface_given_conditions call per day with batch = S samples
-    (generate_surfaces.py:41-49), literal evaluation (all C+H decoder steps for
-    every sample, as the reference does).  Bounded sample: whole days until
-    `budget_s` seconds have been spent (>= 2 days after one untimed warm-up day)."""
+    """The CPU port (oracle/torch_port.py: the torch CPU ops the reference calls, all host threads torch was given),
+    SURVEY 8(d)'s loop shapes on a bounded sample of the same workload:
+      (ii)  the headline figure -- the reference's strongest usage, one get_surface_given_conditions call per day with
+            batch = S samples (generate_surfaces.py:41-49), literal evaluation (all C+H decoder steps for every sample),
+            float32: whole days until `budget_s` seconds have been spent (>= 2 days after one untimed warm-up day);
+      (i)   `literal` -- the reference's own Monte-Carlo loop, one B = 1 call per (day, sample) with a host copy of the
+            result (eval_scripts/eval_utils.py:29-38), float32: 4 days x 48 samples, scaled per call (a call's cost
+            does not depend on how many follow it);
+      fp64  `fp64` -- shape (ii) in float64, the generation scripts' default dtype (train_quantile_models.py:20)."""
     from oracle.torch_port import TorchPort
-    port = TorchPort(cfg, W, torch.float32)
     L = cfg["latent_dim"]
-    gen = torch.Generator().manual_seed(99)
     tv = torch.from_numpy(vol)
     te = None if ex is None else torch.from_numpy(ex)
+    n_win = max(1, vol.shape[0] - C)
 
-    def one_day(d):
-        win = tv[d:d + C].unsqueeze(0).expand(S, C, 5, 5).contiguous()
-        wex = None if te is None else te[d:d + C].unsqueeze(0).expand(S, C, te.shape[1]).contiguous()
-        z = torch.randn((S, C + H, L), generator=gen)
-        port.get_surface_given_conditions(win, wex, z, H)
+    def batched(dtype, budget):
+        port = TorchPort(cfg, W, dtype)
+        gen = torch.Generator().manual_seed(99)
+        v = tv.to(dtype)
+        e = None if te is None else te.to(dtype)
 
-    one_day(0)
-    t0 = time.perf_counter()
-    days = 0
-    while True:
-        one_day(days % max(1, vol.shape[0] - C))
-        days += 1
-        el = time.perf_counter() - t0
-        if days >= 2 and el >= budget_s:
-            break
-    return {"value": days * S * H / el, "unit": "surfaces/s", "cores": int(torch.get_num_threads()), "kind": "port",
-            "sample": f"{days} days x {S} samples x horizon {H}, one batched call per day (literal C+H decode), "
-                      f"torch CPU float32, {el:.1f} s"}
+        def one_day(d):
+            win = v[d:d + C].unsqueeze(0).expand(S, C, 5, 5).contiguous()
+            wex = None if e is None else e[d:d + C].unsqueeze(0).expand(S, C, e.shape[1]).contiguous()
+            z = torch.randn((S, C + H, L), generator=gen, dtype=dtype)
+            port.get_surface_given_conditions(win, wex, z, H)
+
+        one_day(0)
+        t0 = time.perf_counter()
+        days = 0
+        while True:
+            one_day(days % n_win)
+            days += 1
+            el = time.perf_counter() - t0
+            if days >= 2 and el >= budget:
+                break
+        return days, el
+
+    days, el = batched(torch.float32, budget_s)
+    out = {"value": days * S * H / el, "unit": "surfaces/s", "cores": int(torch.get_num_threads()), "kind": "port",
+           "sample": f"{days} days x {S} samples x horizon {H}, one batched call per day (literal C+H decode), "
+                     f"torch CPU float32, {el:.1f} s"}
+    try:
+        d64, e64 = batched(torch.float64, budget_s / 3)
+        out["fp64"] = {"value": d64 * S * H / e64, "unit": "surfaces/s",
+                       "sample": f"{d64} days x {S} samples, the same batched shape in float64 (the scripts' default), {e64:.1f} s"}
+        port = TorchPort(cfg, W, torch.float32)
+        gen = torch.Generator().manual_seed(98)
+        n_days_lit, n_smp_lit = 4, 48
+
+        def literal_day(d, n):
+            win = tv[d:d + C].unsqueeze(0).contiguous()
+            wex = None if te is None else te[d:d + C].unsqueeze(0).contiguous()
+            for _ in range(n):
+                z = torch.randn((1, C + H, L), generator=gen)
+                s_, _e = port.get_surface_given_conditions(win, wex, z, H)
+                s_.detach().cpu().numpy()
+
+        literal_day(0, 4)
+        t0 = time.perf_counter()
+        for d in range(n_days_lit):
+            literal_day(d % n_win, n_smp_lit)
+        el_lit = time.perf_counter() - t0
+        calls = n_days_lit * n_smp_lit
+        out["literal"] = {"value": calls * H / el_lit, "unit": "surfaces/s", "ms_per_call": el_lit / calls * 1e3,
+                          "sample": f"{n_days_lit} days x {n_smp_lit} samples, one B = 1 call per (day, sample) with a host "
+                                    f"copy (eval_utils.py:29-38), float32, {el_lit:.1f} s; per-call cost scales to "
+                                    f"{S} samples/day unchanged"}
+    except Exception as exc:                       # the extra shapes must not cost the bench line
+        out["extra_error"] = repr(exc)[:200]
+    return out
 
 
 def train_bench(dev, steps: int, cpu_steps: int):
@@ -136,6 +176,38 @@ def train_bench(dev, steps: int, cpu_steps: int):
            "config": {"workload": "BASELINE configs[1]: CVAEMemRand ex_loss train_step, batch 64, T ~ U[2,21], "
                                   "horizon 1, AdamW(1e-5), clip 1.0, dropout 0", "steps": steps,
                       "hip_graphs": bool(model._use_graphs())}}
+    # roofline of the step: algorithmic FLOPs (3 x forward; context stack over T - 1 steps, posterior
+    # encoder and decoder over T) over the step time, and the latency model that bounds it -- the step is a chain of
+    # eight recurrent launches (encoder | context encoder layer 0, layer 1, decoder layer 0, layer 1, and their BPTT
+    # mirrors), each walking T dependent time steps on the two-to-sixteen CUs a batch of 64 occupies: step time
+    # fitted as fixed + per_time_step * T from replays at T = 5 and T = 21
+    flt = flops_per_unit(5, 3, Q=3)
+    Ts = [int(b["surface"].shape[1]) for b in batches[3:]]
+    fl_step = float(np.mean([B * 3 * ((T - 1) * flt["ctx"] + T * (flt["enc"] + flt["dec_lstm"]) + flt["dec_head"]) for T in Ts]))
+    out["roofline"] = {"bound": "latency (recurrent chain), not mfma", "flops_per_step": fl_step,
+                       "achieved": fl_step / (dt / steps) / 1e12, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                       "frac": fl_step / (dt / steps) / 1e12 / PEAK_F32_MFMA_TFLOPS}
+    try:
+        fit = {}
+        for T in (5, 21):
+            b = warm[T]
+            for _ in range(3):
+                model.train_step(b, opt)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(20):
+                model.train_step(b, opt)
+            torch.cuda.synchronize()
+            fit[T] = (time.perf_counter() - t0) / 20
+        per_t = (fit[21] - fit[5]) / 16
+        out["roofline"]["critical_path"] = {
+            "ms_at_T5": fit[5] * 1e3, "ms_at_T21": fit[21] * 1e3, "us_per_time_step": per_t * 1e6,
+            "fixed_ms": (fit[5] - 5 * per_t) * 1e3, "mean_T": float(np.mean(Ts)),
+            "model_ms_at_mean_T": (fit[5] + (float(np.mean(Ts)) - 5) * per_t) * 1e3,
+            "note": "a time step of the chain = 8 dependent recurrent steps (4 forward, 4 BPTT) plus the per-T share of the "
+                    "T-parallel launches; the fixed part is the launches whose length does not grow with T"}
+    except Exception as exc:
+        out["roofline"]["critical_path"] = {"error": repr(exc)[:200]}
     # the same steps launched eagerly (config hip_graphs = False)
     try:
         model.config["hip_graphs"] = False
@@ -196,53 +268,118 @@ def train_bench(dev, steps: int, cpu_steps: int):
     return out
 
 
-def other_workloads(eng, dev, L, X, C, S):
-    """Secondary, smaller legs of the same engine so the other BASELINE configs carry a measured
-    figure too (not the headline; one untimed + one timed pass each):
-    c3 prior at horizon 30, c3 oracle (posterior) MC, c4-shaped autoregressive 30-step rollouts."""
+def _leg_roofline(kernel: str, flops: float, wall_s: float, events):
+    """Per-leg roofline: algorithmic FLOPs over the leg's wall time (whole job) and, where the decode
+    launches were bracketed by HIP events on their stream, over the summed launch time of that kernel."""
+    out = {"bound": "mfma", "kernel": kernel, "flops": flops, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+           "whole_job_achieved": flops / wall_s / 1e12, "whole_job_frac": flops / wall_s / 1e12 / PEAK_F32_MFMA_TFLOPS}
+    if events:
+        ms = float(sum(a.elapsed_ms(b) for a, b, _ in events))
+        out.update({"decode_launch_ms_total": ms, "decode_launches": len(events),
+                    "avg_launch_ms": ms / len(events)})
+    return out
+
+
+def other_workloads(eng, dev, L, X, C, S, cpu_budget: float):
+    """The other BASELINE configs on the same engine, each with its own roofline (one untimed + one timed pass):
+    c3 prior at horizon 30 and c3 oracle (posterior) MC at the config's 4000 days, c4-shaped autoregressive 30-step
+    rollouts (64 days x 10000), c0 (no_ex, context 20, latent 5, 256 days x 1000: the reference's CPU-runnable case)
+    on the GPU and on the CPU port."""
     from vsv import paths
+    from vsv.engine import Engine
     res = []
 
     def timed(fn):
-        fn()
+        fn(None)
         torch.cuda.synchronize()
+        ev = []
         t0 = time.perf_counter()
-        fn()
+        q = fn(ev)
         torch.cuda.synchronize()
-        return time.perf_counter() - t0
+        return time.perf_counter() - t0, ev, q
 
-    def cal(n, extra=0):
-        v, e = synthetic_calendar(n + extra, C, X, seed=77)
-        return torch.from_numpy(v).to(dev), (torch.from_numpy(e).to(dev) if X else None)
+    def cal(n, extra=0, ctx=C, x=X, seed=77):
+        v, e = synthetic_calendar(n + extra, ctx, x, seed=seed)
+        return torch.from_numpy(v).to(dev), (torch.from_numpy(e).to(dev) if x else None)
 
-    n, H = 1000, 30
+    fl = flops_per_unit(L, X, Q=1)
+    per_day_prefix = C * (fl["enc"] + fl["ctx"] + fl["dec_lstm"])
+
+    n, H = 4000, 30
     v, e = cal(n)
-    dt = timed(lambda: paths.prior_mc_windows(eng, v, e, C, n, C, H, S, seed=1, chunk_days=100))
+    dt, ev, q = timed(lambda evs: paths.prior_mc_windows(eng, v, e, C, n, C, H, S, seed=1, decode_events=evs))
+    check_quantiles(q, "c3 prior H=30")
+    flops = n * (per_day_prefix + S * (fl["dec_lstm_first"] + (H - 1) * fl["dec_lstm"] + H * fl["dec_head"]))
     res.append({"workload": f"c3 prior MC, context {C}, latent {L}, {n} days x {S} samples x horizon {H}",
-                "value": n * S * H / dt, "unit": "surfaces/s", "ms": dt * 1e3})
-    n, H = 500, 1
+                "value": n * S * H / dt, "unit": "surfaces/s", "ms": dt * 1e3,
+                "roofline": _leg_roofline("dec_seq_kernel<16> (T-step fused MC decode, one wave per row tile)", flops, dt, ev)})
+    del v, e, q
+    n, H = 4000, 1
     v, e = cal(n, H)
-    dt = timed(lambda: paths.oracle_mc_windows(eng, v, e, C, n, C, H, S, seed=1, chunk_days=50))
+    dt, ev, q = timed(lambda evs: paths.oracle_mc_windows(eng, v, e, C, n, C, H, S, seed=1, decode_events=evs))
+    check_quantiles(q, "c3 oracle")
+    flops = n * ((C + H) * fl["enc"] + C * fl["ctx"] + S * ((C + H) * fl["dec_lstm"] + H * fl["dec_head"]))
     res.append({"workload": f"c3 oracle (posterior) MC, context {C}, latent {L}, {n} days x {S} samples x horizon {H} "
                             f"(every sample decodes all {C + H} positions)",
-                "value": n * S * H / dt, "unit": "surfaces/s", "ms": dt * 1e3})
-    # c4 at 64 days x 10000 rollouts x 30 steps (19.2 M surfaces): one untimed 8-day pass, then the timed 64 days
-    n, H, Sa, Ca, chunk = 64, 30, 10000, 20, 8
-    va, ea = synthetic_calendar(n, Ca, X, seed=78)
-    va = torch.from_numpy(va).to(dev)
-    ea = torch.from_numpy(ea).to(dev) if X else None
-    paths.ar_mc_windows(eng, va, ea, Ca, chunk, Ca, H, Sa, seed=1, chunk_days=chunk)
+                "value": n * S * H / dt, "unit": "surfaces/s", "ms": dt * 1e3,
+                "roofline": _leg_roofline("dec_seq_kernel<16> (decoder over all C+H positions per sample)", flops, dt, ev)})
+    del v, e, q
+    # c4 at 64 days x 10000 rollouts x 30 steps (19.2 M surfaces): one untimed chunk, then the timed 64 days
+    n, H, Sa, Ca = 64, 30, 10000, 20
+    va, ea = cal(n, 0, Ca, X, 78)
+    paths.ar_mc_windows(eng, va, ea, Ca, 13, Ca, H, Sa, seed=1)
     torch.cuda.synchronize()
+    ev = []
     t0 = time.perf_counter()
-    q = paths.ar_mc_windows(eng, va, ea, Ca, n, Ca, H, Sa, seed=1, chunk_days=chunk)
+    q = paths.ar_mc_windows(eng, va, ea, Ca, n, Ca, H, Sa, seed=1, decode_events=ev)
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     check_quantiles(q, "c4 autoregressive MC")
+    # FLOPs actually required after the build's de-duplication (what the roofline fraction is priced on): at rollout
+    # step k the first C - k days of a window are still the day's own context (run once per DAY), the other
+    # min(k, C) days are the rollout's own (per row; their conv embedding and first-layer input product computed
+    # once, when the day was generated), and every row decodes its one new day
+    Hm, E = 100, 125 + X
+    enc_rec = 2 * 4 * Hm * Hm + 2 * 4 * Hm * 2 * Hm                  # a memory step whose input product comes from the table
+    enc_tab = 2 * 25 * 9 * 55 + 2 * 4 * Hm * E                       # conv embedding + first-layer input product of one day
+    flops = 0.0
+    for k in range(H):
+        ns, nr = max(Ca - k, 0), min(k, Ca)
+        flops += n * ns * (fl["enc"] + fl["ctx"] + fl["dec_lstm"])
+        flops += n * Sa * (nr * (2 * enc_rec + 2 * Hm * 3 * L + fl["dec_lstm"]) + fl["dec_lstm"] + fl["dec_head"])
+        if k < H - 1:
+            flops += n * Sa * 2 * enc_tab
+    # SURVEY 8(d)'s counted figure, for reference: per (rollout, step) a full re-encode of the C-day window by both
+    # encoders, C decoder memory steps and one decoded day -- no sharing (the build skips part of that work, so this
+    # fraction can exceed 1)
+    flops_survey = n * Sa * H * (Ca * (fl["enc"] + fl["ctx"] + fl["dec_lstm"]) + fl["dec_lstm"] + fl["dec_head"])
     res.append({"workload": f"c4-shaped autoregressive MC, context {Ca}, latent {L}, ex_feats {X}, {n} days x {Sa} "
-                            f"rollouts x {H} steps in chunks of {chunk} days (each step re-encodes its {Ca}-day window; "
+                            f"rollouts x {H} steps in chunks of 13 days (each step re-encodes its {Ca}-day window; "
                             f"the days a day's rollouts still share once per day; every step's p05/p50/p95 over the "
                             f"{Sa} rollouts reduced on the side stream, samples never stored)",
-                "value": n * Sa * H / dt, "unit": "surfaces/s", "ms": dt * 1e3})
+                "value": n * Sa * H / dt, "unit": "surfaces/s", "ms": dt * 1e3,
+                "roofline": dict(_leg_roofline("enc_seq_kernel<13> x2 + dec_seq_kernel<16> per rollout step", flops, dt, ev),
+                                 survey_count_flops=flops_survey,
+                                 survey_count_frac=flops_survey / dt / 1e12 / PEAK_F32_MFMA_TFLOPS)})
+    del va, ea, q
+    # c0: the reference's own CPU-runnable configuration
+    L0, X0, C0, n0 = 5, 0, 20, 256
+    cfg0 = make_config(L0, X0)
+    W0 = init_weights(cfg0, 0, 1.0, np.float32)
+    eng0 = Engine(cfg0, W0, dev)
+    v0np, _ = synthetic_calendar(n0, C0, X0, seed=79)
+    v0 = torch.from_numpy(v0np).to(dev)
+    dt, ev, q = timed(lambda evs: paths.prior_mc_windows(eng0, v0, None, C0, n0, C0, 1, S, seed=1, decode_events=evs))
+    check_quantiles(q, "c0 prior MC")
+    fl0 = flops_per_unit(L0, X0, Q=1)
+    flops = n0 * (C0 * (fl0["enc"] + fl0["ctx"] + fl0["dec_lstm"]) + S * (fl0["dec_lstm_first"] + fl0["dec_head"]))
+    leg = {"workload": f"c0 prior MC (no ex-features), context {C0}, latent {L0}, {n0} days x {S} samples x horizon 1",
+           "value": n0 * S / dt, "unit": "surfaces/s", "ms": dt * 1e3,
+           "roofline": _leg_roofline("mc_decode1_kernel<16> + the 20-step date-range prefix of 256 days (latency-bound: "
+                                     "8 row tiles per stack)", flops, dt, ev)}
+    if cpu_budget > 0:
+        leg["cpu_baseline"] = cpu_baseline(cfg0, W0, v0np, None, C0, 1, S, min(cpu_budget, 6.0))
+    res.append(leg)
     return res
 
 
@@ -432,7 +569,7 @@ def main(argv=None):
     if rank == 0 and world == 1 and args.train_steps > 0:
         out["train"] = train_bench(dev, args.train_steps, 10 if args.cpu_budget > 0 else 0)
     if world == 1 and args.others:
-        out["other_workloads"] = other_workloads(eng, dev, L, X, C, S)
+        out["other_workloads"] = other_workloads(eng, dev, L, X, C, S, args.cpu_budget)
     if rank == 0:
         print(json.dumps(out), flush=True)
     if dist:

@@ -58,6 +58,21 @@ def prior_generate(eng: Engine, surf_ctx: torch.Tensor, ex_ctx: Optional[torch.T
 
 SPLIT_MAX_DAYS = 6000      # beyond: the fused three-segment schedule (see _context_prefix)
 
+# The T-step decode / rollout kernels (dec_seq_kernel, enc_seq_kernel) run ONE wave per 32-row tile and SIMD: 1024 row
+# tiles (32768 rows) are resident at a time and a tile lives for the whole sequence, so a launch is quantised in rounds
+# of 1024 tiles.  Chunks are sized to fill their last round.
+ROUND_ROWS = 1024 * 32
+
+
+def _arm_decode_events(eng: Engine, decode_events, rows: int):
+    """Benchmark instrumentation: a (start, stop) hipevents.Event pair around the NEXT vsv_decode launch."""
+    if decode_events is None:
+        return
+    from .hipevents import Event
+    ev = (Event(), Event())
+    eng.lib.vsv_profile_next_decode(ev[0].h, ev[1].h)
+    decode_events.append((ev[0], ev[1], rows))
+
 
 def _context_prefix(eng: Engine, sv: torch.Tensor, se: Optional[torch.Tensor], n_days: int, ctx_len: int,
                     n_seg: Optional[int] = None):
@@ -232,11 +247,7 @@ def prior_mc_windows(eng: Engine, vol: torch.Tensor, ex: Optional[torch.Tensor],
     outs = []
     for d0 in range(0, n_days, chunk_days):
         nd = min(chunk_days, n_days - d0)
-        if decode_events is not None:
-            from .hipevents import Event
-            ev = (Event(), Event())
-            eng.lib.vsv_profile_next_decode(ev[0].h, ev[1].h)
-            decode_events.append((ev[0], ev[1], nd * n_samples))
+        _arm_decode_events(eng, decode_events, nd * n_samples)
         # one channel wanted: the decoder neither computes nor stores the others
         r = eng.decode(nd * n_samples, horizon, 0, state_in=state[d0:d0 + nd], state_div=n_samples,
                        gate_in=gates[d0:d0 + nd], seed=seed, S=n_samples, day0=day_index0 + d0,
@@ -384,7 +395,7 @@ def ar_offset_windows(eng: Engine, vol: torch.Tensor, ex: Optional[torch.Tensor]
 def ar_generate(eng: Engine, surf_ctx: torch.Tensor, ex_ctx: Optional[torch.Tensor], horizon: int,
                 n_samples: int = 1, eps: Optional[torch.Tensor] = None, seed: int = 0, day0: int = 0,
                 share_prefix: Optional[bool] = None, reduce_qs: Optional[Sequence[float]] = None,
-                reduce_channel: Optional[int] = 1):
+                reduce_channel: Optional[int] = 1, decode_events=None):
     """generate_autoregressive_sequence (cvae_with_mem_randomized.py:717-807) for D
     context windows x S samples: every row rolls its OWN window -- each step is a
     one-day prior generation (:776), whose p50 channel (:786/:794) and predicted
@@ -438,6 +449,7 @@ def ar_generate(eng: Engine, surf_ctx: torch.Tensor, ex_ctx: Optional[torch.Tens
             # the window is all generated days k-C .. k-1
             enc = eng.encode_from_pre(0, ptab[0][k - C:], R, C)
             ctx = eng.encode_from_pre(1, ptab[1][k - C:], R, C)
+            _arm_decode_events(eng, decode_events, R)
             r = eng.decode(R, C + 1, C, ctx=ctx, zb=enc[..., :L].contiguous(), eps=ek, eps_t0=C,
                            seed=seed, S=S, day0=day0, step0=k, out_mode=om)
         elif share and k < C:
@@ -448,12 +460,14 @@ def ar_generate(eng: Engine, surf_ctx: torch.Tensor, ex_ctx: Optional[torch.Tens
                                            D, ns, want_state=k > 0)
             pre = eng.decode(D, ns, ns, ctx=ctx_s, zb=enc_s[..., :L].contiguous(), want_state=True, want_gates=k == 0)
             if k == 0:
+                _arm_decode_events(eng, decode_events, R)
                 r = eng.decode(R, 1, 0, state_in=pre["state"], state_div=S, gate_in=pre["gates"],
                                eps=ek, eps_t0=0, seed=seed, S=S, day0=day0, step0=0, out_mode=om)
             else:
                 # the rows' own generated days 0..k-1, from their tables
                 enc_r = eng.encode_from_pre(0, ptab[0], R, k, state_in=st_e, state_div=S)
                 ctx_r = eng.encode_from_pre(1, ptab[1], R, k, state_in=st_c, state_div=S)
+                _arm_decode_events(eng, decode_events, R)
                 r = eng.decode(R, k + 1, k, ctx=ctx_r, zb=enc_r[..., :L].contiguous(),
                                state_in=pre["state"], state_div=S,
                                eps=ek, eps_t0=k, seed=seed, S=S, day0=day0, step0=k, out_mode=om)
@@ -462,6 +476,7 @@ def ar_generate(eng: Engine, surf_ctx: torch.Tensor, ex_ctx: Optional[torch.Tens
             wex = exb[:, k:] if X > 0 else None
             enc, ctx = eng.encode_both_strided(win, TT * 25, 25, wex, TT * X, X, R, C)
             zm = enc[..., :L].contiguous()
+            _arm_decode_events(eng, decode_events, R)
             r = eng.decode(R, C + 1, C, ctx=ctx, zb=zm, eps=ek, eps_t0=C,
                            seed=seed, S=S, day0=day0, step0=k, out_mode=om)
         if reducing:
@@ -542,8 +557,8 @@ def ar_offset_generate(eng: Engine, surf_ctx: torch.Tensor, ex_ctx: Optional[tor
 
 def ar_mc_windows(eng: Engine, vol: torch.Tensor, ex: Optional[torch.Tensor], first_day: int, n_days: int,
                   ctx_len: int, horizon: int, n_samples: int, seed: int = 0,
-                  qs: Sequence[float] = (5, 50, 95), channel: Optional[int] = 1, chunk_days: int = 8,
-                  day_index0: Optional[int] = None):
+                  qs: Sequence[float] = (5, 50, 95), channel: Optional[int] = 1, chunk_days: Optional[int] = None,
+                  day_index0: Optional[int] = None, decode_events=None):
     """Autoregressive MC backfill with on-device quantile reduction (BASELINE configs[4]):
     for every day, S independent `horizon`-day rollouts from the window vol[day-C:day],
     reduced to np.percentile-style quantiles -> (n_days, horizon, nq, 5, 5) for one decoder
@@ -557,6 +572,11 @@ def ar_mc_windows(eng: Engine, vol: torch.Tensor, ex: Optional[torch.Tensor], fi
     Q, S = eng.Q, n_samples
     if n_days == 0:
         return _empty_quantiles(eng, horizon, len(qs), channel)
+    if not chunk_days:
+        # days per chunk: the day count whose rollouts come closest to filling a whole number (<= 4) of rounds of
+        # resident row tiles (10 000 rollouts a day: 13 days = 3.97 rounds; 8 days = 2.44 rounds ran 23 % slower)
+        cands = range(1, max(1, min(n_days, 4 * ROUND_ROWS // max(1, S))) + 1)
+        chunk_days = max(cands, key=lambda d: (d * S / ROUND_ROWS) / -(-d * S // ROUND_ROWS) + 1e-6 * d)
     outs = []
     for d0 in range(0, n_days, chunk_days):
         nd = min(chunk_days, n_days - d0)
@@ -564,15 +584,15 @@ def ar_mc_windows(eng: Engine, vol: torch.Tensor, ex: Optional[torch.Tensor], fi
         win = vol[w0:w0 + nd + ctx_len - 1].reshape(-1, 25).unfold(0, ctx_len, 1).permute(0, 2, 1)   # (nd, C, 25)
         wex = ex[w0:w0 + nd + ctx_len - 1].unfold(0, ctx_len, 1).permute(0, 2, 1) if eng.X > 0 else None
         q, _ = ar_generate(eng, win.reshape(nd, ctx_len, 5, 5), wex, horizon, S, seed=seed, day0=day_index0 + d0,
-                           reduce_qs=qs, reduce_channel=channel)
+                           reduce_qs=qs, reduce_channel=channel, decode_events=decode_events)
         outs.append(q)
     return torch.cat(outs, dim=0)
 
 
 def oracle_mc_windows(eng: Engine, vol: torch.Tensor, ex: Optional[torch.Tensor], first_day: int, n_days: int,
                       ctx_len: int, horizon: int, n_samples: int, seed: int = 0,
-                      qs: Sequence[float] = (5, 50, 95), channel: Optional[int] = 1, chunk_days: int = 64,
-                      day_index0: Optional[int] = None):
+                      qs: Sequence[float] = (5, 50, 95), channel: Optional[int] = 1, chunk_days: Optional[int] = None,
+                      day_index0: Optional[int] = None, decode_events=None):
     """Oracle (posterior) MC generation over a date range (the teacher-forcing generators,
     experiments/backfill/context20/generate_vae_tf_sequences.py:109-123): for every day the
     model sees context AND target, vol[day-C : day+H], and z is SAMPLED from the posterior at
@@ -595,9 +615,14 @@ def oracle_mc_windows(eng: Engine, vol: torch.Tensor, ex: Optional[torch.Tensor]
     se = ex[w0:] if X > 0 else None
     enc, ctx = eng.encode_both_windows(sv, se, n_days, T, ctx_len)   # posterior on context + target
     zm, zl = enc[..., :L].contiguous(), enc[..., L:].contiguous()
+    if not chunk_days:
+        # as prior_mc_windows: as many days per decode launch as fit 2 GiB of samples (long launches waste the
+        # smallest share of their last round of resident row tiles)
+        chunk_days = max(1, (1 << 31) // (n_samples * horizon * (Q if channel is None else 1) * 25 * 4))
     outs = []
     for d0 in range(0, n_days, chunk_days):
         nd = min(chunk_days, n_days - d0)
+        _arm_decode_events(eng, decode_events, nd * n_samples)
         r = eng.decode(nd * n_samples, T, ctx_len, ctx=ctx[d0:d0 + nd], ctx_div=n_samples,
                        zb=zm[d0:d0 + nd], lv=zl[d0:d0 + nd], z_div=n_samples,
                        seed=seed, S=n_samples, day0=day_index0 + d0,

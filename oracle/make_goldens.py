@@ -745,6 +745,56 @@ def main_round2():
     case_gmm("g12_gmm_noex12_C20_H7_K5", vo.make_config(12, 0), 44, 2.0, 4, 20, 7, 5)
 
 
+def case_optimizer_step(name, cfg, seed, scale, B, T, horizon, n_steps=2, lr=1e-5):
+    """G15: whole train_step calls of the reference (cvae_with_mem_randomized.py:1101-1131: zero_grad, forward with the
+    injected eps, pinball + ex-feature + KL loss, backward, clip_grad_norm_(1.0), optimizer.step()) with the optimizer
+    every trainer builds, AdamW(model.parameters(), lr) (vae/utils.py:49), lr 1e-5, dropout 0, in FLOAT32 (the build's
+    arithmetic and the reference's CPU path).  Stored per parameter: 64 sampled entries before and after each step, the
+    clipped gradient of each step at the same entries (Adam's update is lr * m / (sqrt(v) + eps): entries whose
+    gradient is below ~1e-6 are ill-conditioned in float32 and the test skips them), sum and norm after the last."""
+    np_dtype = np.float32
+    model, _ = build_reference(cfg, seed, scale, np_dtype)
+    model.train()                                   # dropout is 0 in cfg
+    rng = np.random.Generator(np.random.PCG64(15000 + seed))
+    X, L = cfg["ex_feats_dim"], cfg["latent_dim"]
+    surf, ex = synth(rng, B, T, X, np_dtype)
+    eps = rng.standard_normal((n_steps, B, T, L)).astype(np_dtype)
+    x = {"surface": torch.from_numpy(surf)}
+    if X:
+        x["ex_feats"] = torch.from_numpy(ex)
+    model.horizon = horizon
+    opt = torch.optim.AdamW(model.parameters(), lr=lr)
+    d = dict(surface=surf, eps=eps, horizon=horizon, seed=seed, scale=scale, lr=np.float64(lr), n_steps=n_steps)
+    if X:
+        d["ex_feats"] = ex
+    idx = {}
+    for n, p_ in model.named_parameters():
+        flat = p_.detach().numpy().ravel()
+        idx[n] = np.linspace(0, flat.size - 1, num=min(flat.size, 64)).astype(np.int64)
+        d["idx/" + n] = idx[n]
+        d["w0/" + n] = flat[idx[n]].copy()
+    for k in range(n_steps):
+        with NoiseQueue() as nq:
+            nq.push(eps[k])
+            out = model.train_step(x, opt)
+        d[f"loss{k + 1}"] = np.float64(t2n(out["loss"]).reshape(-1)[0])
+        for n, p_ in model.named_parameters():
+            d[f"w{k + 1}/" + n] = p_.detach().numpy().ravel()[idx[n]].copy()
+            d[f"g{k + 1}/" + n] = p_.grad.detach().numpy().ravel()[idx[n]].copy()       # clipped (:1128)
+    for n, p_ in model.named_parameters():
+        w = p_.detach().numpy().astype(np.float64)
+        d["sum/" + n] = np.float64(w.sum())
+        d["norm/" + n] = np.float64(np.sqrt((w ** 2).sum()))
+    torch.set_default_dtype(torch.float32)
+    save(name, cfg, d)
+
+
+def main_round3():
+    case_optimizer_step("g15_optstep_ex5_B8_T21_h1", vo.make_config(5, 3, re_feat_weight=1.0, ex_loss_on_ret_only=True,
+                                                                     ex_feats_loss_type="l2"), 60, 2.0, 8, 21, 1)
+    case_optimizer_step("g15_optstep_noex12_B4_T30_h7", vo.make_config(12, 0), 61, 2.0, 4, 30, 7)
+
+
 class UniformQueue:
     """Patches torch.rand_like (the legacy encoder's uniform reparameterisation noise, cvae_with_mem.py:157)."""
 
@@ -849,6 +899,9 @@ if __name__ == "__main__":
     elif len(sys.argv) > 1 and sys.argv[1] == "round2":
         os.makedirs(OUT, exist_ok=True)
         main_round2()
+    elif len(sys.argv) > 1 and sys.argv[1] == "round3":
+        os.makedirs(OUT, exist_ok=True)
+        main_round3()
     elif len(sys.argv) > 1 and sys.argv[1] == "dense":
         os.makedirs(OUT, exist_ok=True)
         main_dense()

@@ -254,3 +254,42 @@ def test_hidden_widths_run_on_the_built_tile_counts():
         assert np.isfinite(blob).all()
     with pytest.raises(NotImplementedError, match="mem_hidden"):
         dims_from_config(vo.make_config(5, 0, mem_hidden=200))
+
+
+def _frozen_configs():
+    import json
+    import os
+    from conftest import GOLDEN
+    return json.load(open(os.path.join(GOLDEN, "configs.json")))
+
+
+@pytest.mark.parametrize("entry", _frozen_configs(), ids=[e["name"] for e in _frozen_configs()])
+def test_reference_driver_configs_construct_with_the_reference_contract(entry):
+    """The literal config dicts of the reference's training drivers (tests/golden/configs.json, frozen by
+    oracle/freeze_configs.py from the drivers' own source): the class built from each -- under the default dtype the
+    driver sets -- mutates its config as the reference's check_input / __init__ do and has the reference's state_dict,
+    name for name, shape for shape, dtype for dtype."""
+    import torch
+    from vae.cvae_conditional_prior import CVAEMemRandConditionalPrior
+    from vae.cvae_with_mem_randomized import CVAEMemRand
+    cls = CVAEMemRandConditionalPrior if entry["model_class"] == "CVAEMemRandConditionalPrior" else CVAEMemRand
+    cfg = dict(entry["config"], device="cpu")
+    cfg["feat_dim"] = tuple(cfg["feat_dim"])
+    old = torch.get_default_dtype()
+    torch.set_default_dtype(getattr(torch, entry["default_dtype"]))
+    try:
+        model = cls(cfg)
+        sd = model.state_dict()
+        got = [[k, list(v.shape), str(v.dtype).replace("torch.", "")] for k, v in sd.items()]
+        assert got == entry["state_dict"]
+        assert int(sum(p.numel() for p in model.parameters())) == entry["n_params"]
+        want_cfg = dict(entry["mutated_config"])
+        have = {k: (list(v) if isinstance(v, tuple) else (str(v) if isinstance(v, torch.device) else v))
+                for k, v in model.config.items()}
+        for k in ("device",):
+            want_cfg.pop(k, None)
+            have.pop(k, None)
+        have = {k: v for k, v in have.items() if k != "hip_graphs"}
+        assert have == want_cfg
+    finally:
+        torch.set_default_dtype(old)

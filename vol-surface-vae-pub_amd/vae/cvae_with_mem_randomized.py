@@ -564,7 +564,8 @@ class CVAEMemRand(BaseVAE):
                     ex_l2=int(isinstance(self.ex_feats_loss_fn, nn.MSELoss)),
                     ex_weight=float(self.config["re_feat_weight"]), kl_weight=float(self.kl_weight))
 
-    def _loss_terms(self, x, horizon, want_grads):
+    def _loss_terms(self, x, horizon, want_grads, eps=None):
+        """eps (private, parity tests): the posterior noise (B, T, latent_dim) in place of the randn_like of :198."""
         surf, ex = self._batched(x)
         T = surf.shape[1]
         if T - horizon < 1:
@@ -578,14 +579,17 @@ class CVAEMemRand(BaseVAE):
             te = self._train_engine(pack=False)
             cache = self.__dict__.setdefault("_vsv_graphs", GraphCache())
             params = self._hip_named_params()
-            g = cache.get(te, params, surf, ex, horizon, self._loss_cfg(), p if self.config["mem_layers"] > 1 else 0.0)
-            losses, grads = g.run(surf, ex)
+            g = cache.get(te, params, surf, ex, horizon, self._loss_cfg(), p if self.config["mem_layers"] > 1 else 0.0,
+                          inject_eps=eps is not None)
+            losses, grads = g.run(surf, ex, eps)
             self.__dict__["_vsv_key"] = tuple((q.data_ptr(), q._version) for _, q in params)
             if ex is None:
                 losses["re_ex_feats"] = torch.zeros(1)
             return losses, grads
         te = self._train_engine()
-        losses, gp, _ = te.loss_and_grads(surf, ex, horizon, self._loss_cfg(), seed=self._draw_seed(),
+        if eps is not None:
+            eps = eps.to(surf.device, torch.float32).contiguous()
+        losses, gp, _ = te.loss_and_grads(surf, ex, horizon, self._loss_cfg(), eps=eps, seed=self._draw_seed(),
                                           want_grads=want_grads, dropout_p=p,
                                           dropout_seed=self._draw_seed() if p > 0 else 0)
         if ex is None:
@@ -717,17 +721,18 @@ class CVAEMemRand(BaseVAE):
             optimizer._opt_called = True                           # (what LRScheduler's wrapper of step() records)
         return True
 
-    def test_step(self, x):
-        """Reference :1265-1308: forward + losses, returns a dict of tensors."""
-        return self._loss_terms(x, self.horizon, False)[0]
+    def test_step(self, x, _eps=None):
+        """Reference :1265-1308: forward + losses, returns a dict of tensors.  _eps (private, like
+        train_step_multihorizon's _eps_per_horizon): injected posterior noise for parity tests."""
+        return self._loss_terms(x, self.horizon, False, eps=_eps)[0]
 
-    def train_step(self, x, optimizer: torch.optim.Optimizer):
+    def train_step(self, x, optimizer: torch.optim.Optimizer, _eps=None):
         """Reference :1076-1137: zero_grad, forward, pinball + ex-feature + KL loss, backward,
         clip_grad_norm_(1.0), optimizer.step().  Computed in float32 (the reference's CUDA path
         runs this under bf16 autocast; its CPU path, which the parity goldens pin, in float32).
         Returns a dict of tensors."""
         optimizer.zero_grad()
-        losses, gp = self._loss_terms(x, self.horizon, True)
+        losses, gp = self._loss_terms(x, self.horizon, True, eps=_eps)
         flat = self._accumulate_grads(gp, alias=True)
         if flat is not None:
             self._clip_flat_(flat, 1.0)

@@ -26,7 +26,7 @@ class GraphedLossGrads:
     """Captured (pack weights -> forward -> loss -> backward -> parameter gradients) for one shape."""
 
     def __init__(self, te, named_params, B: int, T: int, has_ex: bool, horizon: int, loss_cfg: dict,
-                 dropout_p: float):
+                 dropout_p: float, inject_eps: bool = False):
         self.te, self.eng = te, te.eng
         self.params = [p for _, p in named_params]
         self.named = list(named_params)
@@ -35,6 +35,8 @@ class GraphedLossGrads:
         self.surf = torch.zeros(B, T, 5, 5, dtype=torch.float32, device=dev)
         self.ex = torch.zeros(B, T, te.X, dtype=torch.float32, device=dev) if has_ex else None
         self.shape = (B, T)
+        # parity tests: the posterior noise comes from a static buffer the caller fills, not from torch.randn
+        self.eps_in = torch.zeros(B, T, te.L, dtype=torch.float32, device=dev) if inject_eps else None
         cur = torch.cuda.current_stream(dev)
         warm = torch.cuda.Stream(dev)
         warm.wait_stream(cur)
@@ -54,7 +56,7 @@ class GraphedLossGrads:
         B, T = self.shape
         with torch.no_grad():
             eng.set_weights_from_params(self.named)
-            eps = torch.randn(B, T, te.L, dtype=torch.float32, device=te.dev)
+            eps = self.eps_in if self.eps_in is not None else torch.randn(B, T, te.L, dtype=torch.float32, device=te.dev)
             seed = 0
             if self.p > 0:
                 seed = torch.empty(1, dtype=torch.int64, device=te.dev).random_()
@@ -65,9 +67,11 @@ class GraphedLossGrads:
                                ("loss", "re_surface", "re_ex_feats", "reconstruction_loss", "kl_loss")])
         return vec, grads, eng.packed
 
-    def run(self, surf: torch.Tensor, ex: Optional[torch.Tensor]):
+    def run(self, surf: torch.Tensor, ex: Optional[torch.Tensor], eps: Optional[torch.Tensor] = None):
         """-> (losses dict of 0-d float64 tensors (own memory), parameter gradients in parameter order:
         views of the graph's static output, valid until this object's next run)."""
+        if self.eps_in is not None:
+            self.eps_in.copy_(eps.to(self.eps_in.device, torch.float32), non_blocking=True)
         self.surf.copy_(surf, non_blocking=True)
         if self.ex is not None:
             self.ex.copy_(ex, non_blocking=True)
@@ -87,14 +91,15 @@ class GraphCache:
         self.capacity = capacity
         self._d: "OrderedDict[tuple, GraphedLossGrads]" = OrderedDict()
 
-    def get(self, te, named_params, surf, ex, horizon, loss_cfg: Dict, dropout_p: float) -> GraphedLossGrads:
+    def get(self, te, named_params, surf, ex, horizon, loss_cfg: Dict, dropout_p: float,
+            inject_eps: bool = False) -> GraphedLossGrads:
         B, T = surf.shape[:2]
-        key = (B, T, ex is not None, int(horizon), float(dropout_p),
+        key = (B, T, ex is not None, int(horizon), float(dropout_p), bool(inject_eps),
                tuple(sorted((k, tuple(v) if isinstance(v, (list, tuple)) else v) for k, v in loss_cfg.items())),
                tuple(p.data_ptr() for _, p in named_params), id(te))
         g = self._d.get(key)
         if g is None:
-            g = GraphedLossGrads(te, named_params, B, T, ex is not None, horizon, loss_cfg, dropout_p)
+            g = GraphedLossGrads(te, named_params, B, T, ex is not None, horizon, loss_cfg, dropout_p, inject_eps)
             self._d[key] = g
             while len(self._d) > self.capacity:
                 self._d.popitem(last=False)

@@ -12,10 +12,26 @@
  *     DEVICE pointer to float32 unless the name ends in _host;
  *   - `stream` is a hipStream_t passed as void*;
  *   - return value: 0 ok, <0 argument error (vsv_last_error() has the text),
- *     >0 a hipError_t from a launch;
- *   - nothing here allocates or frees device memory, synchronises the device
- *     or keeps global state; scratch space comes in through `ws` (size from the
- *     matching *_ws_bytes query); calls on different streams do not interact;
+ *     >0 a hipError_t from a launch or a runtime call;
+ *   - no entry point allocates or frees DEVICE memory or synchronises the device;
+ *     scratch space comes in through `ws` (size from the matching *_ws_bytes
+ *     query) and calls on different streams do not interact -- with these
+ *     exceptions, each repeated at its declaration:
+ *       . vsv_context_prefix creates and destroys HIP events (host objects) and
+ *         issues work onto the worker streams it is given; it joins them back
+ *         into `stream` on every return path;
+ *       . vsv_encode_windows_noalloc uses a device array built into the library,
+ *         one per GPU, shared by all calls on that GPU (overlapping calls race);
+ *   - state the library keeps between calls, all of it host-side:
+ *       . per THREAD: the text behind vsv_last_error() and the two events armed
+ *         by vsv_profile_next_decode (consumed by that thread's next vsv_decode);
+ *       . per DEVICE: the address of the built-in scratch array, looked up once
+ *         (vsv_init_device or the first vsv_encode_windows_noalloc on that device,
+ *         under a process-wide mutex);
+ *       . per PROCESS: the environment switches (VSV_DSEQ, VSV_ESEQ, VSV_*_WG ...:
+ *         kernel-choice overrides for A/B timing, INTEGRATION.md lists them) are
+ *         read once, at the first call that consults them;
+ *     nothing else: no handles, no caches, no weights are retained;
  *   - rows are independent sequences (a training sample, a day's context window,
  *     or one (day, MC sample) pair).
  */
@@ -29,7 +45,7 @@
 extern "C" {
 #endif
 
-#define VSV_ABI_VERSION 19
+#define VSV_ABI_VERSION 20
 #define VSV_MAX_CONV 4
 #define VSV_MAX_CHAIN 8
 #define VSV_MAX_INTERACT 3
@@ -98,9 +114,12 @@ int vsv_abi_version(void);
 const char *vsv_last_error(void);
 
 /* ---- weights -------------------------------------------------------------
- * The kernels read weights in an MFMA-fragment order (one 1 KiB block per
- * (4 k-steps x 16 output rows) tile of v_mfma_f32_16x16x4_f32; conv layers are
- * expanded to their dense 5x5 Toeplitz matrices).  vsv_pack_weights converts a
+ * The kernels read weights as ready-made A operands of v_mfma_f32_32x32x2_f32: a
+ * layer with K inputs and N outputs is stored as [k-quad = ceil(K/8)][tile = ceil(N/32)][64 lanes][4]
+ * floats (1 KiB per (k-quad, tile) block: one float4 per lane feeds the four k-pair MFMAs of
+ * the quad; lane l holds output row 32*tile + l%32, k = 8*quad + 2*j + l/32 in float j), biases
+ * behind the fragments; conv layers are expanded to their dense 5x5 Toeplitz matrices and
+ * only the k-quads inside each tile's band are multiplied.  vsv_pack_weights converts a
  * state_dict once on the host; the caller uploads the blob and passes its device
  * address as `packed` to every compute call.  Replaces: nn.Module parameter
  * storage read by nn.Conv2d/nn.ConvTranspose2d/nn.LSTM/nn.Linear at
@@ -219,8 +238,13 @@ int vsv_context_prefix(const vsv_dims *dims, const float *packed, const float *v
  * it are refused with -6 (e.g. 512 windows x 60 steps fit, 4000 x 60 do not).  The call makes no hipMalloc /
  * hipFree and calls no allocating routine; its first call on a device looks the array's address up
  * (hipGetSymbolAddress).  All calls on one GPU share that GPU's array: calls that overlap on one GPU (two
- * streams, two threads) race -- serialise them. */
+ * streams, two threads) race -- serialise them.
+ * UNDER HIP GRAPH CAPTURE: the address lookup loads the library's code object and must not happen inside a
+ * capture -- call vsv_init_device() (or make one eager call of this entry point) on the device first; after that
+ * the call only enqueues kernels.  vsv_init_device: resolves the current device's copy of the scratch array,
+ * 0 or a hipError_t; idempotent, thread-safe, no allocation. */
 #define VSV_NOALLOC_SCRATCH_BYTES (16u << 20)
+int vsv_init_device(void);
 int vsv_encode_windows_noalloc(const vsv_dims *dims, const float *packed, int which, const float *vol, const float *ex,
                                long n_windows, int T, float *out, void *stream);
 
@@ -288,8 +312,8 @@ int vsv_decode(const vsv_dims *dims, const float *packed, const vsv_decode_in *i
  * out[(v / inner)*nq*inner + k*inner + v % inner] is the k-th percentile of vector v
  * (inner = 25 gives (..., nq, 5, 5) per (day, step)).  q_host: nq percentiles in [0,100] (host).
  * S <= 1024: one wavefront sorts a vector in registers (bitonic network, cross-lane exchanges);
- * S <= 16384: one workgroup per vector, sorted in LDS.  A NaN sample is ordered arbitrarily
- * (np.percentile would return NaN). */
+ * S <= 16384: one workgroup per vector, sorted in LDS; S > 16384 is refused (-1): the reference's MC
+ * products use 1000 samples per day.  A NaN sample is ordered arbitrarily (np.percentile would return NaN). */
 int vsv_percentile(const float *in, long n_vec, int S, const double *q_host, int nq,
                    int inner, long group_stride, float *out, void *stream);
 
@@ -467,6 +491,9 @@ typedef struct vsv_loss {
     double *sums;
     int Hs;  float grad_scale;
     int surf_l2;                            /* 1: re_surface = F.mse_loss (legacy one-channel CVAEMem, cvae_with_mem.py:681; Q must be 1) */
+    const float *weights_dev;               /* optional DEVICE pair {ex_weight, kl_weight} read by the kernel in place of
+                                             * the two fields above: a captured graph follows a KL-annealing schedule
+                                             * (kl_weight changed between steps) without being captured again */
 } vsv_loss;
 int vsv_loss_grad(const vsv_loss *d, void *stream);
 

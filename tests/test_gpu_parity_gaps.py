@@ -136,3 +136,96 @@ def test_reference_driver_configs_train_and_generate(entry):
             assert gen[1].shape == (4, 1, X)
     finally:
         torch.set_default_dtype(old)
+
+
+def test_compiled_wrapper_and_orig_mod_checkpoint(tmp_path):
+    """The v3 trainer wraps the model in torch.compile(mode="default", dynamic=True)
+    (train_backfill_context60_latent12_v3_conditional_prior.py:298) and saves the WRAPPER's state_dict, whose keys
+    carry an "_orig_mod." prefix; every consumer strips it before load_state_dict
+    (teacher_forcing/generate_vae_tf_sequences.py:45-51).  Both through this class: a train_step and a forward on the
+    compiled wrapper, the prefixed checkpoint written, read back weights-only, stripped, loaded strictly, and the
+    reloaded model generating the same surfaces."""
+    from vae.cvae_with_mem_randomized import CVAEMemRand
+    cfg = dict(vo.make_config(12, 3), device="cuda:0")
+    torch.manual_seed(1)
+    model = CVAEMemRand(cfg)
+    compiled = torch.compile(model, mode="default", dynamic=True)
+    rng = np.random.default_rng(0)
+    x = {"surface": torch.from_numpy((0.2 + 0.1 * rng.standard_normal((8, 9, 5, 5))).astype(np.float32)),
+         "ex_feats": torch.from_numpy((0.01 * rng.standard_normal((8, 9, 3))).astype(np.float32))}
+    opt = torch.optim.AdamW(compiled.parameters(), lr=1e-5)
+    compiled.train()
+    out = compiled.train_step(x, opt)
+    assert bool(torch.isfinite(out["loss"]))
+    compiled.eval()
+    with torch.no_grad():
+        fw = compiled(x)                                           # OptimizedModule.__call__ -> the (opaque) forward
+    assert fw[0].shape == (8, 1, 3, 5, 5) and bool(torch.isfinite(fw[0]).all())
+    sd = compiled.state_dict()
+    assert all(k.startswith("_orig_mod.") for k in sd)
+    path = str(tmp_path / "ckpt.pt")
+    torch.save({"model": sd, "model_config": {k: v for k, v in cfg.items() if k != "device"}}, path)
+    data = torch.load(path, weights_only=True)
+    stripped = {(k.replace("_orig_mod.", "") if k.startswith("_orig_mod.") else k): v for k, v in data["model"].items()}
+    fresh = CVAEMemRand(dict(data["model_config"], device="cuda:0"))
+    fresh.load_state_dict(stripped)                                # strict
+    fresh.eval()
+    c = {k: v[:, :8] for k, v in x.items()}
+    torch.manual_seed(5)
+    a = model.get_surface_given_conditions(c)
+    torch.manual_seed(5)
+    b = fresh.get_surface_given_conditions(c)
+    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
+
+
+def test_frozen_parameters_are_left_alone():
+    """requires_grad = False on some parameters (fine-tuning): under the reference's autograd they get no .grad and the
+    optimizer skips them -- no update, no weight decay, no moments.  Same here, graphs on and off."""
+    from vae.cvae_with_mem_randomized import CVAEMemRand
+    rng = np.random.default_rng(0)
+    x = {"surface": torch.from_numpy((0.2 + 0.1 * rng.standard_normal((8, 9, 5, 5))).astype(np.float32)),
+         "ex_feats": torch.from_numpy((0.01 * rng.standard_normal((8, 9, 3))).astype(np.float32))}
+    for graphs in (True, False):
+        torch.manual_seed(1)
+        model = CVAEMemRand(dict(vo.make_config(12, 3), device="cuda:0", hip_graphs=graphs))
+        frozen = [p for n, p in model.named_parameters() if n.startswith("ctx_encoder.")]
+        assert frozen
+        for p in frozen:
+            p.requires_grad_(False)
+        before = {n: p.detach().clone() for n, p in model.named_parameters()}
+        opt = torch.optim.AdamW(model.parameters(), lr=1e-3)
+        model.train()
+        for _ in range(2):                                         # (the second step is the one-launch AdamW's turn)
+            model.train_step(x, opt)
+        for n, p in model.named_parameters():
+            if n.startswith("ctx_encoder."):
+                assert p.grad is None and torch.equal(p.detach(), before[n]) and p not in opt.state, n
+            else:
+                assert p.grad is not None and not torch.equal(p.detach(), before[n]), n
+
+
+def test_kl_annealing_replays_one_graph():
+    """kl_weight changed between steps (an annealing schedule): the captured graph reads the weight from device memory,
+    so the cache keeps ONE graph, and every step's numbers equal the eager path's at that weight."""
+    from vae.cvae_with_mem_randomized import CVAEMemRand
+    rng = np.random.default_rng(0)
+    x = {"surface": torch.from_numpy((0.2 + 0.1 * rng.standard_normal((8, 9, 5, 5))).astype(np.float32)),
+         "ex_feats": torch.from_numpy((0.01 * rng.standard_normal((8, 9, 3))).astype(np.float32))}
+    eps = torch.from_numpy(rng.standard_normal((8, 9, 12)).astype(np.float32))
+    models = []
+    for graphs in (True, False):
+        torch.manual_seed(1)
+        m = CVAEMemRand(dict(vo.make_config(12, 3), device="cuda:0", hip_graphs=graphs))
+        m.train()
+        models.append((m, torch.optim.AdamW(m.parameters(), lr=1e-4)))
+    for klw in (1e-5, 1e-3, 0.05, 1e-5):
+        outs = []
+        for m, opt in models:
+            m.kl_weight = klw
+            outs.append(m.train_step(x, opt, _eps=eps))
+        for k in outs[0]:
+            # (the three sums are double atomics over workgroups: the order, hence the last bit, is free)
+            assert abs(float(outs[0][k]) - float(outs[1][k])) <= 1e-12 * abs(float(outs[1][k])), (klw, k)
+        for (_, p), (_, q) in zip(models[0][0].named_parameters(), models[1][0].named_parameters()):
+            assert torch.equal(p, q)
+    assert len(models[0][0].__dict__["_vsv_graphs"]._d) == 1

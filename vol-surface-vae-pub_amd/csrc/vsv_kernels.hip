@@ -22,6 +22,7 @@
 #include <cstdio>
 #include <mutex>
 #include <type_traits>
+#include <vector>
 
 #include "vsv_layout.h"
 
@@ -3938,6 +3939,10 @@ __global__ void __launch_bounds__(256) loss_grad_kernel(const LossArgs a) {
     // others is written as zero)
     const int Hs = a.Hs > 0 ? a.Hs : a.H, h_skip = Hs - a.H;
     const double gs = a.grad_scale != 0.0f ? (double)a.grad_scale : 1.0;
+    // the two loss weights from device memory when given (a captured graph then follows a KL-annealing schedule
+    // without being captured again), else from the argument struct
+    const float ex_weight = a.weights_dev ? a.weights_dev[0] : a.ex_weight;
+    const float kl_weight = a.weights_dev ? a.weights_dev[1] : a.kl_weight;
     const long n_s = (long)a.B * Hs * a.Q * 25;
     const double inv_s = 1.0 / ((double)a.B * a.H * 25);
     for (long i = (long)blockIdx.x * 256 + tid; i < n_s; i += (long)gridDim.x * 256) {
@@ -3974,10 +3979,10 @@ __global__ void __launch_bounds__(256) loss_grad_kernel(const LossArgs a) {
                 const float d = a.ex_pred[i] - a.ex_target[((size_t)b * a.T + (a.T - a.H + h)) * a.X + f];
                 if (a.ex_l2) {
                     s1 += (double)d * d * inv_e;
-                    g = (float)(2.0 * d * inv_e * a.ex_weight * gs);
+                    g = (float)(2.0 * d * inv_e * ex_weight * gs);
                 } else {
                     s1 += (double)fabsf(d) * inv_e;
-                    g = (float)(((d > 0.0f) - (d < 0.0f)) * inv_e * a.ex_weight * gs);
+                    g = (float)(((d > 0.0f) - (d < 0.0f)) * inv_e * ex_weight * gs);
                 }
             }
             a.d_ex[i] = g;
@@ -3989,8 +3994,8 @@ __global__ void __launch_bounds__(256) loss_grad_kernel(const LossArgs a) {
         const float mu = a.zm[i], lv = a.zl[i];
         const float ev = expf(lv);
         s2 += -0.5 * (1.0 + (double)lv - (double)ev - (double)mu * mu) * inv_z;
-        a.d_zm[i] = (float)((double)mu * inv_z * a.kl_weight * gs);
-        a.d_zl[i] = (float)(-0.5 * (1.0 - (double)ev) * inv_z * a.kl_weight * gs);
+        a.d_zm[i] = (float)((double)mu * inv_z * kl_weight * gs);
+        a.d_zl[i] = (float)(-0.5 * (1.0 - (double)ev) * inv_z * kl_weight * gs);
     }
     red[0][tid] = s0; red[1][tid] = s1; red[2][tid] = s2;
     __syncthreads();
@@ -5059,13 +5064,22 @@ extern "C" int vsv_context_prefix(const vsv_dims* dims, const float* packed, con
         static const int map4[6] = {0, 0, 1, 1, 2, 3}, map3[6] = {0, 0, 1, 1, 2, 2}, map2[6] = {0, 0, 1, 1, 0, 0};
         sq[k] = (hipStream_t)streams[n_streams == 6 ? k : (n_streams == 4 ? map4[k] : (n_streams == 3 ? map3[k] : map2[k]))];
     }
-    auto ev_new = [](hipEvent_t& e) { return hipEventCreateWithFlags(&e, hipEventDisableTiming) == hipSuccess; };
-    auto fail_hip = [](const char* what) { set_error("vsv_context_prefix: %s: %s", what, hipGetErrorString(hipGetLastError())); return -3; };
-    hipEvent_t fork;
-    if (!ev_new(fork)) return fail_hip("hipEventCreate");
+    // every event the call needs is created BEFORE the fork: nothing below can fail between the fork and the join
+    // except a launch, and a failed launch still runs through the join (rc is returned after it)
+    std::vector<hipEvent_t> ev((size_t)1 + 5 * (size_t)n_seg + (size_t)n_streams, nullptr);
+    for (size_t k = 0; k < ev.size(); ++k) {
+        const hipError_t e = hipEventCreateWithFlags(&ev[k], hipEventDisableTiming);
+        if (e != hipSuccess) {
+            for (size_t j = 0; j < k; ++j) (void)hipEventDestroy(ev[j]);
+            set_error("vsv_context_prefix: hipEventCreate: %s", hipGetErrorString(e));
+            return (int)e;
+        }
+    }
+    hipEvent_t fork = ev[0];
+    hipEvent_t* const seg_ev = ev.data() + 1;
+    hipEvent_t* const join_ev = ev.data() + 1 + 5 * (size_t)n_seg;
     (void)hipEventRecord(fork, main);
     for (int k = 0; k < n_streams; ++k) (void)hipStreamWaitEvent((hipStream_t)streams[k], fork, 0);
-    (void)hipEventDestroy(fork);
 
     char* base = (char*)(((uintptr_t)ws + 255) & ~(uintptr_t)255);
     const size_t nse = (size_t)lay.NL * 2 * 8 * lay.NTm;
@@ -5087,8 +5101,7 @@ extern "C" int vsv_context_prefix(const vsv_dims* dims, const float* packed, con
         float* nd = last ? state_out : (float*)b;
         const float* v = vol + (size_t)25 * t0;
         const float* e = lay.X > 0 ? ex + (size_t)lay.X * t0 : nullptr;
-        hipEvent_t evs[5];
-        for (auto& q : evs) if (!ev_new(q)) return fail_hip("hipEventCreate");
+        hipEvent_t* const evs = seg_ev + 5 * (size_t)i;
         // encoders: layer 0, then (other stream) layer 1 + head; the final states of the last segment are not needed
         for (int which = 0; which < 2 && rc == 0; ++which) {
             hipStream_t s0 = sq[2 * which], s1 = sq[2 * which + 1];
@@ -5117,17 +5130,15 @@ extern "C" int vsv_context_prefix(const vsv_dims* dims, const float* packed, con
                 rc = vsv_decode_prefix_layer1(dims, packed, &din, n_days, T, nd, ws_d, wsd, sq[5]);
             }
         }
-        for (auto& q : evs) (void)hipEventDestroy(q);
         st_e = ne; st_c = nc; st_d = nd;
     }
-    // join: the caller's stream continues when every worker stream has drained
+    // join: the caller's stream continues when every worker stream has drained (also after a failed launch: the
+    // segments issued before it are still running on the worker streams)
     for (int k = 0; k < n_streams; ++k) {
-        hipEvent_t j;
-        if (!ev_new(j)) return fail_hip("hipEventCreate");
-        (void)hipEventRecord(j, (hipStream_t)streams[k]);
-        (void)hipStreamWaitEvent(main, j, 0);
-        (void)hipEventDestroy(j);
+        (void)hipEventRecord(join_ev[k], (hipStream_t)streams[k]);
+        (void)hipStreamWaitEvent(main, join_ev[k], 0);
     }
+    for (hipEvent_t e : ev) (void)hipEventDestroy(e);
     return rc;
 }
 
@@ -5162,6 +5173,11 @@ int noalloc_scratch(void** out) {
     return 0;
 }
 }  // namespace
+
+extern "C" int vsv_init_device(void) {
+    void* p = nullptr;
+    return noalloc_scratch(&p);
+}
 
 extern "C" int vsv_encode_windows_noalloc(const vsv_dims* dims, const float* packed, int which, const float* vol,
                                           const float* ex, long n_windows, int T, float* out, void* stream) {

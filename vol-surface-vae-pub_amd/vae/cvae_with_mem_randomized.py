@@ -368,8 +368,11 @@ class CVAEMemRand(BaseVAE):
         return r["surf"].to(dt)
 
     # -- forward / generation ------------------------------------------------------
+    @torch.compiler.disable
     def forward(self, x: Dict[str, torch.Tensor]):
-        """Reference :1022-1074.  Returns (recon (B,H,Q,5,5)[, ex (B,H,n)], z_mean, z_log_var, z)."""
+        """Reference :1022-1074.  Returns (recon (B,H,Q,5,5)[, ex (B,H,n)], z_mean, z_log_var, z).
+        Under torch.compile (the v3 trainer wraps the model, train_..._v3_conditional_prior.py:298) the whole
+        forward is one opaque call: its work is ctypes launches of libvsv_hip.so, nothing for a tracer to fuse."""
         from vsv import paths
         surf, ex = self._batched(x)
         T = surf.shape[1]
@@ -615,13 +618,19 @@ class CVAEMemRand(BaseVAE):
         .grad point at it directly -- train_step, one replay per step --, otherwise it is copied out)."""
         te = self.__dict__["_vsv_train_engine"]
         params = [p for _, p in self._hip_named_params()]
+        frozen = [not p.requires_grad for p in params]
         graphed = isinstance(gp, (list, tuple))
         grads = gp if graphed else te.param_grads(gp)
         if weight != 1.0:
             grads = torch._foreach_mul(list(grads), weight)
             graphed = False                                  # fresh tensors
         views = weight == 1.0 and (alias or not graphed)        # every .grad set below is a view of te.last_flat
-        for p, g in zip(params, grads):
+        # a frozen parameter (requires_grad False, user fine-tuning) gets no .grad, as under the reference's autograd:
+        # the optimizer then leaves it alone -- and the one-launch clip / AdamW over the flat buffer do not apply
+        views = views and not any(frozen)
+        for p, g, fz in zip(params, grads, frozen):
+            if fz:
+                continue
             g = g.to(p.dtype)
             views = views and p.grad is None and g.dtype == torch.float32
             if p.grad is None:
@@ -669,6 +678,8 @@ class CVAEMemRand(BaseVAE):
         if not all(isinstance(v, (int, float)) for v in (lr, b1, b2, g["eps"], g["weight_decay"])):
             return False
         params = [p for _, p in self._hip_named_params()]
+        if any((not p.requires_grad) or p.grad is None for p in params):
+            return False
         gp = g["params"]
         if len(gp) != len(params) or any(a is not b for a, b in zip(gp, params)):
             return False

@@ -11,7 +11,10 @@ and replays it per step.  What varies between replays lives in device memory:
   * the latent noise               -> torch.randn inside the graph (torch advances its Philox offset
                                       per replay; the reference draws torch.randn_like here, :199),
   * the nn.LSTM dropout mask seed  -> a device word filled by Tensor.random_() inside the graph and read
-                                      by the kernels through vsv_train_save.drop_seed_dev.
+                                      by the kernels through vsv_train_save.drop_seed_dev,
+  * kl_weight / re_feat_weight     -> a device pair the loss kernel reads (vsv_loss.weights_dev) and the 5 x 3
+                                      matrix that mixes the loss terms: a KL-annealing schedule rewrites 17
+                                      numbers per change instead of capturing a graph per value.
 Clipping and the optimizer stay outside (they belong to the caller's optimizer object).
 """
 from __future__ import annotations
@@ -37,6 +40,11 @@ class GraphedLossGrads:
         self.shape = (B, T)
         # parity tests: the posterior noise comes from a static buffer the caller fills, not from torch.randn
         self.eps_in = torch.zeros(B, T, te.L, dtype=torch.float32, device=dev) if inject_eps else None
+        self.wts = torch.zeros(2, dtype=torch.float32, device=dev)
+        self.mix = torch.zeros(5, 3, dtype=torch.float64, device=dev)
+        self._wkey = None
+        self.set_loss_weights(loss_cfg)
+        self.loss_cfg["weights_dev"], self.loss_cfg["mix_dev"] = self.wts, self.mix
         cur = torch.cuda.current_stream(dev)
         warm = torch.cuda.Stream(dev)
         warm.wait_stream(cur)
@@ -50,6 +58,18 @@ class GraphedLossGrads:
             self.loss_vec, self.grads, self.packed = self._body()
         self.flat = te.last_flat                 # the gradients are views of this static buffer
         self.partials = te.last_partials         # (its sums of squares per 256 elements, for the clip)
+
+    def set_loss_weights(self, loss_cfg: dict) -> None:
+        """The two loss weights as the replays will read them (no-op while they are unchanged)."""
+        exw = float(loss_cfg["ex_weight"]) if self.ex is not None else 0.0
+        klw = float(loss_cfg["kl_weight"])
+        if self._wkey == (exw, klw):
+            return
+        self._wkey = (exw, klw)
+        self.wts.copy_(torch.tensor([float(loss_cfg["ex_weight"]), klw], dtype=torch.float32))
+        # rows: loss, re_surface, re_ex_feats, reconstruction_loss, kl_loss from (re_surface, re_ex_feats, kl)
+        self.mix.copy_(torch.tensor([[1.0, exw, klw], [1.0, 0.0, 0.0], [0.0, 1.0, 0.0], [1.0, exw, 0.0],
+                                     [0.0, 0.0, 1.0]], dtype=torch.float64))
 
     def _body(self):
         te, eng = self.te, self.eng
@@ -95,7 +115,8 @@ class GraphCache:
             inject_eps: bool = False) -> GraphedLossGrads:
         B, T = surf.shape[:2]
         key = (B, T, ex is not None, int(horizon), float(dropout_p), bool(inject_eps),
-               tuple(sorted((k, tuple(v) if isinstance(v, (list, tuple)) else v) for k, v in loss_cfg.items())),
+               tuple(sorted((k, tuple(v) if isinstance(v, (list, tuple)) else v) for k, v in loss_cfg.items()
+                            if k not in ("ex_weight", "kl_weight"))),
                tuple(p.data_ptr() for _, p in named_params), id(te))
         g = self._d.get(key)
         if g is None:
@@ -105,4 +126,5 @@ class GraphCache:
                 self._d.popitem(last=False)
         else:
             self._d.move_to_end(key)
+            g.set_loss_weights(loss_cfg)
         return g

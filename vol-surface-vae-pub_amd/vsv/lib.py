@@ -127,7 +127,8 @@ class VsvLoss(C.Structure):
                 ("ex_weight", C.c_float), ("kl_weight", C.c_float),
                 ("zm", C.c_void_p), ("zl", C.c_void_p), ("L", C.c_int),
                 ("d_pred", C.c_void_p), ("d_ex", C.c_void_p), ("d_zm", C.c_void_p), ("d_zl", C.c_void_p),
-                ("sums", C.c_void_p), ("Hs", C.c_int), ("grad_scale", C.c_float), ("surf_l2", C.c_int)]
+                ("sums", C.c_void_p), ("Hs", C.c_int), ("grad_scale", C.c_float), ("surf_l2", C.c_int),
+                ("weights_dev", C.c_void_p)]
 
 
 # name -> (restype, argtypes); the full list of symbols include/vsv_hip.h declares
@@ -145,6 +146,7 @@ SIGNATURES = {
                                      C.c_long, C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     "vsv_encode_windows_noalloc": (C.c_int, [C.POINTER(VsvDims), C.c_void_p, C.c_int, C.c_void_p, C.c_void_p,
                                              C.c_long, C.c_int, C.c_void_p, C.c_void_p]),
+    "vsv_init_device": (C.c_int, []),
     "vsv_enc_state_floats": (C.c_size_t, [C.POINTER(VsvDims)]),
     "vsv_encode_state": (C.c_int, [C.POINTER(VsvDims), C.c_void_p, C.c_int,
                                    C.c_void_p, C.c_long, C.c_long, C.c_void_p, C.c_long, C.c_long,
@@ -234,7 +236,7 @@ def load() -> C.CDLL:
             fn = getattr(lib, name)
             fn.restype = res
             fn.argtypes = args
-        if lib.vsv_abi_version() != 19:
+        if lib.vsv_abi_version() != 20:
             raise RuntimeError("libvsv_hip.so ABI version mismatch")
         _lib = lib
     return _lib

@@ -590,6 +590,11 @@ class TrainEngine:
                 la.X, la.ex_n, la.ex_l2 = X, int(loss_cfg["ex_n"]), int(loss_cfg["ex_l2"])
             la.surf_l2 = int(bool(loss_cfg.get("surf_l2", False)))
             la.ex_weight, la.kl_weight = float(loss_cfg["ex_weight"]), (0.0 if kl_fn is not None else klw)
+            wdev = loss_cfg.get("weights_dev")           # (graphed step: the two weights live in device memory)
+            if wdev is not None:
+                if kl_fn is not None:
+                    raise ValueError("weights_dev and kl_fn are exclusive")
+                la.weights_dev = wdev.data_ptr()
             la.zm, la.zl, la.L = zm.data_ptr(), zl.data_ptr(), L
             la.d_pred, la.d_zm, la.d_zl = d_pred.data_ptr(), d_zm.data_ptr(), d_zl.data_ptr()
             sums = torch.zeros(3, dtype=torch.float64, device=dev)
@@ -606,7 +611,9 @@ class TrainEngine:
             # loss = re_surface + ex_weight * re_ex_feats + kl_weight * kl etc. as ONE small matrix-vector product
             exw = float(loss_cfg["ex_weight"]) if X > 0 else 0.0
             key = (exw, klw)
-            M = self.__dict__.setdefault("_loss_mix", {}).get(key)
+            M = loss_cfg.get("mix_dev")
+            if M is None:
+                M = self.__dict__.setdefault("_loss_mix", {}).get(key)
             if M is None:
                 M = self._loss_mix[key] = torch.tensor([[1.0, exw, klw], [1.0, 0.0, 0.0], [0.0, 1.0, 0.0],
                                                         [1.0, exw, 0.0], [0.0, 0.0, 1.0]], dtype=torch.float64, device=dev)

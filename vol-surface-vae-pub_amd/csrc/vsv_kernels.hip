@@ -2266,6 +2266,17 @@ __device__ __forceinline__ DenseLayerArg chain_layer_of(int li) {
 // every layer updates in place.  Same products in the same k order as lstm_kernel: results are bit-equal.
 // Eight such waves per CU (two 4-wave workgroups, 64 KB LDS each) overlap freely.
 // ---------------------------------------------------------------------------
+#ifndef VSV_MC1_STREAM
+#define VSV_MC1_STREAM gemm_stream_buf2
+#endif
+#ifndef VSV_MC1_HEAD_REG
+#define VSV_MC1_HEAD_REG 1
+#endif
+// (the register-resident head, defined with dec_seq_kernel below)
+template <int NT>
+__device__ __forceinline__ void dec_seq_head(const LstmSeqArgs& a, float (&act)[16 * kHeadTiles], const int lane,
+                                             const long rowtile, const int to, const uint32_t day_rel, const uint32_t sample,
+                                             float4 (&fa)[4 * kHeadTiles], float (&bf)[4], const int dsq_t, const int wave);
 template <int NT>
 __global__ void __launch_bounds__(256, 2) mc_decode1_kernel(const LstmSeqArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -2322,62 +2333,135 @@ __global__ void __launch_bounds__(256, 2) mc_decode1_kernel(const LstmSeqArgs a)
     const int qx0 = a.Lc >> 3, qxn = ((a.Lc + a.L + 7) >> 3) - qx0;
     MC1_STAMP(1);
 
-    // ---- the two memory layers
+    // ---- the two memory layers: eight passes of four gate tiles.  A pass's accumulators start from the day's
+    // bias + W_hh . h_prefix (gate_in) and its cell state from the day's state: both are requested one pass AHEAD,
+    // tile by tile, as the cell math of the pass before frees the tile's registers -- a pass that began with these
+    // loads waited an L2 round trip for them with nothing to multiply (layer 0's passes are 24 products long).
+    // Layer 0 multiplies only the k-pairs that hold z (kmask): the context half of its input is the zero padding.
+    unsigned kmask = 0;
+    for (int j = 0; j < 4 * qxn && j < 32; ++j) {
+        const int f = 8 * qx0 + 2 * j;
+        if (f + 1 >= a.Lc && f < a.Lc + a.L) kmask |= 1u << j;
+    }
+    f32x16 acc[4];
+    float c[4][4];
+    float4 a0[4];
+    auto fetch_tile = [&](int l, int tile, f32x16& ac, float (&cc)[4], int hh) {
+        const float4* gp = (const float4*)(gate_in + (size_t)l * NT * 32 + tile * 32 + hh * 16);
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+            const float4 x = gp[v];
+            ac[4 * v + 0] = x.x; ac[4 * v + 1] = x.y; ac[4 * v + 2] = x.z; ac[4 * v + 3] = x.w;
+        }
+        const float4 cv = *(const float4*)(st + (size_t)l * 2 * HP + HP + 8 * tile + 4 * hh);
+        cc[0] = cv.x; cc[1] = cv.y; cc[2] = cv.z; cc[3] = cv.w;
+    };
+    auto w_of = [&](int l) { return (const float4*)a.w[l] + (l == 0 ? (size_t)qx0 * NT * 64 : 0); };
+    {
+        const int lv = opaque(lane);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) fetch_tile(0, i, acc[i], c[i], lv >> 5);
+        wload_buf<4>(a0, make_wrsrc(w_of(0)), (unsigned)lv * 16u, 0u);
+    }
+    float hold[NT][4];                                            // a layer's h, unit 8*tile + 2*jj + hh
+#if VSV_MC1_HEAD_REG
+    float4 fa[4 * kHeadTiles];                                    // the head's fragment buffer (dec_seq_head)
+    float hbf[4];
+#endif
 #pragma unroll
     for (int l = 0; l < 2; ++l) {
-        float hold[NT][4];                                        // this layer's h, unit 8*tile + 2*jj + hh
-        const float4* const w = (const float4*)a.w[l] + (l == 0 ? (size_t)qx0 * NT * 64 : 0);
-        const int nq = (l == 0) ? qxn : NT;
-        const int bslot0 = (l == 0) ? 4 * qx0 : 0;
 #pragma unroll
         for (int p = 0; p < NP; ++p) {
             const int lv = opaque(lane);
             const int hh = lv >> 5;
-            f32x16 acc[4];
-            float c[4][4], hn[4][4];
-            float4 a0[4];
-            const wrsrc_t wr = make_wrsrc(w);
+            const wrsrc_t wr = make_wrsrc(w_of(l));
             const unsigned voff = (unsigned)lv * 16u, sb = (unsigned)p * 4096u;      // tiles 4p .. 4p + 3
-            wload_buf<4>(a0, wr, voff, sb);
-            // gate accumulators start from bias + W_hh . h_prefix of the day (gate_in); c from the day's state
+            if (l == 0) {
+                const float* const bcol = col0 + lv + (size_t)(4 * qx0) * 64;
+#pragma unroll 1
+                for (int q = 0; q < qxn; ++q) {
+                    float4 a1[4];
+                    const int qn = (q + 1 < qxn) ? q + 1 : q;
+                    wload_buf<4>(a1, wr, voff, sb + (unsigned)qn * (NT * 1024u));
+                    float bv[4];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) bv[j] = bcol[(4 * q + j) * 64];
+                    const unsigned km = kmask >> (4 * q);
+                    if (km & 1u) {
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) acc[i] = mfma32(a0[i].x, bv[0], acc[i]);
+                    }
+                    if (km & 2u) {
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) acc[i] = mfma32(a0[i].y, bv[1], acc[i]);
+                    }
+                    if (km & 4u) {
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) acc[i] = mfma32(a0[i].z, bv[2], acc[i]);
+                    }
+                    if (km & 8u) {
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) acc[i] = mfma32(a0[i].w, bv[3], acc[i]);
+                    }
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) a0[i] = a1[i];
+                }
+            } else {
+                const float* const bcol = col0 + lv;
+                VSV_MC1_STREAM<4>(acc, a0, wr, voff, sb, NT * 1024u, NT, [&](int q, float (&bv)[4]) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) bv[j] = bcol[(4 * q + j) * 64];
+                });
+            }
+            MC1_STAMP(2 * (l * NP + p) + 2);
+#if VSV_MC1_HEAD_REG
+            if (l == 1 && p == NP - 1) {
+                // the head's first fragments and bias, in front of the memory's last cell
+                const DenseLayerArg& ly = hd.layer[0];
+                band_load_all<4 * kHeadTiles>(fa, make_wrsrc(ly.w), voff, 0u, (unsigned)ly.nt * 1024u, 0, 4 * kHeadTiles);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) hbf[i] = bias_frag(ly.b, i, lv);
+            }
+#endif
+            // cell math tile by tile; a tile's registers then take the NEXT pass's starting values
+            const bool more = !(l == 1 && p == NP - 1);
+            const int nl = (p == NP - 1) ? l + 1 : l, np = (p + 1) % NP;
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                const float4* gp = (const float4*)(gate_in + (size_t)l * NT * 32 + (4 * p + i) * 32 + hh * 16);
-#pragma unroll
-                for (int v = 0; v < 4; ++v) {
-                    const float4 x = gp[v];
-                    acc[i][4 * v + 0] = x.x; acc[i][4 * v + 1] = x.y; acc[i][4 * v + 2] = x.z; acc[i][4 * v + 3] = x.w;
-                }
-                const float4 cv = *(const float4*)(st + (size_t)l * 2 * HP + HP + 8 * (4 * p + i) + 4 * hh);
-                c[i][0] = cv.x; c[i][1] = cv.y; c[i][2] = cv.z; c[i][3] = cv.w;
-            }
-            const float* const bcol = col0 + lv + (size_t)bslot0 * 64;
-            gemm_stream_buf<4>(acc, a0, wr, voff, sb, NT * 1024u, nq, [&](int q, float (&bv)[4]) {
-#pragma unroll
-                for (int j = 0; j < 4; ++j) bv[j] = bcol[(4 * q + j) * 64];
-            });
-            MC1_STAMP(2 * (l * NP + p) + 2);
-            lstm_cell_pk(acc, c, hn);
-            // (pinned: left to itself the compiler sinks the cell math of all four passes below the last
-            // pass's GEMM and parks the earlier passes' accumulators in scratch meanwhile)
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
+                float hn[1][4];
+                lstm_cell_pk<1>(reinterpret_cast<f32x16(&)[1]>(acc[i]), reinterpret_cast<float(&)[1][4]>(c[i]), hn);
+                // (pinned: left to itself the compiler sinks the cell math of all four passes below the last
+                // pass's GEMM and parks the earlier passes' accumulators in scratch meanwhile)
 #pragma unroll
                 for (int jj = 0; jj < 4; ++jj) {
-                    asm volatile("" : "+v"(hn[i][jj]));
-                    hold[4 * p + i][jj] = hn[i][jj];
+                    asm volatile("" : "+v"(hn[0][jj]));
+                    hold[4 * p + i][jj] = hn[0][jj];
                 }
+                if (more) fetch_tile(nl, 4 * np + i, acc[i], c[i], hh);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            if (more) wload_buf<4>(a0, make_wrsrc(w_of(nl)), voff, (unsigned)np * 4096u);
             __builtin_amdgcn_sched_barrier(0);
             MC1_STAMP(2 * (l * NP + p) + 3);
         }
         // every pass has read the layer's input: the column now takes the layer's h (natural k-step order)
-        float* const colw = col0 + opaque(lane);
+        if (l == 0 || !VSV_MC1_HEAD_REG) {
+            float* const colw = col0 + opaque(lane);
 #pragma unroll
-        for (int t = 0; t < NT; ++t)
+            for (int t = 0; t < NT; ++t)
 #pragma unroll
-            for (int jj = 0; jj < 4; ++jj) colw[(4 * t + jj) * 64] = hold[t][jj];
+                for (int jj = 0; jj < 4; ++jj) colw[(4 * t + jj) * 64] = hold[t][jj];
+        }
     }
 
+#if VSV_MC1_HEAD_REG
+    // ---- decoder head, from registers: its input is the top layer's h as it stands (k-step 4 t + jj <-> hold[t][jj]),
+    // a layer's accumulators are the next layer's B operands (dec_seq_head)
+    {
+        float (&act)[16 * kHeadTiles] = reinterpret_cast<float(&)[16 * kHeadTiles]>(hold);
+        dec_seq_head<NT>(a, act, lane, rowtile, 0, day_rel, sample, fa, hbf, 0, wave);
+    }
+#else
     // ---- decoder head: every layer reads the column and overwrites it with its (ReLU'd) outputs
     const int n_layers = hd.n_layers;                             // 4: [Linear . ConvT] ConvT ConvT Conv
     auto bias_init = [&](f32x16 (&acc)[4], const DenseLayerArg& ly, int hh) {
@@ -2486,6 +2570,7 @@ __global__ void __launch_bounds__(256, 2) mc_decode1_kernel(const LstmSeqArgs a)
         epilogue(acc, ly, li, lv);
         MC1_STAMP(19 + 2 * li);
     }
+#endif
 }
 
 // ---------------------------------------------------------------------------
@@ -5401,6 +5486,9 @@ static bool mc_decode1_applies(const LstmSeqArgs& l, const Layout& lay, int T, i
     if (hd.n_layers != 4 || hd.layer[0].nt != 4 || hd.layer[0].nq != 16) return false;
     for (int i = 1; i < 4; ++i)
         if (hd.layer[i].nt < 1 || hd.layer[i].nt > 4 || hd.layer[i].nq != 16) return false;
+    for (int i = 0; i < 4; ++i)
+        for (int t = 0; t < hd.layer[i].nt; ++t)                   // (the banded tiles clamp into non-empty bands)
+            if (hd.layer[i].nqb[t] < 1 || hd.layer[i].q0[t] < 0 || hd.layer[i].q0[t] + hd.layer[i].nqb[t] > 16) return false;
     return true;
 }
 

@@ -2459,7 +2459,7 @@ __global__ void __launch_bounds__(256, 2) mc_decode1_kernel(const LstmSeqArgs a)
     // a layer's accumulators are the next layer's B operands (dec_seq_head)
     {
         float (&act)[16 * kHeadTiles] = reinterpret_cast<float(&)[16 * kHeadTiles]>(hold);
-        dec_seq_head<NT>(a, act, lane, rowtile, 0, day_rel, sample, fa, hbf, 0, wave);
+        dec_seq_head<NT>(a, act, lane, rowtile, 0, day_rel, sample, fa, hbf, 1, wave);       // (1: the head's phase stamps, diagnostic builds)
     }
 #else
     // ---- decoder head: every layer reads the column and overwrites it with its (ReLU'd) outputs

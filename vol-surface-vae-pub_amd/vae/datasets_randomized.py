@@ -16,41 +16,46 @@ import torch
 from torch.utils.data import BatchSampler, Dataset, Sampler
 
 
+def _calendar_tensor(array, dtype) -> torch.Tensor:
+    """numpy calendar array -> tensor sharing its memory (float64 as loaded) or a float32 copy."""
+    t = torch.from_numpy(array)
+    return t.float() if dtype == torch.float32 else t
+
+
 class VolSurfaceDataSetRand(Dataset):
     """Item idx -> (seq_len_idx, start) = divmod(idx, N); window [start, start+seq_len)
     of the calendar (windows that run past the end are SHORTER, as in the reference).
     dataset: numpy (N, 5, 5) or tuple ((N, 5, 5), (N, X) | (N,))."""
 
     def __init__(self, dataset, min_seq_len=4, max_seq_len=10, dtype=torch.float64):
-        if isinstance(dataset, tuple):
-            self.dataset = torch.from_numpy(dataset[0])
-            self.ex_feats = torch.from_numpy(dataset[1])
-            if dtype == torch.float32:
-                self.dataset, self.ex_feats = self.dataset.float(), self.ex_feats.float()
-            assert len(self.dataset) == len(self.ex_feats), "dataset and ex_feats should have the same length"
-            if self.ex_feats.dim() == 1:
-                self.ex_feats = self.ex_feats.unsqueeze(-1)
-        else:
-            self.dataset = torch.from_numpy(dataset)
-            self.ex_feats = None
-            if dtype == torch.float32:
-                self.dataset = self.dataset.float()
-        self.seq_lens = list(range(min_seq_len, max_seq_len + 1))
+        surfaces, extras = (dataset[0], dataset[1]) if isinstance(dataset, tuple) else (dataset, None)
+        self.dataset = _calendar_tensor(surfaces, dtype)
+        self.ex_feats = None
+        if extras is not None:
+            ex = _calendar_tensor(extras, dtype)
+            assert len(self.dataset) == len(ex), "dataset and ex_feats should have the same length"
+            self.ex_feats = ex if ex.dim() > 1 else ex[:, None]           # (N,) -> (N, 1)
+        self.seq_lens = [*range(min_seq_len, max_seq_len + 1)]
 
     def __len__(self):
-        return len(self.dataset) * len(self.seq_lens)
+        return len(self.seq_lens) * len(self.dataset)
+
+    def _locate(self, idx: int):
+        """(first calendar row, nominal window length) of item idx: all starts for the shortest length first."""
+        which, start = divmod(idx, len(self.dataset))
+        return start, self.seq_lens[which]
 
     def window_length(self, idx: int) -> int:
         """Length of item idx without building it."""
-        seq_len_idx, start = divmod(idx, len(self.dataset))
-        return min(self.seq_lens[seq_len_idx], len(self.dataset) - start)
+        start, n = self._locate(idx)
+        return min(n, len(self.dataset) - start)
 
     def __getitem__(self, idx):
-        seq_len_idx, start = divmod(idx, len(self.dataset))
-        seq_len = self.seq_lens[seq_len_idx]
-        item = {"surface": self.dataset[start:start + seq_len]}
+        start, n = self._locate(idx)
+        rows = slice(start, start + n)
+        item = {"surface": self.dataset[rows]}
         if self.ex_feats is not None:
-            item["ex_feats"] = self.ex_feats[start:start + seq_len]
+            item["ex_feats"] = self.ex_feats[rows]
         return item
 
 
@@ -73,11 +78,14 @@ class GroupedRandomSampler(Sampler):
                 self.groups[n].append(idx)
 
     def __iter__(self) -> Iterator:
-        group_idx = list(self.groups.values())
-        random.shuffle(group_idx)
-        for group in group_idx:
-            random.shuffle(group)
-            yield from group
+        # (a shuffle's permutation depends on the list's length alone: shuffling the lengths draws what shuffling
+        # the groups themselves would)
+        lengths = list(self.groups)
+        random.shuffle(lengths)
+        for n in lengths:
+            members = self.groups[n]
+            random.shuffle(members)
+            yield from members
 
     def __len__(self):
         return len(self.dataset)

@@ -56,10 +56,20 @@ __device__ unsigned long long g_stamps[(size_t)kStampWgs * 4 * 32];
             g_stamps[((size_t)blockIdx.x * 4 + wave) * 32 + (i)] = __builtin_amdgcn_s_memtime();               \
         __builtin_amdgcn_sched_barrier(0);                                                                    \
     } while (0)
+// (lstm_rec4_kernel / lstm_rec16_kernel, tools/stamps_rec.py: two consecutive time steps from the middle of the
+// sequence -- 4s + 0 top of step, + 1 products issued, + 2 cell and stores issued, + 3 past the barrier)
+#define REC_STAMP(i)                                                                                          \
+    do {                                                                                                      \
+        __builtin_amdgcn_sched_barrier(0);                                                                    \
+        if ((t == (a.T >> 1) || t == (a.T >> 1) + 1) && lane == 0 && wave < 4 && blockIdx.x < kStampWgs)       \
+            g_stamps[((size_t)blockIdx.x * 4 + wave) * 32 + 4 * (t - (a.T >> 1)) + (i)] = __builtin_amdgcn_s_memtime(); \
+        __builtin_amdgcn_sched_barrier(0);                                                                    \
+    } while (0)
 #else
 #define VSV_STAMP(i) do {} while (0)
 #define MC1_STAMP(i) do {} while (0)
 #define DSQ_STAMP(i) do {} while (0)
+#define REC_STAMP(i) do {} while (0)
 #endif
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -1952,10 +1962,12 @@ __global__ void __launch_bounds__(512) lstm_rec16_kernel(const LstmSeqArgs a) {
         const float* hr = hbase + (t & 1) * (KS * 64);
         float* hw = hbase + ((t + 1) & 1) * (KS * 64);
         f32x4 acc[TPW];
+        REC_STAMP(0);
 #pragma unroll
         for (int i = 0; i < TPW; ++i) acc[i] = pre[i];
         if (t + 1 < a.T) load_pre(pre, t + 1);                     // lands while the products run
         if (t > 0 || has_state) products(acc, hr);
+        REC_STAMP(1);
 #pragma unroll
         for (int i = 0; i < TPW; ++i) {
             const float ig = fast_sigmoid(acc[i][0]);
@@ -1986,7 +1998,9 @@ __global__ void __launch_bounds__(512) lstm_rec16_kernel(const LstmSeqArgs a) {
             for (int i = 0; i < TPW; ++i)
                 if (i < ntile) ho[hslot[i] * 64 + l32[i]] = h[i];
         }
+        REC_STAMP(2);
         __syncthreads();                                           // h(t) published (the other buffer is free again)
+        REC_STAMP(3);
     }
     if (a.state_out && row_ok) {
         float* st = a.state_out + ((size_t)row_raw * SNL + a.st_l0) * 2 * HP;
@@ -2146,6 +2160,7 @@ __global__ void __launch_bounds__(512) lstm_rec4_kernel(const LstmSeqArgs a) {
         const float* hr = hcol + (size_t)((t & 1) * R) * (4 * HPAD);
         float* hw = hcol + (size_t)(((t + 1) & 1) * R) * (4 * HPAD);
         f32x4 acc[R];
+        REC_STAMP(0);
 #pragma unroll
         for (int r = 0; r < R; ++r) acc[r] = pre[r];
         if (t + 1 < a.T) {
@@ -2153,6 +2168,7 @@ __global__ void __launch_bounds__(512) lstm_rec4_kernel(const LstmSeqArgs a) {
             for (int r = 0; r < R; ++r) pre[r] = load_pre(r, t + 1);   // lands while the products run
         }
         if ((t > 0 || has_state) && active) products(acc, hr);
+        REC_STAMP(1);
 #pragma unroll
         for (int r = 0; r < R; ++r) {
             const float ig = fast_sigmoid(acc[r][0]);
@@ -2180,7 +2196,9 @@ __global__ void __launch_bounds__(512) lstm_rec4_kernel(const LstmSeqArgs a) {
                     a.hout[((size_t)(rowtile * t_outs + (t - a.t_out0)) * HPK + hslot) * 64 + l32 + 4 * r] = h[r];
             }
         }
+        REC_STAMP(2);
         __syncthreads();                                           // h(t) published (the other buffer is free again)
+        REC_STAMP(3);
     }
     if (a.state_out && uok) {
 #pragma unroll

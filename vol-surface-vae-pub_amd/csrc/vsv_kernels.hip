@@ -2141,6 +2141,34 @@ __global__ void __launch_bounds__(512) lstm_rec4_kernel(const LstmSeqArgs a) {
     // tile shape, so this is bit for bit what lstm_kernel / lstm_rec16_kernel compute; the R chains (and the two
     // waves of a SIMD) fill each other's issue gaps
     auto products = [&](f32x4 (&acc)[R], const float* hr) {
+        if (SAVE) {
+            // training: FOUR chains per tile (k mod 4), summed at the end -- the single chain is HP dependent
+            // products at the instruction's 28-cycle dependent-issue latency (3.6 k of a step's 4.5 k cycles,
+            // profiles/r3_rec_step_stamps.txt), four are issue-bound at 8.  The sum's order differs from the
+            // generation kernels' (which stay on one ascending-k chain, bit-equal to each other): a training forward
+            // agrees with them to rounding, as its backward (lstm_bwd4_kernel, the same split) always has.
+            f32x4 p1[R], p2[R], p3[R];
+#pragma unroll
+            for (int r = 0; r < R; ++r) p1[r] = p2[r] = p3[r] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+            for (int k = 0; k < HP; k += 4) {
+                float4 hv[R];
+#pragma unroll
+                for (int r = 0; r < R; ++r) hv[r] = *(const float4*)(hr + (size_t)r * (4 * HPAD) + k);
+#pragma unroll
+                for (int r = 0; r < R; ++r) {
+                    acc[r] = mfma4(wreg[k + 0], hv[r].x, acc[r]);
+                    p1[r] = mfma4(wreg[k + 1], hv[r].y, p1[r]);
+                    p2[r] = mfma4(wreg[k + 2], hv[r].z, p2[r]);
+                    p3[r] = mfma4(wreg[k + 3], hv[r].w, p3[r]);
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < R; ++r)
+#pragma unroll
+                for (int v = 0; v < 4; ++v) acc[r][v] += (p1[r][v] + p2[r][v]) + p3[r][v];
+            return;
+        }
 #pragma unroll
         for (int k = 0; k < HP; k += 4) {
             float4 hv[R];

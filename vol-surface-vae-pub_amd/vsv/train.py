@@ -226,7 +226,8 @@ class TrainEngine:
                 p.n_inst, p.T = G.shape[0], T
                 p.w_off, p.b_off, p.nt, p.bias = sec.w_off, sec.b_off, sec.nt, int(bias)
             _lib.check(self.lib.vsv_weight_grads(C.byref(a), self._stream()), "vsv_weight_grads")
-        c.wg_keep = q                                        # operands stay referenced until the next flush
+        # operands stay referenced until the step's context goes (a flush may run on a stream of its own)
+        c.wg_keep = getattr(c, "wg_keep", []) + q
 
     # -- building blocks ----------------------------------------------------------------
     class _Ctx:
@@ -531,6 +532,19 @@ class TrainEngine:
             dx = self._e(B, T, Lc + L)
             dg = self._lstm_bwd(c, "d", lay["Hd"], NTd, sv_d, T, c.Cn, dh_top, (Lc + L + 31) // 32, 2, dx_rows=dx, dx_f=Lc + L)
             self._lstm_wgrads(c, gp, d["lstm"], sv_d, dg, T, NTd, sv_d["xe"])
+            # the decoder's weight gradients (head + memory: everything queued so far) on a stream of their own,
+            # beside the encoders' backward -- a batch of 64 leaves most CUs idle, and the launch would otherwise
+            # sit at the end of the step's critical path
+            # (a fork and join cost ~20 us of cross-stream ordering: only where the launch is longer than that --
+            # c2's 400 instances: 2.35 -> 2.29 ms per step; c1's 22: 0.60 -> 0.63, so not there)
+            wg_stream = None
+            if rt * T >= 128:
+                wg_stream = getattr(self.eng, "_third", None)
+                if wg_stream is None:
+                    wg_stream = self.eng._third = torch.cuda.Stream(dev)
+                wg_stream.wait_stream(main)
+                with torch.cuda.stream(wg_stream):
+                    self._wg_flush(c, gp)
             # reparameterisation (:199) and the context embedding: one launch (vsv_reparam_backward)
             d_enc, d_ctx = self._e(B, T, 2 * L), self._e(B, Cn, Lc)
             f32 = lambda t: None if t is None else t.to(dev, torch.float32).contiguous()
@@ -545,6 +559,8 @@ class TrainEngine:
             ds_e = self._enc_bwd(c, gp, 0, c.sv_e, T, d_enc, want_input_grad)
             main.wait_stream(side)
             self._wg_flush(c, gp)
+            if wg_stream is not None:
+                main.wait_stream(wg_stream)
             if want_input_grad:
                 ds_e[:, :Cn] += ds_c
                 c.outputs["d_surface"] = ds_e.view(B, T, 5, 5)

@@ -85,3 +85,38 @@ def test_train_step_over_sequence_lengths_uses_one_graph_per_shape():
     model.train()
     mh = model.train_step_multihorizon(xs[9], opt, horizons=[1, 3, 3])
     assert np.isfinite(mh["loss"])
+
+
+@pytest.mark.parametrize("p", [0.0, 0.25])
+def test_graphed_multihorizon_step_matches_eager_step(p):
+    """train_step_multihorizon as one replay (the horizons are row groups of one captured forward / backward) against
+    the same step launched eagerly: same injected noise per horizon -> same reported floats and, with dropout off, the
+    same parameters after every step (with dropout the two draw their mask seeds differently: losses stay finite and
+    the graph is captured once)."""
+    rng = np.random.default_rng(5)
+    B, T, hs = 16, 12, [1, 3, 7]
+    xs = [_batch(rng, B, T) for _ in range(3)]
+    eps = [[torch.from_numpy(rng.standard_normal((B, T, 5)).astype(np.float32)) for _ in hs] for _ in xs]
+    outs = {}
+    for graphs in (True, False):
+        model = _model(p, hip_graphs=graphs)
+        opt = torch.optim.AdamW(model.parameters(), lr=1e-3)
+        res = []
+        for x, e in zip(xs, eps):
+            r = model.train_step_multihorizon(x, opt, horizons=hs, _eps_per_horizon=e)
+            assert set(r) == {"loss", "reconstruction_loss", "kl_loss", "horizon_losses"} and set(r["horizon_losses"]) == set(hs)
+            assert all(isinstance(r[k], float) for k in ("loss", "reconstruction_loss", "kl_loss"))
+            res.append(r)
+        outs[graphs] = (res, [q.detach().clone() for q in model.parameters()])
+        if graphs:
+            assert len(model.__dict__["_vsv_graphs"]._d) == 1
+    if p == 0.0:
+        for a, b in zip(outs[True][0], outs[False][0]):
+            for k in ("loss", "reconstruction_loss", "kl_loss"):
+                assert abs(a[k] - b[k]) <= 1e-9 * abs(b[k]) + 1e-12, k
+            for h in hs:
+                assert abs(a["horizon_losses"][h] - b["horizon_losses"][h]) <= 1e-9 * abs(b["horizon_losses"][h]) + 1e-12
+        for qa, qb in zip(outs[True][1], outs[False][1]):
+            assert torch.equal(qa, qb)
+    else:
+        assert all(np.isfinite(r["loss"]) for r in outs[True][0])

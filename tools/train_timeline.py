@@ -12,7 +12,9 @@ with open(path) as f:
 rows.sort()
 # a step ends with the optimizer's last multi_tensor_apply launch: split on the loss kernel instead (one per step)
 marks = [i for i, r in enumerate(rows) if "loss_grad_kernel" in r[2]]
-marks = marks[-steps:]
+import os
+per_step = int(os.environ.get("MARKS_PER_STEP", "1"))          # (the multi-horizon step launches the loss kernel once per horizon)
+marks = marks[::per_step][-steps:]
 per = []
 for a, b in zip(marks[:-1], marks[1:]):
     seg = rows[a:b]

@@ -769,11 +769,26 @@ class CVAEMemRand(BaseVAE):
                              f"need at least T >= {1 + max_horizon}")
         optimizer.zero_grad()
         p = float(self.config.get("mem_dropout", 0) or 0) if self.training else 0.0
-        te = self._train_engine()
-        losses, gp = te.loss_and_grads_multihorizon(
-            surf, ex, list(horizons), [weights.get(h, 1.0) for h in horizons], self._loss_cfg(),
-            eps=_eps_per_horizon, seed=self._draw_seed(), dropout_p=p, dropout_seed=self._draw_seed() if p > 0 else 0)
-        flat = self._accumulate_grads(gp)
+        hw = [weights.get(h, 1.0) for h in horizons]
+        if self._use_graphs():
+            # one HIP-graph replay per step, as in train_step (vsv/graphed.py): launched eagerly the step's ~70
+            # launches and the dozen small torch ops that mix the loss terms leave the GPU waiting for the host
+            from vsv.graphed import GraphCache
+            te = self._train_engine(pack=False)
+            cache = self.__dict__.setdefault("_vsv_graphs", GraphCache())
+            params = self._hip_named_params()
+            g = cache.get(te, params, surf, ex, 0, self._loss_cfg(), p if self.config["mem_layers"] > 1 else 0.0,
+                          inject_eps=_eps_per_horizon is not None, horizons=list(horizons), weights=hw)
+            eps = None if _eps_per_horizon is None else torch.stack([e.to(surf.device, torch.float32) for e in _eps_per_horizon])
+            losses, gp = g.run(surf, ex, eps)
+            self.__dict__["_vsv_key"] = tuple((q.data_ptr(), q._version) for _, q in params)
+            flat = self._accumulate_grads(gp, alias=True)
+        else:
+            te = self._train_engine()
+            losses, gp = te.loss_and_grads_multihorizon(
+                surf, ex, list(horizons), hw, self._loss_cfg(),
+                eps=_eps_per_horizon, seed=self._draw_seed(), dropout_p=p, dropout_seed=self._draw_seed() if p > 0 else 0)
+            flat = self._accumulate_grads(gp)
         if flat is None or not self._adamw_step_(optimizer, flat):
             optimizer.step()
         # one read-back for all the reported numbers

@@ -16,6 +16,8 @@ and replays it per step.  What varies between replays lives in device memory:
                                       matrix that mixes the loss terms: a KL-annealing schedule rewrites 17
                                       numbers per change instead of capturing a graph per value.
 Clipping and the optimizer stay outside (they belong to the caller's optimizer object).
+The multi-horizon step (train_step_multihorizon: the horizons as row groups of one forward / backward) is captured the
+same way; its loss weights stay kernel arguments (part of the cache key).
 """
 from __future__ import annotations
 
@@ -29,22 +31,29 @@ class GraphedLossGrads:
     """Captured (pack weights -> forward -> loss -> backward -> parameter gradients) for one shape."""
 
     def __init__(self, te, named_params, B: int, T: int, has_ex: bool, horizon: int, loss_cfg: dict,
-                 dropout_p: float, inject_eps: bool = False):
+                 dropout_p: float, inject_eps: bool = False, horizons=None, weights=None):
+        """horizons / weights: the multi-horizon step (TrainEngine.loss_and_grads_multihorizon) instead of the
+        single-horizon one; `horizon` is then unused."""
         self.te, self.eng = te, te.eng
         self.params = [p for _, p in named_params]
         self.named = list(named_params)
         self.horizon, self.loss_cfg, self.p = int(horizon), dict(loss_cfg), float(dropout_p)
+        self.horizons = None if horizons is None else [int(h) for h in horizons]
+        self.weights = None if weights is None else [float(w) for w in weights]
         dev = te.dev
         self.surf = torch.zeros(B, T, 5, 5, dtype=torch.float32, device=dev)
         self.ex = torch.zeros(B, T, te.X, dtype=torch.float32, device=dev) if has_ex else None
         self.shape = (B, T)
         # parity tests: the posterior noise comes from a static buffer the caller fills, not from torch.randn
-        self.eps_in = torch.zeros(B, T, te.L, dtype=torch.float32, device=dev) if inject_eps else None
+        G = 1 if self.horizons is None else len(self.horizons)
+        eshape = (B, T, te.L) if self.horizons is None else (G, B, T, te.L)
+        self.eps_in = torch.zeros(eshape, dtype=torch.float32, device=dev) if inject_eps else None
         self.wts = torch.zeros(2, dtype=torch.float32, device=dev)
         self.mix = torch.zeros(5, 3, dtype=torch.float64, device=dev)
         self._wkey = None
         self.set_loss_weights(loss_cfg)
-        self.loss_cfg["weights_dev"], self.loss_cfg["mix_dev"] = self.wts, self.mix
+        if self.horizons is None:                # (the multi-horizon step reads the two weights from its arguments)
+            self.loss_cfg["weights_dev"], self.loss_cfg["mix_dev"] = self.wts, self.mix
         cur = torch.cuda.current_stream(dev)
         warm = torch.cuda.Stream(dev)
         warm.wait_stream(cur)
@@ -76,10 +85,23 @@ class GraphedLossGrads:
         B, T = self.shape
         with torch.no_grad():
             eng.set_weights_from_params(self.named)
-            eps = self.eps_in if self.eps_in is not None else torch.randn(B, T, te.L, dtype=torch.float32, device=te.dev)
+            eps = self.eps_in
+            if eps is None and self.horizons is None:
+                eps = torch.randn(B, T, te.L, dtype=torch.float32, device=te.dev)
             seed = 0
             if self.p > 0:
                 seed = torch.empty(1, dtype=torch.int64, device=te.dev).random_()
+            if self.horizons is not None:
+                G = len(self.horizons)
+                if eps is None:                  # fresh noise per horizon (the reference's randn_like per forward, :1218)
+                    eps = torch.randn(G, B, T, te.L, dtype=torch.float32, device=te.dev)
+                losses, gp = te.loss_and_grads_multihorizon(self.surf, self.ex, self.horizons, self.weights, self.loss_cfg,
+                                                            eps=[eps[g] for g in range(G)], dropout_p=self.p,
+                                                            dropout_seed=seed)
+                grads = te.param_grads(gp)
+                vec = torch.cat([torch.stack([losses["loss"], losses["reconstruction_loss"], losses["kl_loss"]]),
+                                 losses["horizon_losses"]]).to(torch.float64)
+                return vec, grads, eng.packed
             losses, gp, _ = te.loss_and_grads(self.surf, self.ex, self.horizon, self.loss_cfg, eps=eps,
                                               dropout_p=self.p, dropout_seed=seed)
             grads = te.param_grads(gp)
@@ -99,7 +121,10 @@ class GraphedLossGrads:
         self.eng.packed = self.packed            # what the blob now holds: the parameters as of this replay
         self.eng._fold_stale = True              # (generation's folded head section is rebuilt on demand)
         v = self.loss_vec.clone()
-        losses = {"loss": v[0], "re_surface": v[1], "re_ex_feats": v[2], "reconstruction_loss": v[3], "kl_loss": v[4]}
+        if self.horizons is not None:
+            losses = {"loss": v[0], "reconstruction_loss": v[1], "kl_loss": v[2], "horizon_losses": v[3:]}
+        else:
+            losses = {"loss": v[0], "re_surface": v[1], "re_ex_feats": v[2], "reconstruction_loss": v[3], "kl_loss": v[4]}
         self.te.last_flat, self.te.last_partials = self.flat, self.partials
         return losses, self.grads
 
@@ -112,15 +137,18 @@ class GraphCache:
         self._d: "OrderedDict[tuple, GraphedLossGrads]" = OrderedDict()
 
     def get(self, te, named_params, surf, ex, horizon, loss_cfg: Dict, dropout_p: float,
-            inject_eps: bool = False) -> GraphedLossGrads:
+            inject_eps: bool = False, horizons=None, weights=None) -> GraphedLossGrads:
         B, T = surf.shape[:2]
+        mh = horizons is not None
         key = (B, T, ex is not None, int(horizon), float(dropout_p), bool(inject_eps),
                tuple(sorted((k, tuple(v) if isinstance(v, (list, tuple)) else v) for k, v in loss_cfg.items()
-                            if k not in ("ex_weight", "kl_weight"))),
+                            if mh or k not in ("ex_weight", "kl_weight"))),
+               None if not mh else (tuple(int(h) for h in horizons), tuple(float(w) for w in weights)),
                tuple(p.data_ptr() for _, p in named_params), id(te))
         g = self._d.get(key)
         if g is None:
-            g = GraphedLossGrads(te, named_params, B, T, ex is not None, horizon, loss_cfg, dropout_p, inject_eps)
+            g = GraphedLossGrads(te, named_params, B, T, ex is not None, horizon, loss_cfg, dropout_p, inject_eps,
+                                 horizons, weights)
             self._d[key] = g
             while len(self._d) > self.capacity:
                 self._d.popitem(last=False)

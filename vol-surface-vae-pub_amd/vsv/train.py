@@ -707,7 +707,11 @@ class TrainEngine:
                 la.d_pred, la.d_zm, la.d_zl = d_pred[r0:].data_ptr(), d_zm[r0:].data_ptr(), d_zl[r0:].data_ptr()
                 la.sums = sums[g:].data_ptr()
                 _lib.check(lib.vsv_loss_grad(C.byref(la), st), "vsv_loss_grad")
-            w = torch.tensor([float(x) for x in weights], dtype=torch.float64, device=dev)
+            wkey = tuple(float(x) for x in weights)
+            wc = self.__dict__.setdefault("_mh_weights", {})
+            w = wc.get(wkey)                                      # (cached: no host copy inside a graph capture)
+            if w is None:
+                w = wc[wkey] = torch.tensor(list(wkey), dtype=torch.float64, device=dev)
             recon = sums[:, 0] + float(loss_cfg["ex_weight"]) * sums[:, 1] if X > 0 else sums[:, 0]
             hl = recon + klw * sums[:, 2]
             losses = {"loss": (w * hl).sum(), "reconstruction_loss": (w * recon).sum(),

@@ -45,7 +45,7 @@
 extern "C" {
 #endif
 
-#define VSV_ABI_VERSION 20
+#define VSV_ABI_VERSION 21
 #define VSV_MAX_CONV 4
 #define VSV_MAX_CHAIN 8
 #define VSV_MAX_INTERACT 3
@@ -377,6 +377,16 @@ int vsv_train_encode(const vsv_dims *dims, const float *packed, int which,
                      const float *surf, long surf_row_stride, long surf_t_stride,
                      const float *ex, long ex_row_stride, long ex_t_stride,
                      long n_rows, int T, float *out, const vsv_train_save *sv, void *stream);
+/* Both encoders' vsv_train_encode in one call -- posterior encoder (which = 0) over T0 steps into out0 / sv0, context
+ * encoder (which = 1) over T1 steps into out1 / sv1, same batch: CVAEMemRand.forward's two independent encoder calls
+ * (cvae_with_mem_randomized.py:1046-1058).  Few row tiles (<= 16 of 32 rows): every launch of a stack goes out
+ * together with its twin of the other stack as ONE launch (half the launches, both stacks side by side without a second
+ * stream); otherwise the two stacks run one after the other on `stream`.  Results equal two vsv_train_encode calls. */
+int vsv_train_encode_pair(const vsv_dims *dims, const float *packed,
+                          const float *surf, long surf_row_stride, long surf_t_stride,
+                          const float *ex, long ex_row_stride, long ex_t_stride,
+                          long n_rows, int T0, int T1, float *out0, float *out1,
+                          const vsv_train_save *sv0, const vsv_train_save *sv1, void *stream);
 int vsv_train_decode(const vsv_dims *dims, const float *packed, const vsv_decode_in *in,
                      long n_rows, int T, int t_out0, float *z_out, float *surf_out, float *ex_out,
                      const vsv_train_save *sv, void *stream);

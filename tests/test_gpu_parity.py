@@ -971,6 +971,25 @@ def test_one_launch_adamw_step_equals_torch_adamw():
         assert float((a - b).abs().max()) <= 2e-6 * max(1.0, float(b.abs().max()))
     for a, b in zip(ma + va, mb + vb):
         assert float((a - b).abs().max()) <= 1e-5 * max(1e-12, float(b.abs().max()))
+    # the validated-once fast path notices a replaced optimizer state: state_dict round trip in the middle of a run
+    # (new state tensors, step counters that are no longer views of one block) against an uninterrupted run
+    finals = []
+    for reload in (False, True):
+        torch.manual_seed(4)
+        model = CVAEMemRand(vo.make_config(5, 3, device="cuda:0"))
+        opt = torch.optim.AdamW(model.parameters(), lr=1e-3, weight_decay=0.02)
+        eps = torch.from_numpy(np.random.default_rng(9).standard_normal((8, 16, 9, 5)).astype(np.float32))
+        for k in range(8):
+            if reload and k == 4:
+                sd = {kk: (vv.clone() if torch.is_tensor(vv) else vv) for kk, vv in opt.state_dict().items()}
+                import copy
+                opt.load_state_dict(copy.deepcopy(opt.state_dict()))
+                assert float(opt.state[next(model.parameters())]["step"]) == 4.0
+            model.train_step(x, opt, _eps=eps[k])
+        assert {float(opt.state[q]["step"]) for q in model.parameters()} == {8.0}
+        finals.append([q.detach().clone() for q in model.parameters()])
+    for a, b in zip(*finals):
+        assert torch.equal(a, b)
     # anything but the plain case keeps torch's step(): amsgrad here
     model = CVAEMemRand(vo.make_config(5, 0, device="cuda:0"))
     opt = torch.optim.AdamW(model.parameters(), lr=1e-3, amsgrad=True)

@@ -683,9 +683,12 @@ constexpr int kDenseSlots = 16 * kHeadTiles;     // LDS k-step slots per wave
 // loads at a run-time offset): indexing the by-value copy with a run-time li makes the compiler keep
 // the whole struct in scratch (1 KiB per lane).  The struct is the kernel's only explicit argument,
 // so it sits at offset 0 of the segment.
-__device__ __forceinline__ DenseLayerArg chain_layer_of_kernarg(int li) {
+__device__ __forceinline__ DenseLayerArg chain_layer_of_kernarg(int li, unsigned koff = 0) {
+    // (koff: byte offset of the DenseChainArgs inside the kernarg segment -- 0 for the kernels whose only argument
+    // it is, sizeof(DenseChainArgs) for the second set of dense_chain_wg_pair_kernel)
     typedef const __attribute__((address_space(4))) DenseChainArgs* KP;
-    const KP kp = (KP)__builtin_amdgcn_kernarg_segment_ptr();
+    typedef const __attribute__((address_space(4))) char* KC;
+    const KP kp = (KP)((KC)__builtin_amdgcn_kernarg_segment_ptr() + koff);
     DenseLayerArg r;
     r.w = kp->layer[li].w;
     r.b = kp->layer[li].b;
@@ -883,7 +886,7 @@ __global__ void __launch_bounds__(256, 2) dense_chain_kernel(const DenseChainArg
 // training batch of 64 at horizon 1 is two instances; the latent heads and small date ranges likewise): wave w
 // computes output tile w of every layer from the column shared in LDS.  Per-tile product chains as in
 // dense_chain_kernel: results are bit-equal.
-__global__ void __launch_bounds__(256) dense_chain_wg_kernel(const DenseChainArgs a) {
+__device__ __forceinline__ void dense_chain_wg_body(const DenseChainArgs& a, const unsigned koff) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const long inst = (long)blockIdx.x;
@@ -924,7 +927,7 @@ __global__ void __launch_bounds__(256) dense_chain_wg_kernel(const DenseChainArg
 #pragma unroll
             for (int k = 0; k < 16; ++k) sv[(s_lo + k) * 64] = col[(s_lo + k) * 64];
         }
-        const DenseLayerArg ly = chain_layer_of_kernarg(li);
+        const DenseLayerArg ly = chain_layer_of_kernarg(li, koff);
         const bool last = (li == a.n_layers - 1);
         const bool mine = wave < ly.nt;
         f32x16 acc[1];
@@ -982,6 +985,15 @@ __global__ void __launch_bounds__(256) dense_chain_wg_kernel(const DenseChainArg
             for (int r = 0; r < 16; ++r) col[(s_lo + r) * 64] = acc[0][r];        // (tiles >= nt: zeros)
             __syncthreads();
         }
+    }
+}
+__global__ void __launch_bounds__(256) dense_chain_wg_kernel(const DenseChainArgs a) { dense_chain_wg_body(a, 0u); }
+// two chains as one launch (blockIdx.y picks the argument set; see lstm_rec4_pair_kernel)
+__global__ void __launch_bounds__(256) dense_chain_wg_pair_kernel(const DenseChainArgs a0, const DenseChainArgs a1) {
+    if (blockIdx.y == 0) {
+        if ((long)blockIdx.x < a0.n_rowtiles * a0.T) dense_chain_wg_body(a0, 0u);
+    } else {
+        if ((long)blockIdx.x < a1.n_rowtiles * a1.T) dense_chain_wg_body(a1, (unsigned)sizeof(DenseChainArgs));
     }
 }
 
@@ -2054,7 +2066,7 @@ __device__ __forceinline__ f32x4 mfma4(float a, float b, f32x4 c) { return __bui
 // time grows with R (four tiles per workgroup measured no better than lstm_rec16_kernel), so larger launches stay on
 // that kernel.  Every tile's chain is the same ascending-k chain: results do not depend on R.
 template <int NT, bool SAVE, int R>
-__global__ void __launch_bounds__(512) lstm_rec4_kernel(const LstmSeqArgs a) {
+__device__ __forceinline__ void lstm_rec4_body(const LstmSeqArgs& a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int HP = 8 * NT, HPK = 4 * NT;
     constexpr int NG = (HP + 15) / 16;                             // unit groups (waves with work)
@@ -2249,6 +2261,22 @@ __global__ void __launch_bounds__(512) lstm_rec4_kernel(const LstmSeqArgs a) {
         for (int r = 0; r < R; ++r)
             if (row_ok[r] && uok)
                 *(float4*)(a.din.gate_out + ((size_t)row[r] * SNL + a.st_l0) * NT * 32 + bi) = make_float4(g[r][0], g[r][1], g[r][2], g[r][3]);
+    }
+}
+template <int NT, bool SAVE, int R>
+__global__ void __launch_bounds__(512) lstm_rec4_kernel(const LstmSeqArgs a) {
+    lstm_rec4_body<NT, SAVE, R>(a);
+}
+// Two independent launches of the above as ONE (blockIdx.y picks the argument set): the two encoders of a training
+// step are independent stacks of sixteen 4-row tiles each at batch 64 -- a launch of its own per stack leaves the
+// chip to one of them at a time, and running them on two streams costs a cross-queue fork and join (~25 us, and the
+// side queue picks its first packet up 60 - 90 us late: profiles/r3_f_train_timeline_graph.txt).
+template <int NT, bool SAVE, int R>
+__global__ void __launch_bounds__(512) lstm_rec4_pair_kernel(const LstmSeqArgs a0, const LstmSeqArgs a1) {
+    if (blockIdx.y == 0) {
+        if ((long)blockIdx.x * R < 8 * a0.n_rowtiles) lstm_rec4_body<NT, SAVE, R>(a0);
+    } else {
+        if ((long)blockIdx.x * R < 8 * a1.n_rowtiles) lstm_rec4_body<NT, SAVE, R>(a1);
     }
 }
 
@@ -4636,8 +4664,8 @@ constexpr int kPreMaxQ = 16;     // input quads (8 features each) of a layer: <=
 // the result lands in the layer's slots of sv_gates, where the recurrent launch (rec) picks it up and
 // later overwrites it with the activated gates.
 template <int NT>
-__global__ void __launch_bounds__(64 * NT) lstm_pre_kernel(const float* w, const float* b, int nq_in, const float* x,
-                                                           long x_stride, float* gates, long g_stride, long n_inst, int ipw) {
+__device__ __forceinline__ void lstm_pre_body(const float* w, const float* b, int nq_in, const float* x,
+                                              long x_stride, float* gates, long g_stride, long n_inst, int ipw) {
     // an instance's x (4 nq_in k-steps x 64 lanes, contiguous) is shared by the NT waves: the workgroup copies it
     // into LDS once -- the NEXT instance's while this one's products run (double buffer, one barrier per instance) --
     // and every wave reads its B operands from there.  (Read straight from global memory, quad by quad in front of
@@ -4707,6 +4735,25 @@ __global__ void __launch_bounds__(64 * NT) lstm_pre_kernel(const float* w, const
         if (k + 1 < n_here) stash((k + 1) & 1, after);             // (that buffer's readers passed the last barrier)
         __syncthreads();
     }
+}
+template <int NT>
+__global__ void __launch_bounds__(64 * NT) lstm_pre_kernel(const float* w, const float* b, int nq_in, const float* x,
+                                                           long x_stride, float* gates, long g_stride, long n_inst, int ipw) {
+    lstm_pre_body<NT>(w, b, nq_in, x, x_stride, gates, g_stride, n_inst, ipw);
+}
+// two launches as one (see lstm_rec4_pair_kernel): blockIdx.y picks the argument set, all of it scalars
+struct PreArgs {
+    const float *w, *b, *x;
+    float* gates;
+    long x_stride, g_stride, n_inst;
+    int nq_in, ipw;
+};
+template <int NT>
+__global__ void __launch_bounds__(64 * NT) lstm_pre_pair_kernel(const PreArgs p0, const PreArgs p1) {
+    const bool y = blockIdx.y != 0;
+    lstm_pre_body<NT>(y ? p1.w : p0.w, y ? p1.b : p0.b, y ? p1.nq_in : p0.nq_in, y ? p1.x : p0.x,
+                      y ? p1.x_stride : p0.x_stride, y ? p1.gates : p0.gates, y ? p1.g_stride : p0.g_stride,
+                      y ? p1.n_inst : p0.n_inst, y ? p1.ipw : p0.ipw);
 }
 
 static int launch_lstm_pre(int NT, const float* w, const float* b, int nq_in, const float* x, long x_stride,
@@ -5784,21 +5831,30 @@ extern "C" int vsv_philox_normal(uint64_t seed, long day0, long n_days, long S, 
 // ---------------------------------------------------------------------------
 // training entry points
 // ---------------------------------------------------------------------------
-extern "C" int vsv_train_encode(const vsv_dims* dims, const float* packed, int which,
-                                const float* surf, long surf_row_stride, long surf_t_stride,
-                                const float* ex, long ex_row_stride, long ex_t_stride,
-                                long n_rows, int T, float* out, const vsv_train_save* sv, void* stream) {
-    VSV_LAYOUT_OR_FAIL("vsv_train_encode")
+// The launches of one encoder stack's training forward: conv embedding chain, per layer the input product for all
+// steps + the recurrent launch, latent / compression head.
+struct TrainEncPlan {
+    DenseChainArgs emb, head;
+    LstmSeqArgs l;
+    const EncLayout* e;
+    long rt;
+    int T;
+};
+static int plan_train_encode(const Layout& lay, const float* packed, int which,
+                             const float* surf, long surf_row_stride, long surf_t_stride,
+                             const float* ex, long ex_row_stride, long ex_t_stride,
+                             long n_rows, int T, float* out, const vsv_train_save* sv, TrainEncPlan& p) {
     if (!packed || !surf || !out || !sv) { set_error("vsv_train_encode: null pointer"); return -1; }
     if (!sv->emb_acts || !sv->xe || !sv->gates || !sv->c || !sv->h || !sv->hout) { set_error("vsv_train_encode: incomplete save set"); return -1; }
     if (which < 0 || which > 1) { set_error("vsv_train_encode: which must be 0 or 1"); return -1; }
     if (n_rows < 1 || T < 1) { set_error("vsv_train_encode: empty batch"); return -1; }
     if (lay.X > 0 && !ex) { set_error("vsv_train_encode: ex_feats_dim > 0 but ex is null"); return -1; }
-    hipStream_t st = (hipStream_t)stream;
     const EncLayout& e = lay.enc[which];
     const long rt = (n_rows + 31) / 32;
+    p.e = &e; p.rt = rt; p.T = T;
 
-    DenseChainArgs a = {};
+    DenseChainArgs& a = p.emb;
+    a = DenseChainArgs();
     a.n_layers = e.n_chain;
     for (int i = 0; i < e.n_chain; ++i) fill_dense(a, i, packed, e.conv[i]);
     a.inj_layer = e.n_conv - 1;
@@ -5809,10 +5865,9 @@ extern "C" int vsv_train_encode(const vsv_dims* dims, const float* packed, int w
     a.out_mode = 0; a.out = sv->xe; a.out_f = e.E; a.S = 1;
     a.aux_layer = -1;
     a.save = sv->emb_acts;
-    int rc = launch_dense_chain(a, st);
-    if (rc) return rc;
 
-    LstmSeqArgs l = {};
+    LstmSeqArgs& l = p.l;
+    l = LstmSeqArgs();
     l.gru = lay.gru;
     for (int i = 0; i < lay.NL; ++i) { l.w[i] = packed + e.lstm[i].w_off; l.b[i] = packed + e.lstm[i].b_off; }
     l.kx = e.kx; l.n_rows = n_rows; l.n_rowtiles = rt; l.T = T;
@@ -5820,34 +5875,120 @@ extern "C" int vsv_train_encode(const vsv_dims* dims, const float* packed, int w
     l.hout = sv->hout; l.t_out0 = 0;
     l.sv_gates = sv->gates; l.sv_c = sv->c; l.sv_h = sv->h;
     if (int rcd = fill_dropout(l, sv, lay.NL, "vsv_train_encode")) return rcd;
-    if (per_layer_forward(lay.NL, rt)) {
-        const int NT = lay.NTm;
-        const long gs = (long)lay.NL * 16 * NT * 64, hs = (long)lay.NL * 4 * NT * 64;
-        for (int L = 0; L < 2 && !rc; ++L) {
-            const float* x = (L == 0) ? sv->xe : (l.sv_hd ? l.sv_hd : sv->h);
-            const long xs = (L == 0) ? (long)e.kx * 64 : (l.sv_hd ? (long)4 * NT * 64 : hs);
-            const int nq_in = (L == 0) ? e.kx >> 2 : NT;
-            rc = launch_lstm_pre(NT, l.w[L], l.b[L], nq_in, x, xs, sv->gates + (size_t)L * 16 * NT * 64, gs, rt * T, st);
-            if (rc) return rc;
-            LstmSeqArgs r = l;
-            r.w[0] = l.w[L]; r.b[0] = l.b[L]; r.kx = 4 * nq_in;
-            r.rec = 1; r.sv_nl = 2; r.sv_l0 = L;
-            r.hout = (L == 1) ? sv->hout : nullptr;
-            rc = launch_lstm<0>(r, NT, 1, false, st);
-        }
-    } else {
-        rc = launch_lstm<0>(l, lay.NTm, lay.NL, false, st);
-    }
-    if (rc) return rc;
 
-    DenseChainArgs h = {};
+    DenseChainArgs& h = p.head;
+    h = DenseChainArgs();
     h.n_layers = 1;
     fill_dense(h, 0, packed, e.head);
     h.n_rows = n_rows; h.n_rowtiles = rt; h.T = T;
     h.in_mode = 1; h.in = sv->hout; h.in_ks = 4 * lay.NTm;
     h.out_mode = 1; h.out = out; h.out_f = e.nh; h.S = 1;
     h.aux_layer = -1;
-    return launch_dense_chain(h, st);
+    return 0;
+}
+// layer L of a per-layer forward: the input product's arguments and the recurrent launch's
+static void train_encode_layer(const Layout& lay, const TrainEncPlan& p, const vsv_train_save* sv, int L, PreArgs& pre, LstmSeqArgs& r) {
+    const int NT = lay.NTm;
+    const LstmSeqArgs& l = p.l;
+    const long gs = (long)lay.NL * 16 * NT * 64, hs = (long)lay.NL * 4 * NT * 64;
+    pre.x = (L == 0) ? sv->xe : (l.sv_hd ? l.sv_hd : sv->h);
+    pre.x_stride = (L == 0) ? (long)p.e->kx * 64 : (l.sv_hd ? (long)4 * NT * 64 : hs);
+    pre.nq_in = (L == 0) ? p.e->kx >> 2 : NT;
+    pre.w = l.w[L]; pre.b = l.b[L];
+    pre.gates = sv->gates + (size_t)L * 16 * NT * 64; pre.g_stride = gs;
+    pre.n_inst = p.rt * p.T; pre.ipw = 0;
+    r = l;
+    r.w[0] = l.w[L]; r.b[0] = l.b[L]; r.kx = 4 * pre.nq_in;
+    r.rec = 1; r.sv_nl = 2; r.sv_l0 = L;
+    r.hout = (L == 1) ? sv->hout : nullptr;
+}
+static int run_train_encode(const Layout& lay, const TrainEncPlan& p, const vsv_train_save* sv, hipStream_t st) {
+    int rc = launch_dense_chain(p.emb, st);
+    if (rc) return rc;
+    if (per_layer_forward(lay.NL, p.rt)) {
+        for (int L = 0; L < 2 && !rc; ++L) {
+            PreArgs pre;
+            LstmSeqArgs r;
+            train_encode_layer(lay, p, sv, L, pre, r);
+            rc = launch_lstm_pre(lay.NTm, pre.w, pre.b, pre.nq_in, pre.x, pre.x_stride, pre.gates, pre.g_stride, pre.n_inst, st);
+            if (rc) return rc;
+            rc = launch_lstm<0>(r, lay.NTm, 1, false, st);
+        }
+    } else {
+        rc = launch_lstm<0>(p.l, lay.NTm, lay.NL, false, st);
+    }
+    if (rc) return rc;
+    return launch_dense_chain(p.head, st);
+}
+
+extern "C" int vsv_train_encode(const vsv_dims* dims, const float* packed, int which,
+                                const float* surf, long surf_row_stride, long surf_t_stride,
+                                const float* ex, long ex_row_stride, long ex_t_stride,
+                                long n_rows, int T, float* out, const vsv_train_save* sv, void* stream) {
+    VSV_LAYOUT_OR_FAIL("vsv_train_encode")
+    TrainEncPlan p;
+    if (int rc = plan_train_encode(lay, packed, which, surf, surf_row_stride, surf_t_stride, ex, ex_row_stride, ex_t_stride,
+                                   n_rows, T, out, sv, p)) return rc;
+    return run_train_encode(lay, p, sv, (hipStream_t)stream);
+}
+
+// Both encoders of a training step in one call: the posterior encoder (which = 0) over T0 steps and the context
+// encoder (which = 1) over T1 steps of the same batch.  With few row tiles (a batch of 64: sixteen 4-row tiles per
+// stack) every launch of a stack has a twin in the other stack, and each pair goes out as ONE launch whose
+// blockIdx.y picks the stack -- six launches instead of twelve, the two stacks side by side on the chip without a
+// second stream.  Larger batches (or other memories) run the two stacks one after the other on `stream`: same
+// results either way (the kernels and their arguments are those of vsv_train_encode).
+extern "C" int vsv_train_encode_pair(const vsv_dims* dims, const float* packed,
+                                     const float* surf, long surf_row_stride, long surf_t_stride,
+                                     const float* ex, long ex_row_stride, long ex_t_stride,
+                                     long n_rows, int T0, int T1, float* out0, float* out1,
+                                     const vsv_train_save* sv0, const vsv_train_save* sv1, void* stream) {
+    VSV_LAYOUT_OR_FAIL("vsv_train_encode_pair")
+    hipStream_t st = (hipStream_t)stream;
+    TrainEncPlan p[2];
+    const int Ts[2] = {T0, T1};
+    float* outs[2] = {out0, out1};
+    const vsv_train_save* svs[2] = {sv0, sv1};
+    for (int k = 0; k < 2; ++k)
+        if (int rc = plan_train_encode(lay, packed, k, surf, surf_row_stride, surf_t_stride, ex, ex_row_stride, ex_t_stride,
+                                       n_rows, Ts[k], outs[k], svs[k], p[k])) return rc;
+    static const bool off = [] { const char* e = getenv("VSV_ENC_PAIR"); return e && e[0] == '0'; }();
+    const long rt = p[0].rt;
+    bool pair = !off && lay.NL == 2 && !lay.gru && lay.NTm == 13 && per_layer_forward(lay.NL, rt) && 8 * rt <= 128;
+    for (int k = 0; k < 2 && pair; ++k) {
+        PreArgs pre;
+        LstmSeqArgs r;
+        train_encode_layer(lay, p[k], svs[k], 0, pre, r);
+        pair = lstm_rec16_applies(r, 1) && lstm_rec4_applies(r) && rt * Ts[k] <= 512 && p[k].emb.in_ks <= kDenseSlots;
+    }
+    if (!pair) {
+        for (int k = 0; k < 2; ++k)
+            if (int rc = run_train_encode(lay, p[k], svs[k], st)) return rc;
+        return 0;
+    }
+    const long nmax = rt * (Ts[0] > Ts[1] ? Ts[0] : Ts[1]);
+    const size_t lds1 = (size_t)kDenseSlots * 64 * sizeof(float);
+    hipLaunchKernelGGL(dense_chain_wg_pair_kernel, dim3((unsigned)nmax, 2), dim3(256), lds1, st, p[0].emb, p[1].emb);
+    if (int rc = launch_check("dense_chain_wg_pair_kernel")) return rc;
+    for (int L = 0; L < 2; ++L) {
+        PreArgs pre[2];
+        LstmSeqArgs r[2];
+        unsigned grid = 0;
+        for (int k = 0; k < 2; ++k) {
+            train_encode_layer(lay, p[k], svs[k], L, pre[k], r[k]);
+            int ipw = (int)((pre[k].n_inst + 255) / 256);
+            pre[k].ipw = ipw < 1 ? 1 : (ipw > 64 ? 64 : ipw);
+            const unsigned g = (unsigned)((pre[k].n_inst + pre[k].ipw - 1) / pre[k].ipw);
+            grid = g > grid ? g : grid;
+        }
+        hipLaunchKernelGGL(lstm_pre_pair_kernel<13>, dim3(grid, 2), dim3(64 * 13), 0, st, pre[0], pre[1]);
+        if (int rc = launch_check("lstm_pre_pair_kernel")) return rc;
+        const size_t lds = (size_t)2 * 1 * 4 * 144 * sizeof(float);
+        hipLaunchKernelGGL((lstm_rec4_pair_kernel<13, true, 1>), dim3((unsigned)(8 * rt), 2), dim3(512), lds, st, r[0], r[1]);
+        if (int rc = launch_check("lstm_rec4_pair_kernel")) return rc;
+    }
+    hipLaunchKernelGGL(dense_chain_wg_pair_kernel, dim3((unsigned)nmax, 2), dim3(256), lds1, st, p[0].head, p[1].head);
+    return launch_check("dense_chain_wg_pair_kernel");
 }
 
 extern "C" int vsv_train_decode(const vsv_dims* dims, const float* packed, const vsv_decode_in* in,

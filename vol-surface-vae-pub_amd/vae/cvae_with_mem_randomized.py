@@ -631,8 +631,9 @@ class CVAEMemRand(BaseVAE):
         for p, g, fz in zip(params, grads, frozen):
             if fz:
                 continue
-            g = g.to(p.dtype)
-            views = views and p.grad is None and g.dtype == torch.float32
+            if g.dtype is not p.dtype:
+                g = g.to(p.dtype)
+            views = views and p.grad is None and g.dtype is torch.float32
             if p.grad is None:
                 # eager-path gradients and scaled copies are fresh tensors; graph outputs are copied out
                 # unless aliasing was allowed
@@ -678,51 +679,88 @@ class CVAEMemRand(BaseVAE):
         if not all(isinstance(v, (int, float)) for v in (lr, b1, b2, g["eps"], g["weight_decay"])):
             return False
         params = [p for _, p in self._hip_named_params()]
-        if any((not p.requires_grad) or p.grad is None for p in params):
-            return False
-        gp = g["params"]
-        if len(gp) != len(params) or any(a is not b for a, b in zip(gp, params)):
-            return False
-        st = optimizer.state
-        ms, vs, steps = [], [], []
         for p in params:
-            s = st.get(p)
-            if not s or "exp_avg" not in s:
+            if p.grad is None or not p.requires_grad:
                 return False
-            ms.append(s["exp_avg"]); vs.append(s["exp_avg_sq"]); steps.append(s["step"])
-        dev = flat.device
-        if any(t.dtype != torch.float32 or t.device != dev or not t.is_contiguous() for t in params + ms + vs):
+        gp = g["params"]
+        if len(gp) != len(params):
             return False
-        if any(t.device.type != "cpu" for t in steps):
-            return False
-        step = float(steps[0])
-        if any(float(t) != step for t in steps[1:]) or step < 1 or step != int(step):
-            return False
+        for a, b in zip(gp, params):
+            if a is not b:
+                return False
+        st = optimizer.state
         te = self.__dict__["_vsv_train_engine"]
-        key = tuple(t.data_ptr() for t in params + ms + vs)
-        cache = self.__dict__.get("_vsv_adamw")
-        if cache is None or cache[0] != key:
-            n = len(params)
-            tab = torch.tensor(key, dtype=torch.int64).to(dev)
+        dev = flat.device
+        n = len(params)
+        # The per-step host cost of this method used to exceed the step's GPU time at batch 64 (56 parameters x
+        # dtype / device / contiguity / step-count checks): what has been validated once is re-checked by IDENTITY --
+        # the optimizer's state dicts and their three tensors are the objects validated, and every tensor still
+        # lives where the device pointer table says (load_state_dict, .to() and .data swaps all change one of these).
+        fast = self.__dict__.get("_vsv_adamw")
+        ok = fast is not None and fast["optimizer"] is optimizer and fast["n"] == n and len(st) == n
+        if ok:
+            for p, sd, m, v, k in zip(params, fast["dicts"], fast["ms"], fast["vs"], fast["steps"]):
+                s = st.get(p)
+                if s is not sd or s.get("exp_avg") is not m or s.get("exp_avg_sq") is not v or s.get("step") is not k:
+                    ok = False
+                    break
+        if ok:
+            ms, vs = fast["ms"], fast["vs"]
+            ok = fast["key"] == tuple([t.data_ptr() for t in params] + [t.data_ptr() for t in ms] + [t.data_ptr() for t in vs])
+        if ok:
+            big = fast["step_block"]
+            step = float(big[0])
+            ok = step >= 1 and step == int(step) and float(big[n - 1]) == step
+        if not ok:
+            # full validation; builds the pointer table and moves the n step counters into ONE block of host memory
+            # (each state["step"] becomes a 0-d view of it: torch's own step(), state_dict() and LR schedulers see
+            # the same values, and one add_ advances them all -- a foreach over 56 host scalars cost 80 us)
+            self.__dict__["_vsv_adamw"] = None
+            dicts, ms, vs, steps = [], [], [], []
+            for p in params:
+                s = st.get(p)
+                if not s or "exp_avg" not in s:
+                    return False
+                dicts.append(s); ms.append(s["exp_avg"]); vs.append(s["exp_avg_sq"]); steps.append(s["step"])
+            if any(t.dtype != torch.float32 or t.device != dev or not t.is_contiguous() for t in params + ms + vs):
+                return False
+            if any((not torch.is_tensor(t)) or t.device.type != "cpu" or t.dim() != 0 for t in steps):
+                return False
+            step = float(steps[0])
+            if any(float(t) != step for t in steps[1:]) or step < 1 or step != int(step):
+                return False
+            if flat.numel() != int(sum(p.numel() for p in params)):
+                return False
+            big = torch.stack([t.detach().to(torch.float32) for t in steps])
+            if steps[0].dtype == torch.float32:
+                for i, s in enumerate(dicts):
+                    s["step"] = big[i]
+                steps = [s["step"] for s in dicts]
+            else:
+                big = None                                           # (unusual step dtype: leave the counters alone)
+            key = tuple([t.data_ptr() for t in params] + [t.data_ptr() for t in ms] + [t.data_ptr() for t in vs])
             offs = [0]
             for p in params:
                 offs.append(offs[-1] + p.numel())
-            starts = torch.tensor(offs, dtype=torch.int32).to(dev)
-            cache = (key, tab, starts, n)
-            self.__dict__["_vsv_adamw"] = cache
-        _, tab, starts, n = cache
-        if flat.numel() != int(sum(p.numel() for p in params)):
+            fast = dict(optimizer=optimizer, n=n, dicts=dicts, ms=ms, vs=vs, steps=steps, key=key, step_block=big, total=offs[-1],
+                        tab=torch.tensor(key, dtype=torch.int64).to(dev), starts=torch.tensor(offs, dtype=torch.int32).to(dev))
+            if big is not None:
+                self.__dict__["_vsv_adamw"] = fast
+        if flat.numel() != fast["total"]:
             return False
-        base = tab.data_ptr()
-        rc = te.lib.vsv_adamw_step(base, base + 8 * n, base + 16 * n, flat.data_ptr(), starts.data_ptr(), n, flat.numel(),
+        base = fast["tab"].data_ptr()
+        rc = te.lib.vsv_adamw_step(base, base + 8 * n, base + 16 * n, flat.data_ptr(), fast["starts"].data_ptr(), n, flat.numel(),
                                    float(lr), float(b1), float(b2), float(g["eps"]), float(g["weight_decay"]),
                                    int(step) + 1, te._stream())
         if rc != 0:
             raise RuntimeError("vsv_adamw_step: " + te.lib.vsv_last_error().decode())
-        torch._foreach_add_(steps, 1)
+        if fast["step_block"] is not None:
+            fast["step_block"].add_(1)
+        else:
+            torch._foreach_add_(fast["steps"], 1)
         # the tensors were written through their addresses: bump the version counters an in-place torch op would
-        # have bumped (the engine's re-pack test and autograd's saved-tensor checks read them)
-        touched = params + ms + vs
+        # have bumped (the engine's re-pack test and autograd's saved-tensor checks read the parameters')
+        touched = params + fast["ms"] + fast["vs"]
         try:
             torch._C._autograd._unsafe_set_version_counter(touched, [t._version + 1 for t in touched])
         except (AttributeError, TypeError, RuntimeError):

@@ -102,11 +102,10 @@ class GraphedLossGrads:
                 vec = torch.cat([torch.stack([losses["loss"], losses["reconstruction_loss"], losses["kl_loss"]]),
                                  losses["horizon_losses"]]).to(torch.float64)
                 return vec, grads, eng.packed
-            losses, gp, _ = te.loss_and_grads(self.surf, self.ex, self.horizon, self.loss_cfg, eps=eps,
-                                              dropout_p=self.p, dropout_seed=seed)
+            losses, gp, outs = te.loss_and_grads(self.surf, self.ex, self.horizon, self.loss_cfg, eps=eps,
+                                                 dropout_p=self.p, dropout_seed=seed)
             grads = te.param_grads(gp)
-            vec = torch.stack([losses[k].to(torch.float64) for k in
-                               ("loss", "re_surface", "re_ex_feats", "reconstruction_loss", "kl_loss")])
+            vec = outs["loss_vec"]               # (loss, re_surface, re_ex_feats, reconstruction_loss, kl_loss: no gather)
         return vec, grads, eng.packed
 
     def run(self, surf: torch.Tensor, ex: Optional[torch.Tensor], eps: Optional[torch.Tensor] = None):

@@ -199,6 +199,10 @@ SIGNATURES = {
     "vsv_train_encode": (C.c_int, [C.POINTER(VsvDims), C.c_void_p, C.c_int,
                                    C.c_void_p, C.c_long, C.c_long, C.c_void_p, C.c_long, C.c_long,
                                    C.c_long, C.c_int, C.c_void_p, C.POINTER(VsvTrainSave), C.c_void_p]),
+    "vsv_train_encode_pair": (C.c_int, [C.POINTER(VsvDims), C.c_void_p,
+                                        C.c_void_p, C.c_long, C.c_long, C.c_void_p, C.c_long, C.c_long,
+                                        C.c_long, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
+                                        C.POINTER(VsvTrainSave), C.POINTER(VsvTrainSave), C.c_void_p]),
     "vsv_train_decode": (C.c_int, [C.POINTER(VsvDims), C.c_void_p, C.POINTER(VsvDecodeIn),
                                    C.c_long, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
                                    C.POINTER(VsvTrainSave), C.c_void_p]),
@@ -236,7 +240,7 @@ def load() -> C.CDLL:
             fn = getattr(lib, name)
             fn.restype = res
             fn.argtypes = args
-        if lib.vsv_abi_version() != 20:
+        if lib.vsv_abi_version() != 21:
             raise RuntimeError("libvsv_hip.so ABI version mismatch")
         _lib = lib
     return _lib

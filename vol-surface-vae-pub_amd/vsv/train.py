@@ -254,6 +254,35 @@ class TrainEngine:
             s.hd, s.drop_p, s.drop_seed, s.drop_id = sv["hd"].data_ptr(), c.drop_p, c.drop_seed, drop_id
             s.drop_seed_dev = _ptr(c.drop_seed_dev)
 
+    def _enc_save(self, c, which, Tw, drop_id=None):
+        """Buffers of one encoder stack's training forward over Tw days -> (out (B, Tw, nh), sv dict, VsvTrainSave)."""
+        lay, NL, NTm = self.lay, self.NL, self.lay["NTm"]
+        e = lay["enc"][which]
+        NI = c.rt * Tw
+        sv = dict(emb_acts=self._e(self.n_conv[which], NI, 64, 64), xe=self._e(NI, e["kx"], 64),
+                  gates=self._e(NI, NL, 16 * NTm, 64), c=self._e(NI, NL, 4 * NTm, 64),
+                  h=self._e(NI, NL, 4 * NTm, 64), hout=self._e(NI, 4 * NTm, 64))
+        out = self._e(c.B, Tw, e["nh"])
+        s = _lib.VsvTrainSave()
+        for k, v in sv.items():
+            setattr(s, k, v.data_ptr())
+        self._set_drop(c, s, sv, NI, NTm, which if drop_id is None else drop_id)
+        sv["drop_id"] = which if drop_id is None else drop_id
+        return out, sv, s
+
+    def _enc_fwd_pair(self, c, T0, T1):
+        """vsv_train_encode_pair: posterior encoder over T0 days and context encoder over T1, on the current stream.
+        -> (enc_out, sv_e, ctx_out, sv_c)."""
+        out0, sv0, s0 = self._enc_save(c, 0, T0)
+        out1, sv1, s1 = self._enc_save(c, 1, T1)
+        X = self.X
+        rc = self.lib.vsv_train_encode_pair(C.byref(self.dims), c.packed.data_ptr(),
+                                            c.surf.data_ptr(), c.T * 25, 25, _ptr(c.ex), c.T * X, X,
+                                            c.B, T0, T1, out0.data_ptr(), out1.data_ptr(), C.byref(s0), C.byref(s1),
+                                            self._stream())
+        _lib.check(rc, "vsv_train_encode_pair")
+        return out0, sv0, out1, sv1
+
     def _enc_fwd(self, c, which, Tw, stream, drop_id=None):
         """vsv_train_encode of the first Tw days: buffers come from the current stream's pool, the three
         launches go to `stream`.  -> (out (B, Tw, nh), saved activations)."""
@@ -451,11 +480,16 @@ class TrainEngine:
             eng._side = torch.cuda.Stream(dev)
         side = eng._side
         with torch.cuda.device(dev):
-            # the two encoders are independent: context encoder on the side stream
-            side.wait_stream(main)
-            ctx_out, c.sv_c = self._enc_fwd(c, 1, Cc, side)
-            enc_out, c.sv_e = self._enc_fwd(c, 0, T, main)
-            main.wait_stream(side)
+            # the two encoders are independent.  Few row tiles (a batch of 64): one call whose launches carry both
+            # stacks (vsv_train_encode_pair: no second stream, half the launches).  Otherwise: context encoder on
+            # the side stream
+            if 8 * rt <= 128 and self.NL == 2 and self.dims.mem_type == 0 and os.environ.get("VSV_ENC_PAIR", "1") != "0":
+                enc_out, c.sv_e, ctx_out, c.sv_c = self._enc_fwd_pair(c, T, Cc)
+            else:
+                side.wait_stream(main)
+                ctx_out, c.sv_c = self._enc_fwd(c, 1, Cc, side)
+                enc_out, c.sv_e = self._enc_fwd(c, 0, T, main)
+                main.wait_stream(side)
             if ctx_mask is not None:
                 ctx_out = ctx_out * ctx_mask
             zm, zl = enc_out[..., :L].contiguous(), enc_out[..., L:].contiguous()
@@ -637,6 +671,7 @@ class TrainEngine:
                 sums = torch.stack([sums[0], sums[1], kl])
             v = torch.mv(M, sums)
             losses = {"loss": v[0], "re_surface": v[1], "re_ex_feats": v[2], "reconstruction_loss": v[3], "kl_loss": v[4]}
+            outputs["loss_vec"] = v                               # (the five numbers above as one float64 vector)
             if not want_grads:
                 return losses, None, outputs
             gp = self.backward_saved(c, d_pred, d_ex, d_zm, d_zl, None, want_input_grad)

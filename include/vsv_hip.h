@@ -457,6 +457,15 @@ typedef struct vsv_tileb_gemm {
 } vsv_tileb_gemm;
 int vsv_tileb_gemm_launch(const vsv_tileb_gemm *d, void *stream);
 
+/* The three backward launches above for TWO independent stacks at once (the two encoders of a training step, whose
+ * backward passes do not depend on each other: the autograd of cvae_with_mem_randomized.py:1046-1058).  Each takes the
+ * two argument sets of the matching single entry point.  With few instances (a batch of 64) the pair goes out as ONE
+ * launch whose blocks pick their set -- half the launches, both stacks side by side without a second stream --,
+ * otherwise as two launches one after the other on `stream`.  Same results as two single calls. */
+int vsv_dense_backward_pair(const vsv_dense_bwd *d0, const vsv_dense_bwd *d1, void *stream);
+int vsv_lstm_backward_pair(const vsv_lstm_bwd *d0, const vsv_lstm_bwd *d1, int hidden, int layers, void *stream);
+int vsv_tileb_gemm_launch_pair(const vsv_tileb_gemm *d0, const vsv_tileb_gemm *d1, void *stream);
+
 /* Weight gradients of dense / LSTM layers (autograd's dW = dY^T . X for nn.Linear, the conv layers'
  * expanded matrices and nn.LSTM / nn.GRU, reached from loss.backward() at :1127): for each problem,
  *   gp[position of W[n][k]] = sum over instances and rows of G[inst][a][row] * X[inst][k][row]

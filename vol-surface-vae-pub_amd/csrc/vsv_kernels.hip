@@ -3470,7 +3470,7 @@ __global__ void __launch_bounds__(256, 2) dense_bwd_kernel(const DenseBwdArgs a)
 // at horizon 1 is two instances of the decoder head: one wave each walked five layers alone, 128 us).  The column
 // is shared in LDS; wave w handles slots 16w .. 16w+15 in the element-wise phase and output tile w of W^T . g.
 // The per-tile product chains are those of dense_bwd_kernel: results are bit-equal.
-__global__ void __launch_bounds__(256) dense_bwd_wg_kernel(const DenseBwdArgs a) {
+__device__ __forceinline__ void dense_bwd_wg_body(const DenseBwdArgs& a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const long inst = (long)blockIdx.x;
@@ -3528,6 +3528,15 @@ __global__ void __launch_bounds__(256) dense_bwd_wg_kernel(const DenseBwdArgs a)
         float* o = a.dx_out + (size_t)inst * kDenseSlots * 64 + lane;
 #pragma unroll
         for (int k = 0; k < 16; ++k) o[(s_lo + k) * 64] = col[(s_lo + k) * 64];
+    }
+}
+__global__ void __launch_bounds__(256) dense_bwd_wg_kernel(const DenseBwdArgs a) { dense_bwd_wg_body(a); }
+// two launches as one (blockIdx.y picks the argument set; see lstm_rec4_pair_kernel)
+__global__ void __launch_bounds__(256) dense_bwd_wg_pair_kernel(const DenseBwdArgs a0, const DenseBwdArgs a1) {
+    if (blockIdx.y == 0) {
+        if ((long)blockIdx.x < a0.n_rowtiles * a0.T) dense_bwd_wg_body(a0);
+    } else {
+        if ((long)blockIdx.x < a1.n_rowtiles * a1.T) dense_bwd_wg_body(a1);
     }
 }
 
@@ -3880,7 +3889,7 @@ __global__ void __launch_bounds__(512) lstm_bwd16_kernel(const LstmBwdArgs a) {
 //     memory in lstm_bwd_kernel's format.  Two barriers per step.
 // ---------------------------------------------------------------------------
 template <int NT>
-__global__ void __launch_bounds__(512) lstm_bwd4_kernel(const LstmBwdArgs a) {
+__device__ __forceinline__ void lstm_bwd4_body(const LstmBwdArgs& a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int HP = 8 * NT;
     constexpr int GK = 16 * NT;
@@ -3985,6 +3994,16 @@ __global__ void __launch_bounds__(512) lstm_bwd4_kernel(const LstmBwdArgs a) {
         __syncthreads();                                           // dgates(t) published
     }
 }
+template <int NT>
+__global__ void __launch_bounds__(512) lstm_bwd4_kernel(const LstmBwdArgs a) { lstm_bwd4_body<NT>(a); }
+template <int NT>
+__global__ void __launch_bounds__(512) lstm_bwd4_pair_kernel(const LstmBwdArgs a0, const LstmBwdArgs a1) {
+    if (blockIdx.y == 0) {
+        if ((long)blockIdx.x < 8 * a0.n_rowtiles) lstm_bwd4_body<NT>(a0);
+    } else {
+        if ((long)blockIdx.x < 8 * a1.n_rowtiles) lstm_bwd4_body<NT>(a1);
+    }
+}
 
 // ---------------------------------------------------------------------------
 // tileb_gemm_kernel: Y(inst) = W^T-fragments . G(inst) for every (row tile, t) instance at once -- the
@@ -3998,7 +4017,7 @@ typedef vsv_tileb_gemm TilebGemmArgs;
 // waves take a quarter of K each and wave 0 adds the partial tiles in a fixed order -- the dependent chain of 16 NT
 // products per tile, 7 us of one CU's matrix pipe, becomes four chains of 4 NT on four SIMDs.
 template <bool SPLIT>
-__global__ void __launch_bounds__(256) tileb_gemm_kernel(const TilebGemmArgs a) {
+__device__ __forceinline__ void tileb_gemm_body(const TilebGemmArgs& a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const size_t inst = SPLIT ? blockIdx.x / (unsigned)a.ntT : blockIdx.x;
@@ -4080,6 +4099,16 @@ __global__ void __launch_bounds__(256) tileb_gemm_kernel(const TilebGemmArgs a) 
             const int f = feat_of(tile, r, hh);
             if (f < a.out_f) o[f] = acc[0][r];
         }
+    }
+}
+template <bool SPLIT>
+__global__ void __launch_bounds__(256) tileb_gemm_kernel(const TilebGemmArgs a) { tileb_gemm_body<SPLIT>(a); }
+// two SPLIT launches as one (blockIdx.y picks the argument set; see lstm_rec4_pair_kernel)
+__global__ void __launch_bounds__(256) tileb_gemm_pair_kernel(const TilebGemmArgs a0, const TilebGemmArgs a1) {
+    if (blockIdx.y == 0) {
+        if ((long)blockIdx.x < a0.n_rowtiles * a0.T * a0.ntT) tileb_gemm_body<true>(a0);
+    } else {
+        if ((long)blockIdx.x < a1.n_rowtiles * a1.T * a1.ntT) tileb_gemm_body<true>(a1);
     }
 }
 
@@ -6342,6 +6371,84 @@ extern "C" int vsv_tileb_gemm_launch(const vsv_tileb_gemm* d, void* stream) {
         hipLaunchKernelGGL(tileb_gemm_kernel<false>, dim3((unsigned)insts), dim3(256), lds, (hipStream_t)stream, *d);
     }
     return launch_check("tileb_gemm_kernel");
+}
+
+// ---- the backward launches of TWO independent stacks as one launch each (the two encoders of a training step at
+// few row tiles: see vsv_train_encode_pair).  Each *_pair entry point takes the two argument sets of the matching
+// single entry point; when both would run the few-instance kernel they go out as one launch whose blockIdx.y picks
+// the set, otherwise as two launches one after the other on `stream`.  Same results either way.
+static bool pair_off() {
+    static const bool off = [] { const char* e = getenv("VSV_ENC_PAIR"); return e && e[0] == '0'; }();
+    return off;
+}
+extern "C" int vsv_dense_backward_pair(const vsv_dense_bwd* d0, const vsv_dense_bwd* d1, void* stream) {
+    static const bool wg_off = [] { const char* e = getenv("VSV_DENSE_BWD_WG"); return e && e[0] == '0'; }();
+    const bool ok = d0 && d1 && !pair_off() && !wg_off && d0->n_rowtiles * d0->T <= 1024 && d1->n_rowtiles * d1->T <= 1024 &&
+                    d0->n_rowtiles * d0->T >= 1 && d1->n_rowtiles * d1->T >= 1;
+    if (!ok) {
+        if (int rc = vsv_dense_backward(d0, stream)) return rc;
+        return vsv_dense_backward(d1, stream);
+    }
+    // (argument checks of the single entry point, per set)
+    for (const vsv_dense_bwd* d : {d0, d1}) {
+        if (!d->in || d->n_layers < 1 || d->n_layers > VSV_MAX_CHAIN || d->n_rows < 1 || d->T < 1 ||
+            d->n_rowtiles != (d->n_rows + 31) / 32 || (d->in_mode == 0 && d->in_f < 1)) {
+            set_error("vsv_dense_backward_pair: bad arguments"); return -1;
+        }
+        for (int i = 0; i < d->n_layers; ++i) {
+            const vsv_dense_bwd_layer& ly = d->layer[i];
+            if ((ly.add && ly.add_n < 1) || ly.ntT < 0 || ly.ntT > kHeadTiles ||
+                (ly.ntT > 0 && (!ly.wT || ly.nqT < 1 || ly.nqT > 4 * kHeadTiles))) {
+                set_error("vsv_dense_backward_pair: layer %d has an unsupported shape", i); return -1;
+            }
+        }
+    }
+    const long n0 = d0->n_rowtiles * d0->T, n1 = d1->n_rowtiles * d1->T;
+    const size_t lds1 = (size_t)kDenseSlots * 64 * sizeof(float);
+    hipLaunchKernelGGL(dense_bwd_wg_pair_kernel, dim3((unsigned)(n0 > n1 ? n0 : n1), 2), dim3(256), lds1, (hipStream_t)stream, *d0, *d1);
+    return launch_check("dense_bwd_wg_pair_kernel");
+}
+
+extern "C" int vsv_lstm_backward_pair(const vsv_lstm_bwd* d0, const vsv_lstm_bwd* d1, int hidden, int layers, void* stream) {
+    static const bool no4 = [] { const char* e = getenv("VSV_BWD4"); return e && e[0] == '0'; }();
+    const int NT = (hidden + 7) / 8;
+    bool ok = d0 && d1 && !pair_off() && !no4 && NT == 13 && layers == 1;
+    for (const vsv_lstm_bwd* d : {d0, d1}) {
+        if (!ok) break;
+        ok = d->sv_gates && d->sv_c && d->dgates && d->wT_hh[0] && d->n_rows >= 1 && d->T >= 1 && d->t_out0 >= 0 && d->t_out0 <= d->T &&
+             d->n_rowtiles == (d->n_rows + 31) / 32 && d->nt_x == 0 && d->drop_p >= 0.0f && d->drop_p < 1.0f &&
+             !(d->sv_nl < 0 || (d->sv_nl > 0 && (d->sv_l0 < 0 || d->sv_l0 + layers > d->sv_nl))) &&
+             lstm_bwd16_applies(*d, layers) && 8 * d->n_rowtiles <= 256;
+    }
+    if (!ok) {
+        if (int rc = vsv_lstm_backward(d0, hidden, layers, stream)) return rc;
+        return vsv_lstm_backward(d1, hidden, layers, stream);
+    }
+    const long n0 = 8 * d0->n_rowtiles, n1 = 8 * d1->n_rowtiles;
+    const size_t lds = (size_t)(4 * 4 * 144 + 8 * 4 * 64) * sizeof(float);
+    hipLaunchKernelGGL((lstm_bwd4_pair_kernel<13>), dim3((unsigned)(n0 > n1 ? n0 : n1), 2), dim3(512), lds, (hipStream_t)stream, *d0, *d1);
+    return launch_check("lstm_bwd4_pair_kernel");
+}
+
+extern "C" int vsv_tileb_gemm_launch_pair(const vsv_tileb_gemm* d0, const vsv_tileb_gemm* d1, void* stream) {
+    bool ok = d0 && d1 && !pair_off();
+    for (const vsv_tileb_gemm* d : {d0, d1}) {
+        if (!ok) break;
+        ok = d->wT && d->g && (d->out_tile || d->out_rows) && d->nqT >= 1 && d->nqT <= 64 && d->ntT >= 1 && d->ntT <= 4 && d->T >= 1 &&
+             d->n_rows >= 1 && d->n_rowtiles == (d->n_rows + 31) / 32 && d->g_stride >= (long)d->nqT * 4 * 64 &&
+             !(d->out_rows && d->out_f < 1) && d->drop_p >= 0.0f && d->drop_p < 1.0f && d->n_rowtiles * d->T * d->ntT <= 1024;
+    }
+    if (!ok) {
+        if (int rc = vsv_tileb_gemm_launch(d0, stream)) return rc;
+        return vsv_tileb_gemm_launch(d1, stream);
+    }
+    const int nq = d0->nqT > d1->nqT ? d0->nqT : d1->nqT;
+    size_t lds = (size_t)nq * 4 * 64 * sizeof(float);
+    if (lds < (size_t)3 * 16 * 64 * sizeof(float)) lds = (size_t)3 * 16 * 64 * sizeof(float);
+    if (int rc = set_lds(tileb_gemm_pair_kernel, lds)) return rc;
+    const long n0 = d0->n_rowtiles * d0->T * d0->ntT, n1 = d1->n_rowtiles * d1->T * d1->ntT;
+    hipLaunchKernelGGL(tileb_gemm_pair_kernel, dim3((unsigned)(n0 > n1 ? n0 : n1), 2), dim3(256), lds, (hipStream_t)stream, *d0, *d1);
+    return launch_check("tileb_gemm_pair_kernel");
 }
 
 // Backward of the reparameterisation z = mu + exp(0.5 logvar) * eps (:199) and of the decoder-input cat (:1066):

@@ -208,6 +208,9 @@ SIGNATURES = {
                                    C.POINTER(VsvTrainSave), C.c_void_p]),
     "vsv_dense_backward": (C.c_int, [C.POINTER(VsvDenseBwd), C.c_void_p]),
     "vsv_lstm_backward": (C.c_int, [C.POINTER(VsvLstmBwd), C.c_int, C.c_int, C.c_void_p]),
+    "vsv_dense_backward_pair": (C.c_int, [C.POINTER(VsvDenseBwd), C.POINTER(VsvDenseBwd), C.c_void_p]),
+    "vsv_lstm_backward_pair": (C.c_int, [C.POINTER(VsvLstmBwd), C.POINTER(VsvLstmBwd), C.c_int, C.c_int, C.c_void_p]),
+    "vsv_tileb_gemm_launch_pair": (C.c_int, [C.POINTER(VsvTilebGemm), C.POINTER(VsvTilebGemm), C.c_void_p]),
     "vsv_loss_grad": (C.c_int, [C.POINTER(VsvLoss), C.c_void_p]),
     "vsv_tileb_gemm_launch": (C.c_int, [C.POINTER(VsvTilebGemm), C.c_void_p]),
     "vsv_weight_grads": (C.c_int, [C.POINTER(VsvWgrad), C.c_void_p]),

@@ -317,7 +317,7 @@ class TrainEngine:
                 c.blobT = ext[self._bwd_idx]
         return c.blobT
 
-    def _dense_bwd(self, c, layers, n_inst_T, in_mode, in_t, in_f, want_dx):
+    def _dense_bwd_args(self, c, layers, n_inst_T, in_mode, in_t, in_f, want_dx):
         a = _lib.VsvDenseBwd()
         a.n_layers = len(layers)
         for i, ly in enumerate(layers):
@@ -327,10 +327,15 @@ class TrainEngine:
         a.in_mode, a.in_, a.in_f = in_mode, in_t.data_ptr(), in_f
         dx = self._e(c.rt * n_inst_T, 64, 64) if want_dx else None
         a.dx_out = _ptr(dx)
+        return a, dx
+
+    def _dense_bwd(self, c, layers, n_inst_T, in_mode, in_t, in_f, want_dx):
+        a, dx = self._dense_bwd_args(c, layers, n_inst_T, in_mode, in_t, in_f, want_dx)
         _lib.check(self.lib.vsv_dense_backward(C.byref(a), self._stream()), "vsv_dense_backward")
         return dx
 
-    def _lstm_bwd(self, c, prefix, hidden, NT, sv, Tw, t_out0, dh_top, nt_x, drop_id, dx_tile=None, dx_rows=None, dx_f=0):
+    def _lstm_bwd(self, c, prefix, hidden, NT, sv, Tw, t_out0, dh_top, nt_x, drop_id, dx_tile=None, dx_rows=None, dx_f=0,
+                  stages=None):
         """BPTT of one memory stack -> dgates (NI, NL, 16*NT, 64).  Two layers run as four launches: the
         recurrence of layer 1, d h_0 = W_ih(1)^T . dgates(1) for every step at once, the recurrence of
         layer 0, dx = W_ih(0)^T . dgates(0) for every step at once -- only the W_hh^T products stay on the
@@ -340,7 +345,7 @@ class TrainEngine:
         dg = self._e(c.rt * Tw, NL, 16 * NT, 64)
         st = self._stream()
 
-        def rec(l0, layers, dh, t0, ntx):
+        def rec_args(l0, layers, dh, t0, ntx):
             a = _lib.VsvLstmBwd()
             a.drop_p, a.drop_seed, a.drop_id = c.drop_p, c.drop_seed, drop_id
             a.drop_seed_dev = _ptr(c.drop_seed_dev)
@@ -355,10 +360,14 @@ class TrainEngine:
                 a.dx_tile, a.dx_rows, a.dx_f = _ptr(dx_tile), _ptr(dx_rows), dx_f
             if layers != NL:
                 a.sv_nl, a.sv_l0 = NL, l0
-            # (8 * NT: the hidden width as built -- widths between the built tile counts run zero-padded)
-            _lib.check(self.lib.vsv_lstm_backward(C.byref(a), 8 * NT, layers, st), "vsv_lstm_backward")
+            return a
 
-        def off_loop(name, l, out_tile, out_rows, out_f, drop_layer):
+        def rec(l0, layers, dh, t0, ntx):
+            # (8 * NT: the hidden width as built -- widths between the built tile counts run zero-padded)
+            _lib.check(self.lib.vsv_lstm_backward(C.byref(rec_args(l0, layers, dh, t0, ntx)), 8 * NT, layers, st),
+                       "vsv_lstm_backward")
+
+        def off_args(name, l, out_tile, out_rows, out_f, drop_layer):
             w, nq, nt = self._wT(blobT, name)
             g = _lib.VsvTilebGemm()
             g.wT, g.nqT, g.ntT = w, nq, nt
@@ -368,8 +377,20 @@ class TrainEngine:
             if drop_layer is not None and c.drop_p > 0:
                 g.drop_p, g.drop_seed, g.drop_seed_dev = c.drop_p, c.drop_seed, _ptr(c.drop_seed_dev)
                 g.drop_id, g.drop_layer = drop_id, drop_layer
-            _lib.check(self.lib.vsv_tileb_gemm_launch(C.byref(g), st), "vsv_tileb_gemm_launch")
+            return g
 
+        def off_loop(name, l, out_tile, out_rows, out_f, drop_layer):
+            _lib.check(self.lib.vsv_tileb_gemm_launch(C.byref(off_args(name, l, out_tile, out_rows, out_f, drop_layer)), st),
+                       "vsv_tileb_gemm_launch")
+
+        if stages is not None:
+            # the pair path: hand the four stages' argument builders to the caller, who launches each stage for two
+            # stacks at once (_enc_bwd_pair)
+            dh0 = self._e(c.rt * Tw, 64, 64)
+            stages.extend([("rec", rec_args(1, 1, dh_top, t_out0, 0)), ("off", off_args(f"{prefix}.in1", 1, dh0, None, 0, 0)),
+                           ("rec", rec_args(0, 1, dh0, 0, 0)),
+                           ("off", off_args(f"{prefix}.in0", 0, dx_tile, dx_rows, dx_f, None) if nt_x > 0 else None)])
+            return dg
         if NL == 1 or os.environ.get("VSV_BWD_FUSED", "0") == "1":
             rec(0, NL, dh_top, t_out0, nt_x)
             return dg
@@ -433,6 +454,63 @@ class TrainEngine:
         f = torch.arange(25, device=self.dev)
         t = dxs.view(rt, Tw, 64, 2, 32)[:, :, 4 * (f >> 3) + (f & 3), (f >> 2) & 1]      # (rt, Tw, 25, 32)
         return t.permute(0, 3, 1, 2).reshape(rt * 32, Tw, 25)[: c.B]
+
+    def _enc_bwd_pair(self, c, gp, specs):
+        """_enc_bwd of BOTH encoder stacks, stage by stage: specs = [(which, sv, Tw, d_out), (which, sv, Tw, d_out)];
+        every stage's launch carries both stacks (vsv_*_pair).  Same kernels, arguments and queued weight-gradient
+        problems as two _enc_bwd calls."""
+        lay, NTm, lib, st = self.lay, self.lay["NTm"], self.lib, self._stream()
+        blobT = self._blobT(c)
+        rt = c.rt
+        heads, stages, convs, keep = [], [], [], []
+        for which, sv, Tw, d_out in specs:
+            e = lay["enc"][which]
+            pf = f"e{which}"
+            gh = self._e(rt * Tw, 64, 64)
+            w, nq, nt = self._wT(blobT, f"{pf}.head")
+            a, dh = self._dense_bwd_args(c, [dict(wT=w, nqT=nq, ntT=nt, n_relu=0, g_out=gh.data_ptr())], Tw, 0, d_out,
+                                         d_out.shape[-1], True)
+            heads.append(a)
+            self._acc_layer(c, e["head"], gh[:, : 16 * e["head"].nt], sv["hout"])
+            kx = e["kx"]
+            dxt = self._e(rt * Tw, 64, 64) if kx == 64 else self._z(rt * Tw, 64, 64)
+            stg = []
+            dgl = self._lstm_bwd(c, pf, self.Hm, NTm, sv, Tw, 0, dh, kx // 16, sv["drop_id"], dx_tile=dxt, stages=stg)
+            stages.append(stg)
+            self._lstm_wgrads(c, gp, e["lstm"], sv, dgl, Tw, NTm, sv["xe"])
+            nc = self.n_conv[which]
+            xe_act = sv["xe"]
+            if kx < 64:
+                xe_act = self._z(rt * Tw, 64, 64)
+                xe_act[:, :kx] = sv["xe"]
+            layers, gs = [], []
+            for li in range(nc - 1, -1, -1):
+                g = self._e(rt * Tw, 64, 64)
+                gs.append((li, g))
+                ly = dict(ntT=0, nqT=0, n_relu=e["conv"][li].n_relu, g_out=g.data_ptr(),
+                          act_out=(xe_act if li == nc - 1 else sv["emb_acts"][li + 1]).data_ptr())
+                if li > 0:
+                    ly["wT"], ly["nqT"], ly["ntT"] = self._wT(blobT, f"{pf}.conv{li}")
+                layers.append(ly)
+            ca, _ = self._dense_bwd_args(c, layers, Tw, 1, dxt, 0, False)
+            convs.append(ca)
+            for li, g in gs:
+                cs = e["conv"][li]
+                self._acc_layer(c, cs, g[:, : 16 * cs.nt], sv["emb_acts"][li][:, : 4 * cs.nq])
+            keep.append((gh, dh, dxt, dgl, xe_act, gs))
+        _lib.check(lib.vsv_dense_backward_pair(C.byref(heads[0]), C.byref(heads[1]), st), "vsv_dense_backward_pair")
+        for (k0, a0), (k1, a1) in zip(stages[0], stages[1]):
+            assert k0 == k1
+            if a0 is None or a1 is None:
+                for a in (a0, a1):
+                    if a is not None:
+                        _lib.check(lib.vsv_tileb_gemm_launch(C.byref(a), st), "vsv_tileb_gemm_launch")
+            elif k0 == "rec":
+                _lib.check(lib.vsv_lstm_backward_pair(C.byref(a0), C.byref(a1), 8 * NTm, 1, st), "vsv_lstm_backward_pair")
+            else:
+                _lib.check(lib.vsv_tileb_gemm_launch_pair(C.byref(a0), C.byref(a1), st), "vsv_tileb_gemm_launch_pair")
+        _lib.check(lib.vsv_dense_backward_pair(C.byref(convs[0]), C.byref(convs[1]), st), "vsv_dense_backward_pair")
+        c.bwd_keep = keep                                         # (buffers the launches above read or write)
 
     def encoder_pass(self, surf, ex, Tw, d_out_fn, which: int = 0, dropout_p: float = 0.0, dropout_seed: int = 0,
                      drop_id: int = 3, want_grads: bool = True):
@@ -587,11 +665,17 @@ class TrainEngine:
             _lib.check(self.lib.vsv_reparam_backward(dx.data_ptr(), z.data_ptr(), zm.data_ptr(), _ptr(d_zm), _ptr(d_zl),
                                                      _ptr(d_z), _ptr(mask), B, T, Cn, L, Lc, d_enc.data_ptr(),
                                                      d_ctx.data_ptr(), self._stream()), "vsv_reparam_backward")
-            side.wait_stream(main)
-            with torch.cuda.stream(side):
-                ds_c = self._enc_bwd(c, gp, 1, c.sv_c, Cn, d_ctx, want_input_grad)
-            ds_e = self._enc_bwd(c, gp, 0, c.sv_e, T, d_enc, want_input_grad)
-            main.wait_stream(side)
+            if (not want_input_grad and 8 * rt <= 128 and self.NL == 2 and self.dims.mem_type == 0
+                    and os.environ.get("VSV_ENC_PAIR", "1") != "0" and os.environ.get("VSV_BWD_FUSED", "0") != "1"):
+                # few row tiles: the two stacks' launches pairwise as one launch each, no second stream
+                self._enc_bwd_pair(c, gp, [(0, c.sv_e, T, d_enc), (1, c.sv_c, Cn, d_ctx)])
+                ds_e = ds_c = None
+            else:
+                side.wait_stream(main)
+                with torch.cuda.stream(side):
+                    ds_c = self._enc_bwd(c, gp, 1, c.sv_c, Cn, d_ctx, want_input_grad)
+                ds_e = self._enc_bwd(c, gp, 0, c.sv_e, T, d_enc, want_input_grad)
+                main.wait_stream(side)
             self._wg_flush(c, gp)
             if wg_stream is not None:
                 main.wait_stream(wg_stream)

@@ -381,7 +381,9 @@ int vsv_train_encode(const vsv_dims *dims, const float *packed, int which,
  * encoder (which = 1) over T1 steps into out1 / sv1, same batch: CVAEMemRand.forward's two independent encoder calls
  * (cvae_with_mem_randomized.py:1046-1058).  Few row tiles (<= 16 of 32 rows): every launch of a stack goes out
  * together with its twin of the other stack as ONE launch (half the launches, both stacks side by side without a second
- * stream); otherwise the two stacks run one after the other on `stream`.  Results equal two vsv_train_encode calls. */
+ * stream); otherwise the two stacks run one after the other on `stream`.  Results equal two vsv_train_encode calls,
+ * except for the layout of out0: TWO planes (2, n_rows, T0, L) -- z_mean, then z_log_var -- instead of (n_rows, T0, 2L),
+ * the form vsv_train_decode's zb / lv arguments take. */
 int vsv_train_encode_pair(const vsv_dims *dims, const float *packed,
                           const float *surf, long surf_row_stride, long surf_t_stride,
                           const float *ex, long ex_row_stride, long ex_t_stride,

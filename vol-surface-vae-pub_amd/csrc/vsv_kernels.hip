@@ -65,11 +65,21 @@ __device__ unsigned long long g_stamps[(size_t)kStampWgs * 4 * 32];
             g_stamps[((size_t)blockIdx.x * 4 + wave) * 32 + 4 * (t - (a.T >> 1)) + (i)] = __builtin_amdgcn_s_memtime(); \
         __builtin_amdgcn_sched_barrier(0);                                                                    \
     } while (0)
+// (lstm_bwd4_kernel<16>, tools/stamps_bwd.py: one step from the middle of the sequence -- 0 top, 1 products issued,
+// 2 partial tiles published, 3 past the first barrier, 4 cell backward and stores issued, 5 past the second barrier)
+#define BWD_STAMP(i)                                                                                          \
+    do {                                                                                                      \
+        __builtin_amdgcn_sched_barrier(0);                                                                    \
+        if (NT == 16 && t == (a.T >> 1) && lane == 0 && wave < 4 && blockIdx.x < kStampWgs)                    \
+            g_stamps[((size_t)blockIdx.x * 4 + wave) * 32 + (i)] = __builtin_amdgcn_s_memtime();               \
+        __builtin_amdgcn_sched_barrier(0);                                                                    \
+    } while (0)
 #else
 #define VSV_STAMP(i) do {} while (0)
 #define MC1_STAMP(i) do {} while (0)
 #define DSQ_STAMP(i) do {} while (0)
 #define REC_STAMP(i) do {} while (0)
+#define BWD_STAMP(i) do {} while (0)
 #endif
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -3905,6 +3915,10 @@ __device__ __forceinline__ void lstm_bwd4_body(const LstmBwdArgs& a) {
     const int m = 4 * (int)(tile4 & 7) + j;
     const int SL = a.sv_nl > 0 ? a.sv_nl : 1, L0 = a.sv_nl > 0 ? a.sv_l0 : 0;
     const int t_outs = a.T - a.t_out0;
+#ifdef VSV_STAMPS
+    if (NT == 16 && lane == 0 && wave < 4 && blockIdx.x < kStampWgs)
+        g_stamps[((size_t)blockIdx.x * 4 + wave) * 32 + 6] = __builtin_amdgcn_s_memtime();
+#endif
     float* const dgl = smem;                                       // [gate 4][row 4][HPAD]
     float* const part = smem + 4 * 4 * HPAD;                       // [wave 8][register 4][lane 64]
 
@@ -3937,19 +3951,34 @@ __device__ __forceinline__ void lstm_bwd4_body(const LstmBwdArgs& a) {
     float dc = 0.0f;
     const float* const hr = dgl + (size_t)(s * 4 + j) * HPAD;      // this wave's K slice (gate s), this lane's row
 
+    // saved gates and cell states of a step, and the top gradient: fetched ONE STEP AHEAD (a step is ~3 us of dependent
+    // work; requested at its own top, the L2 round trip of these seven loads was most of a microsecond of it)
+    float gsv_n[4], cn_n, cp_n, dht_n;
+    auto fetch = [&](int t) {
+        const size_t inst = (size_t)(rowtile * a.T + t);
+        const float* sg = a.sv_gates + ((inst * SL + L0) * GK + gsl) * 64 + l32;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) gsv_n[g] = sg[(size_t)g * 64];
+        cn_n = a.sv_c[((inst * SL + L0) * (4 * NT) + hsl) * 64 + l32];
+        cp_n = (t > 0) ? a.sv_c[(((inst - 1) * SL + L0) * (4 * NT) + hsl) * 64 + l32] : 0.0f;
+        dht_n = 0.0f;
+        if (t >= a.t_out0 && a.dh_top)
+            dht_n = a.dh_top[((size_t)(rowtile * t_outs + (t - a.t_out0)) * 64 + dsl) * 64 + l32];
+    };
+    fetch(a.T - 1);
+#ifdef VSV_STAMPS
+    __builtin_amdgcn_sched_barrier(0);
+    if (NT == 16 && lane == 0 && wave < 4 && blockIdx.x < kStampWgs)
+        g_stamps[((size_t)blockIdx.x * 4 + wave) * 32 + 7] = __builtin_amdgcn_s_memtime() + (unsigned long long)(wreg[0] == 12345.0f);
+    __builtin_amdgcn_sched_barrier(0);
+#endif
     for (int t = a.T - 1; t >= 0; --t) {
         const size_t inst = (size_t)(rowtile * a.T + t);
-        // saved gates and cell states of the step: requested before the products, which do not depend on them
-        float gsv[4], cn, cp, dht = 0.0f;
-        {
-            const float* sg = a.sv_gates + ((inst * SL + L0) * GK + gsl) * 64 + l32;
+        float gsv[4], cn = cn_n, cp = cp_n, dht = dht_n;
 #pragma unroll
-            for (int g = 0; g < 4; ++g) gsv[g] = sg[(size_t)g * 64];
-            cn = a.sv_c[((inst * SL + L0) * (4 * NT) + hsl) * 64 + l32];
-            cp = (t > 0) ? a.sv_c[(((inst - 1) * SL + L0) * (4 * NT) + hsl) * 64 + l32] : 0.0f;
-            if (t >= a.t_out0 && a.dh_top)
-                dht = a.dh_top[((size_t)(rowtile * t_outs + (t - a.t_out0)) * 64 + dsl) * 64 + l32];
-        }
+        for (int g = 0; g < 4; ++g) gsv[g] = gsv_n[g];
+        BWD_STAMP(0);
+        if (t > 0) fetch(t - 1);
         f32x4 acc = {0.0f, 0.0f, 0.0f, 0.0f};
         if (t + 1 < a.T) {
             f32x4 a1 = acc, a2 = acc, a3 = acc;
@@ -3964,11 +3993,14 @@ __device__ __forceinline__ void lstm_bwd4_body(const LstmBwdArgs& a) {
 #pragma unroll
             for (int v = 0; v < 4; ++v) acc[v] += (a1[v] + a2[v]) + a3[v];
         }
+        BWD_STAMP(1);
         {
             float* o = part + (size_t)(wave * 4) * 64 + lane;
             o[0] = acc[0]; o[64] = acc[1]; o[128] = acc[2]; o[192] = acc[3];
         }
+        BWD_STAMP(2);
         __syncthreads();                                           // partial tiles published; dgates(t+1) read by all
+        BWD_STAMP(3);
         float dh = dht;
         {
             const float* pp = part + (size_t)(4 * Go * 4 + s) * 64 + lane;      // register s of the group's four waves
@@ -3991,8 +4023,14 @@ __device__ __forceinline__ void lstm_bwd4_body(const LstmBwdArgs& a) {
                 o[0] = di; o[64] = df; o[128] = dgg; o[192] = dog;
             }
         }
+        BWD_STAMP(4);
         __syncthreads();                                           // dgates(t) published
+        BWD_STAMP(5);
     }
+#ifdef VSV_STAMPS
+    if (NT == 16 && lane == 0 && wave < 4 && blockIdx.x < kStampWgs)
+        g_stamps[((size_t)blockIdx.x * 4 + wave) * 32 + 8] = __builtin_amdgcn_s_memtime();
+#endif
 }
 template <int NT>
 __global__ void __launch_bounds__(512) lstm_bwd4_kernel(const LstmBwdArgs a) { lstm_bwd4_body<NT>(a); }
@@ -5872,7 +5910,8 @@ struct TrainEncPlan {
 static int plan_train_encode(const Layout& lay, const float* packed, int which,
                              const float* surf, long surf_row_stride, long surf_t_stride,
                              const float* ex, long ex_row_stride, long ex_t_stride,
-                             long n_rows, int T, float* out, const vsv_train_save* sv, TrainEncPlan& p) {
+                             long n_rows, int T, float* out, const vsv_train_save* sv, TrainEncPlan& p,
+                             bool split_planes = false) {
     if (!packed || !surf || !out || !sv) { set_error("vsv_train_encode: null pointer"); return -1; }
     if (!sv->emb_acts || !sv->xe || !sv->gates || !sv->c || !sv->h || !sv->hout) { set_error("vsv_train_encode: incomplete save set"); return -1; }
     if (which < 0 || which > 1) { set_error("vsv_train_encode: which must be 0 or 1"); return -1; }
@@ -5913,6 +5952,12 @@ static int plan_train_encode(const Layout& lay, const float* packed, int which,
     h.in_mode = 1; h.in = sv->hout; h.in_ks = 4 * lay.NTm;
     h.out_mode = 1; h.out = out; h.out_f = e.nh; h.S = 1;
     h.aux_layer = -1;
+    if (split_planes && which == 0) {
+        // posterior encoder: z_mean and z_log_var as two planes (n_rows, T, L) instead of one (n_rows, T, 2L) --
+        // the decoder reads them as separate tensors, and a strided slice of the pair would have to be copied out
+        h.out_f = lay.L;
+        h.aux = out + (size_t)n_rows * T * lay.L; h.aux_f0 = lay.L; h.aux_n = lay.L; h.aux_layer = 0;
+    }
     return 0;
 }
 // layer L of a per-layer forward: the input product's arguments and the recurrent launch's
@@ -5980,7 +6025,7 @@ extern "C" int vsv_train_encode_pair(const vsv_dims* dims, const float* packed,
     const vsv_train_save* svs[2] = {sv0, sv1};
     for (int k = 0; k < 2; ++k)
         if (int rc = plan_train_encode(lay, packed, k, surf, surf_row_stride, surf_t_stride, ex, ex_row_stride, ex_t_stride,
-                                       n_rows, Ts[k], outs[k], svs[k], p[k])) return rc;
+                                       n_rows, Ts[k], outs[k], svs[k], p[k], true)) return rc;
     static const bool off = [] { const char* e = getenv("VSV_ENC_PAIR"); return e && e[0] == '0'; }();
     const long rt = p[0].rt;
     bool pair = !off && lay.NL == 2 && !lay.gru && lay.NTm == 13 && per_layer_forward(lay.NL, rt) && 8 * rt <= 128;

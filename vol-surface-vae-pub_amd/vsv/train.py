@@ -274,6 +274,7 @@ class TrainEngine:
         """vsv_train_encode_pair: posterior encoder over T0 days and context encoder over T1, on the current stream.
         -> (enc_out, sv_e, ctx_out, sv_c)."""
         out0, sv0, s0 = self._enc_save(c, 0, T0)
+        out0 = out0.view(2, c.B, T0, self.L)                      # (the pair entry point writes z_mean / z_log_var planes)
         out1, sv1, s1 = self._enc_save(c, 1, T1)
         X = self.X
         rc = self.lib.vsv_train_encode_pair(C.byref(self.dims), c.packed.data_ptr(),
@@ -563,14 +564,15 @@ class TrainEngine:
             # the side stream
             if 8 * rt <= 128 and self.NL == 2 and self.dims.mem_type == 0 and os.environ.get("VSV_ENC_PAIR", "1") != "0":
                 enc_out, c.sv_e, ctx_out, c.sv_c = self._enc_fwd_pair(c, T, Cc)
+                zm, zl = enc_out[0], enc_out[1]
             else:
                 side.wait_stream(main)
                 ctx_out, c.sv_c = self._enc_fwd(c, 1, Cc, side)
                 enc_out, c.sv_e = self._enc_fwd(c, 0, T, main)
                 main.wait_stream(side)
+                zm, zl = enc_out[..., :L].contiguous(), enc_out[..., L:].contiguous()
             if ctx_mask is not None:
                 ctx_out = ctx_out * ctx_mask
-            zm, zl = enc_out[..., :L].contiguous(), enc_out[..., L:].contiguous()
             # ---- decoder
             NI, NIo = rt * T, rt * horizon
             d = lay["dec"]
@@ -650,7 +652,7 @@ class TrainEngine:
             # (a fork and join cost ~20 us of cross-stream ordering: only where the launch is longer than that --
             # c2's 400 instances: 2.35 -> 2.29 ms per step; c1's 22: 0.60 -> 0.63, so not there)
             wg_stream = None
-            if rt * T >= 128:
+            if rt * T >= 128 and os.environ.get("VSV_WG_FORK", "1") != "0":
                 wg_stream = getattr(self.eng, "_third", None)
                 if wg_stream is None:
                     wg_stream = self.eng._third = torch.cuda.Stream(dev)

@@ -636,10 +636,15 @@ class Engine:
         _lib.check(rc, "vsv_percentile")
         return out
 
-    def reduce_async(self, samples: torch.Tensor, qs, inner: int, channel: Optional[int], n_channels: int):
+    def reduce_async(self, samples: torch.Tensor, qs, inner: int, channel: Optional[int], n_channels: int,
+                     overlap: bool = True):
         """percentile() on the side stream, ordered after the work queued so far on the current stream:
         the reduction of one chunk of MC samples (LDS / VALU work) overlaps the MFMA-bound decode of the
-        next.  Call join_side() before reading the results on the current stream."""
+        next.  Call join_side() before reading the results on the current stream.
+        overlap=False (the caller has no next chunk): on the current stream -- a fork and join across hardware
+        queues costs ~20 us and there is nothing to run beside."""
+        if not overlap:
+            return self.percentile(samples, qs, inner, channel, n_channels)
         main = torch.cuda.current_stream(self.device)
         if self._side is None:
             self._side = torch.cuda.Stream(self.device)

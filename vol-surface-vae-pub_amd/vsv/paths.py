@@ -254,10 +254,11 @@ def prior_mc_windows(eng: Engine, vol: torch.Tensor, ex: Optional[torch.Tensor],
                        out_mode=1 if channel is None else eng.OUT_CHANNEL(channel))
         smp = r["surf"]                                    # (nd, H, Q*25 | 25, S)
         # reduced on the side stream while the next chunk decodes
+        more = d0 + nd < n_days                               # (a next chunk to decode beside this reduction)
         if channel is None:
-            q = eng.reduce_async(smp, qs, Q * 25, None, 1).view(nd, horizon, len(qs), Q, 5, 5)
+            q = eng.reduce_async(smp, qs, Q * 25, None, 1, overlap=more).view(nd, horizon, len(qs), Q, 5, 5)
         else:
-            q = eng.reduce_async(smp, qs, 25, None, 1).view(nd, horizon, len(qs), 5, 5)
+            q = eng.reduce_async(smp, qs, 25, None, 1, overlap=more).view(nd, horizon, len(qs), 5, 5)
         outs.append(q)
     eng.join_side()
     return torch.cat(outs, dim=0)
@@ -628,10 +629,11 @@ def oracle_mc_windows(eng: Engine, vol: torch.Tensor, ex: Optional[torch.Tensor]
                        seed=seed, S=n_samples, day0=day_index0 + d0,
                        out_mode=1 if channel is None else eng.OUT_CHANNEL(channel))
         smp = r["surf"]                                                       # (nd, H, Q*25 | 25, S)
+        more = d0 + nd < n_days                               # (a next chunk to decode beside this reduction)
         if channel is None:
-            q = eng.reduce_async(smp, qs, Q * 25, None, 1).view(nd, horizon, len(qs), Q, 5, 5)
+            q = eng.reduce_async(smp, qs, Q * 25, None, 1, overlap=more).view(nd, horizon, len(qs), Q, 5, 5)
         else:
-            q = eng.reduce_async(smp, qs, 25, None, 1).view(nd, horizon, len(qs), 5, 5)
+            q = eng.reduce_async(smp, qs, 25, None, 1, overlap=more).view(nd, horizon, len(qs), 5, 5)
         outs.append(q)
     eng.join_side()
     return torch.cat(outs, dim=0)

@@ -45,7 +45,7 @@
 extern "C" {
 #endif
 
-#define VSV_ABI_VERSION 21
+#define VSV_ABI_VERSION 22
 #define VSV_MAX_CONV 4
 #define VSV_MAX_CHAIN 8
 #define VSV_MAX_INTERACT 3
@@ -477,7 +477,7 @@ int vsv_tileb_gemm_launch_pair(const vsv_tileb_gemm *d0, const vsv_tileb_gemm *d
  * followed by x[1] (n_b[1] columns, may be 0); shift[j] = 1 reads x[j] of the previous time step of the
  * same row tile (instances are [tile][t], t < T; zeros at t = 0) -- the recurrent input h_{t-1}.
  * Positions follow the packed layout of a section at (w_off, b_off) with nt output tiles. */
-#define VSV_MAX_WGRAD 16
+#define VSV_MAX_WGRAD 24
 typedef struct vsv_wgrad_prob {
     const float *g;  long g_stride;  int n_a;     /* n_a = 32 * (output tiles used), stride in floats per instance */
     const float *x[2];  long x_stride[2];  int n_b[2];  int shift[2];

@@ -104,7 +104,7 @@ class VsvTilebGemm(C.Structure):
                 ("drop_id", C.c_int), ("drop_layer", C.c_int)]
 
 
-VSV_MAX_WGRAD = 16
+VSV_MAX_WGRAD = 24
 
 
 class VsvWgradProb(C.Structure):
@@ -243,7 +243,7 @@ def load() -> C.CDLL:
             fn = getattr(lib, name)
             fn.restype = res
             fn.argtypes = args
-        if lib.vsv_abi_version() != 21:
+        if lib.vsv_abi_version() != 22:
             raise RuntimeError("libvsv_hip.so ABI version mismatch")
         _lib = lib
     return _lib

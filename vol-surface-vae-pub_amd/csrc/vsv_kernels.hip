@@ -929,6 +929,22 @@ __device__ __forceinline__ void dense_chain_wg_body(const DenseChainArgs& a, con
             for (int k = 0; k < 16; ++k) col[(s_lo + k) * 64] = (s_lo + k < a.in_ks) ? v[k] : 0.0f;
         }
     }
+    // A layer's fragments (this wave's tile, all of its <= 16 K quads) and bias are requested one layer AHEAD, behind
+    // the products of the layer before: with a handful of instances per launch (the decoder head of a training batch of
+    // 64 is two) a layer is a chain of 64 dependent products (1.7 us) and used to begin with two exposed round trips
+    // (bias, first fragments) of about that length.
+    float4 wq[4 * kHeadTiles];
+    f32x16 bn[1];
+    auto prefetch = [&](const DenseLayerArg& ly) {
+        const int tw = wave < ly.nt ? wave : ly.nt - 1;          // (waves without a tile fetch the last one's: no branch)
+        const float4* w = (const float4*)ly.w + (unsigned)(tw * 64) + lane;
+#pragma unroll
+        for (int q = 0; q < 4 * kHeadTiles; ++q) wq[q] = w[(unsigned)((q < ly.nq ? q : ly.nq - 1) * ly.nt * 64)];
+        const int toff1[1] = {tw * 64};
+        load_bias<1>(bn, ly.b, toff1, hh);
+    };
+    DenseLayerArg ly = chain_layer_of_kernarg(0, koff);
+    prefetch(ly);
     __syncthreads();
 #pragma unroll 1
     for (int li = 0; li < a.n_layers; ++li) {
@@ -937,16 +953,23 @@ __device__ __forceinline__ void dense_chain_wg_body(const DenseChainArgs& a, con
 #pragma unroll
             for (int k = 0; k < 16; ++k) sv[(s_lo + k) * 64] = col[(s_lo + k) * 64];
         }
-        const DenseLayerArg ly = chain_layer_of_kernarg(li, koff);
         const bool last = (li == a.n_layers - 1);
         const bool mine = wave < ly.nt;
         f32x16 acc[1];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[0][r] = 0.0f;
+        for (int r = 0; r < 16; ++r) acc[0][r] = mine ? bn[0][r] : 0.0f;
         if (mine) {
-            const int toff1[1] = {wave * 64};
-            load_bias<1>(acc, ly.b, toff1, hh);
-            gemm_seg<1>(acc, (const float4*)ly.w, lane, toff1, ly.nt * 64, col, ly.nq);
+#pragma unroll
+            for (int q = 0; q < 4 * kHeadTiles; ++q) {
+                if (q < ly.nq) {
+                    const float4 cur[1] = {wq[q]};
+                    quad_mfma<1>(acc, cur, col, q);
+                }
+            }
+        }
+        const DenseLayerArg lyn = chain_layer_of_kernarg(last ? li : li + 1, koff);
+        if (!last) prefetch(lyn);
+        if (mine) {
 #pragma unroll
             for (int r = 0; r < 16; ++r)
                 acc[0][r] = (feat_of(wave, r, hh) < ly.n_relu) ? fmaxf(acc[0][r], 0.0f) : acc[0][r];
@@ -995,6 +1018,7 @@ __device__ __forceinline__ void dense_chain_wg_body(const DenseChainArgs& a, con
             for (int r = 0; r < 16; ++r) col[(s_lo + r) * 64] = acc[0][r];        // (tiles >= nt: zeros)
             __syncthreads();
         }
+        ly = lyn;
     }
 }
 __global__ void __launch_bounds__(256) dense_chain_wg_kernel(const DenseChainArgs a) { dense_chain_wg_body(a, 0u); }

@@ -388,6 +388,9 @@ class TrainEngine:
             # the pair path: hand the four stages' argument builders to the caller, who launches each stage for two
             # stacks at once (_enc_bwd_pair)
             dh0 = self._e(c.rt * Tw, 64, 64)
+            # (the launches come later, after BOTH stacks' arguments are built: the buffer must outlive this call, or
+            # the allocator hands its memory to the other stack's buffers)
+            c.__dict__.setdefault("bwd_hold", []).append(dh0)
             stages.extend([("rec", rec_args(1, 1, dh_top, t_out0, 0)), ("off", off_args(f"{prefix}.in1", 1, dh0, None, 0, 0)),
                            ("rec", rec_args(0, 1, dh0, 0, 0)),
                            ("off", off_args(f"{prefix}.in0", 0, dx_tile, dx_rows, dx_f, None) if nt_x > 0 else None)])

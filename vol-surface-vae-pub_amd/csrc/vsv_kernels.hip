@@ -57,12 +57,13 @@ __device__ unsigned long long g_stamps[(size_t)kStampWgs * 4 * 32];
         __builtin_amdgcn_sched_barrier(0);                                                                    \
     } while (0)
 // (lstm_rec4_kernel / lstm_rec16_kernel, tools/stamps_rec.py: two consecutive time steps from the middle of the
-// sequence -- 4s + 0 top of step, + 1 products issued, + 2 cell and stores issued, + 3 past the barrier)
+// sequence -- 8s + 0 top of step, + 1 products issued, + 2 cell and stores issued, + 3 past the barrier; lstm_rec16_kernel
+// also + 4 gate activations, + 5 c and h, + 6 h in LDS, inside the cell phase)
 #define REC_STAMP(i)                                                                                          \
     do {                                                                                                      \
         __builtin_amdgcn_sched_barrier(0);                                                                    \
         if ((t == (a.T >> 1) || t == (a.T >> 1) + 1) && lane == 0 && wave < 4 && blockIdx.x < kStampWgs)       \
-            g_stamps[((size_t)blockIdx.x * 4 + wave) * 32 + 4 * (t - (a.T >> 1)) + (i)] = __builtin_amdgcn_s_memtime(); \
+            g_stamps[((size_t)blockIdx.x * 4 + wave) * 32 + 8 * (t - (a.T >> 1)) + (i)] = __builtin_amdgcn_s_memtime(); \
         __builtin_amdgcn_sched_barrier(0);                                                                    \
     } while (0)
 // (lstm_bwd4_kernel<16>, tools/stamps_bwd.py: one step from the middle of the sequence -- 0 top, 1 products issued,
@@ -319,6 +320,12 @@ __device__ __forceinline__ float4 bload(wrsrc_t r, unsigned voff, unsigned soff)
     float4 f;
     f.x = g.x; f.y = g.y; f.z = g.z; f.w = g.w;
     return f;
+}
+__device__ __forceinline__ float bload1(wrsrc_t r, unsigned voff, unsigned soff) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, (int)voff, (int)soff, 0));
+}
+__device__ __forceinline__ void bstore1(wrsrc_t r, float v, unsigned voff, unsigned soff) {
+    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), r, (int)voff, (int)soff, 0);
 }
 // NC consecutive tiles (1 KiB of fragments each) of the quad at scalar byte offset soff
 template <int NC>
@@ -1905,6 +1912,7 @@ __global__ void __launch_bounds__(512) lstm_rec16_kernel(const LstmSeqArgs a) {
     constexpr int KS = 2 * NT;                                     // k-steps of 4 hidden units = gate tiles of 16 rows
     constexpr int TPW = (KS + 7) / 8;                              // gate tiles per wave
     constexpr int HP = 8 * NT, HPK = 4 * NT;
+    constexpr int HB = (KS + 1) * 64;                              // floats of one h buffer: KS rows + a spare one
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const long tile16 = (long)blockIdx.x;
     const int d = lane & 15, ul = lane >> 4;
@@ -1922,11 +1930,13 @@ __global__ void __launch_bounds__(512) lstm_rec16_kernel(const LstmSeqArgs a) {
     float* const hbase = smem + lane;
 
     // per owned tile: this lane's hidden unit and where its values live in the 32-row layouts
-    int gslot[TPW], l32[TPW], hpos[TPW], hslot[TPW];
+    int gslot[TPW], l32[TPW], hpos[TPW], hslot[TPW], hwo[TPW];
 #pragma unroll
     for (int i = 0; i < TPW; ++i) {
         const int q = (i < ntile) ? wave + 8 * i : KS - 1;
         const int u = 4 * q + ul;
+        // where this tile's h goes in an LDS buffer; tiles beyond the wave's own: the spare row behind both buffers
+        hwo[i] = ((i < ntile) ? wave + 8 * i : KS) * 64 + lane;
         gslot[i] = 16 * (u >> 3) + 4 * ((u & 7) >> 1);             // + gate: slot of the gate value
         l32[i] = (u & 1) * 32 + m;                                 // lane of the 32-row layouts
         hslot[i] = 4 * (u >> 3) + ((u & 7) >> 1);                  // slot of h in tile-B
@@ -1950,22 +1960,33 @@ __global__ void __launch_bounds__(512) lstm_rec16_kernel(const LstmSeqArgs a) {
             }
         }
     }
-    auto load_pre = [&](f32x4 (&pre)[TPW], int t) {
+    // Per-step traffic is buffer-addressed: descriptor base (this row tile's part of the array) + a lane offset that
+    // never changes + a scalar step offset, so that a load or store costs no vector instruction and no address pair.
+    const bool from_t = !SAVE && a.pre_t != nullptr;               // wave-uniform
+    const float* pbase = SAVE ? a.sv_gates + ((size_t)rowtile * a.T * SL + L0) * (16 * NT) * 64
+                       : from_t ? a.pre_t : a.pre_g + (size_t)rowtile * a.T * (16 * NT) * 64;
+    const wrsrc_t prs = make_wrsrc(pbase);
+    const unsigned pstep = SAVE ? (unsigned)SL * (16 * NT) * 256u : from_t ? (unsigned)a.pre_tstride * 4u : (16 * NT) * 256u;
+    const unsigned pgate = from_t ? 8u * (unsigned)a.pre_stride : 256u;
+    unsigned pvo[TPW], hvo[TPW];
 #pragma unroll
-        for (int i = 0; i < TPW; ++i) {
-            if (SAVE) {
-                // (training: lstm_pre_kernel left the pre-activations in the layer's slots of sv_gates)
-                const float* p = a.sv_gates + (((size_t)(rowtile * a.T + t) * SL + L0) * (16 * NT) + gslot[i]) * 64 + l32[i];
-                pre[i] = f32x4{p[0], p[64], p[128], p[192]};
-            } else if (a.pre_t) {
-                const float* p = a.pre_t + (size_t)(2 * gslot[i] + (l32[i] >> 5)) * a.pre_stride + row + (size_t)t * a.pre_tstride;
-                const size_t st = 2 * (size_t)a.pre_stride;
-                pre[i] = f32x4{p[0], p[st], p[2 * st], p[3 * st]};
-            } else {
-                const float* p = a.pre_g + ((size_t)(rowtile * a.T + t) * (16 * NT) + gslot[i]) * 64 + l32[i];
-                pre[i] = f32x4{p[0], p[64], p[128], p[192]};
-            }
-        }
+    for (int i = 0; i < TPW; ++i) {
+        pvo[i] = from_t ? 4u * ((unsigned)(2 * gslot[i] + (l32[i] >> 5)) * (unsigned)a.pre_stride + (unsigned)row)
+                        : 4u * (unsigned)(gslot[i] * 64 + l32[i]);
+        hvo[i] = 4u * (unsigned)(hslot[i] * 64 + l32[i]);
+    }
+    const int t_outs = a.T - a.t_out0;
+    const wrsrc_t hrs = make_wrsrc(a.hout ? a.hout + (size_t)rowtile * t_outs * HPK * 64 : a.hout);
+    // (training: the arrays the backward kernels read, this row tile's and this layer's part)
+    const wrsrc_t svc = make_wrsrc(SAVE ? a.sv_c + ((size_t)rowtile * a.T * SL + L0) * HPK * 64 : nullptr);
+    const wrsrc_t svh = make_wrsrc(SAVE ? a.sv_h + ((size_t)rowtile * a.T * SL + L0) * HPK * 64 : nullptr);
+    const wrsrc_t svd = make_wrsrc(dropping ? a.sv_hd + (size_t)rowtile * a.T * HPK * 64 : nullptr);
+    auto load_pre = [&](f32x4 (&pre)[TPW], int t) {
+        const unsigned so = (unsigned)t * pstep;
+#pragma unroll
+        for (int i = 0; i < TPW; ++i)
+            pre[i] = f32x4{bload1(prs, pvo[i], so), bload1(prs, pvo[i], so + pgate), bload1(prs, pvo[i], so + 2 * pgate),
+                           bload1(prs, pvo[i], so + 3 * pgate)};
     };
     f32x4 pre[TPW];
     load_pre(pre, 0);
@@ -1982,72 +2003,146 @@ __global__ void __launch_bounds__(512) lstm_rec16_kernel(const LstmSeqArgs a) {
             h[i] = ps[0];
             c[i] = ps[HP];
         }
-        if (i < ntile) hbase[(wave + 8 * i) * 64] = h[i];
+        smem[hwo[i]] = h[i];
     }
     __syncthreads();
-    const int t_outs = a.T - a.t_out0;
-    auto products = [&](f32x4 (&acc)[TPW], const float* hr) {
-        // (ntile is wave-uniform: two straight-line variants instead of a test per product)
-        if (ntile == TPW) {
+    // products of k-steps [J0, J1) into the sums of the wave's NTL tiles, k-major (one accumulator chain per tile,
+    // ascending k)
+    auto products = [&](f32x4 (&acc)[TPW], const float* hr, auto ntl, auto j0, auto j1) {
 #pragma unroll
-            for (int j = 0; j < KS; ++j) {
-                const float b = hr[j * 64];
+        for (int j = decltype(j0)::value; j < decltype(j1)::value; ++j) {
+            const float b = hr[j * 64];
 #pragma unroll
-                for (int i = 0; i < TPW; ++i) acc[i] = mfma16(wreg[i][j], b, acc[i]);
-            }
-        } else {
-#pragma unroll
-            for (int j = 0; j < KS; ++j) {
-                const float b = hr[j * 64];
-#pragma unroll
-                for (int i = 0; i < TPW - 1; ++i) acc[i] = mfma16(wreg[i][j], b, acc[i]);
-            }
+            for (int i = 0; i < decltype(ntl)::value; ++i) acc[i] = mfma16(wreg[i][j], b, acc[i]);
         }
     };
-    for (int t = 0; t < a.T; ++t) {
-        const float* hr = hbase + (t & 1) * (KS * 64);
-        float* hw = hbase + ((t + 1) & 1) * (KS * 64);
-        f32x4 acc[TPW];
-        REC_STAMP(0);
-#pragma unroll
-        for (int i = 0; i < TPW; ++i) acc[i] = pre[i];
-        if (t + 1 < a.T) load_pre(pre, t + 1);                     // lands while the products run
-        if (t > 0 || has_state) products(acc, hr);
-        REC_STAMP(1);
-#pragma unroll
-        for (int i = 0; i < TPW; ++i) {
-            const float ig = fast_sigmoid(acc[i][0]);
-            const float fg = fast_sigmoid(acc[i][1]);
-            const float gg = fast_tanh(acc[i][2]);
-            const float og = fast_sigmoid(acc[i][3]);
+    // The step in two halves, so that the cells and the barrier waits have products beside them.  A wave publishes
+    // the h of its tiles 0 .. IA-1 (k-steps < KA of the next step) before the step's FIRST barrier and runs the cells
+    // of its remaining tiles together with the next step's k-steps < KA, publishing them before the SECOND barrier:
+    //   step t:  [late cells of t-1 | k < KA of t]  barrier B(t-1)  [k >= KA of t, tile by tile | early cells of t]  barrier A(t)
+    // Every tile's sum still takes its k-steps in ascending order on one accumulator chain: bit for bit the sums of
+    // the other recurrent kernels.  The whole recurrence is compiled twice, for waves that own TPW tiles and for
+    // those that own TPW - 1 (wave-uniform), so that a step has no branch between its products and its cells.
+    constexpr int IA = 2, KA = 8 * IA;
+    static_assert(KA < KS && IA < TPW - 1, "lstm_rec16_kernel: the two-phase step needs more than IA + 1 tiles per wave");
+    using std::integral_constant;
+    auto run = [&](auto ntl_c) {
+        constexpr int NTL = decltype(ntl_c)::value;                // tiles this wave owns
+        // the LSTM cell of tile i on its gate sums of step ts (lane-local: the four gates of one unit of one day)
+        auto cell = [&](auto ic, const f32x4& sum, int ts) {
+            constexpr int i = decltype(ic)::value;
+            const float ig = fast_sigmoid(sum[0]);
+            const float fg = fast_sigmoid(sum[1]);
+            const float gg = fast_tanh(sum[2]);
+            const float og = fast_sigmoid(sum[3]);
             c[i] = __builtin_fmaf(fg, c[i], ig * gg);
             h[i] = og * fast_tanh(c[i]);
-            if (i < ntile) hw[(wave + 8 * i) * 64] = h[i];
-            if (SAVE && i < ntile) {
+            if (SAVE) {
                 // activated gates, cell and hidden state of the step, where the backward kernels read them
-                const size_t il = (size_t)(rowtile * a.T + t) * SL + L0;
-                float* sg = a.sv_gates + (il * (16 * NT) + gslot[i]) * 64 + l32[i];
-                sg[0] = ig; sg[64] = fg; sg[128] = gg; sg[192] = og;
-                a.sv_c[(il * HPK + hslot[i]) * 64 + l32[i]] = c[i];
-                a.sv_h[(il * HPK + hslot[i]) * 64 + l32[i]] = h[i];
+                // (sv_gates: the slots the pre-activations were read from)
+                const unsigned so = (unsigned)ts * pstep;
+                bstore1(prs, ig, pvo[i], so);
+                bstore1(prs, fg, pvo[i], so + 256u);
+                bstore1(prs, gg, pvo[i], so + 512u);
+                bstore1(prs, og, pvo[i], so + 768u);
+                const unsigned sc = (unsigned)ts * (unsigned)(SL * HPK * 256);
+                bstore1(svc, c[i], hvo[i], sc);
+                bstore1(svh, h[i], hvo[i], sc);
                 if (dropping) {
                     float fct[4];
                     const int u = 4 * (wave + 8 * i) + ul;
-                    dropout_factors(drop, (uint32_t)row, (uint32_t)t, u >> 3, u & 1, L0, fct);
-                    a.sv_hd[((size_t)(rowtile * a.T + t) * HPK + hslot[i]) * 64 + l32[i]] = h[i] * fct[(u & 7) >> 1];
+                    dropout_factors(drop, (uint32_t)row, (uint32_t)ts, u >> 3, u & 1, L0, fct);
+                    bstore1(svd, h[i] * fct[(u & 7) >> 1], hvo[i], (unsigned)ts * (unsigned)(HPK * 256));
                 }
             }
-        }
-        if (a.hout && t >= a.t_out0) {                             // (padding rows too: the next stage reads whole tiles)
-            float* ho = a.hout + (size_t)(rowtile * t_outs + (t - a.t_out0)) * HPK * 64;
+        };
+        // h of the wave's tiles [I0, I1) of step ts: into the LDS buffer the next step multiplies from and, where the
+        // launch wants the sequence, into HBM (padding rows too: the next stage reads whole tiles)
+        auto publish = [&](auto i0, auto i1, float* hb, int ts) {
 #pragma unroll
-            for (int i = 0; i < TPW; ++i)
-                if (i < ntile) ho[hslot[i] * 64 + l32[i]] = h[i];
-        }
-        REC_STAMP(2);
-        __syncthreads();                                           // h(t) published (the other buffer is free again)
-        REC_STAMP(3);
-    }
+            for (int i = decltype(i0)::value; i < decltype(i1)::value; ++i) hb[hwo[i]] = h[i];
+            if (a.hout && ts >= a.t_out0) {
+#pragma unroll
+                for (int i = decltype(i0)::value; i < decltype(i1)::value; ++i)
+                    bstore1(hrs, h[i], hvo[i], (unsigned)(ts - a.t_out0) * (unsigned)(HPK * 256));
+            }
+        };
+        f32x4 late[TPW - IA];
+        auto step = [&](int t, auto first_c) {
+            constexpr bool FIRST = decltype(first_c)::value;
+            float* hb_prev = smem + (t & 1) * HB;                  // h(t-1)
+            float* hb_next = smem + ((t + 1) & 1) * HB;            // h(t)
+            const float* hr = hb_prev + lane;
+            f32x4 acc[TPW];
+            REC_STAMP(0);
+#pragma unroll
+            for (int i = 0; i < TPW; ++i) acc[i] = pre[i];
+            load_pre(pre, t + 1 < a.T ? t + 1 : t);                // lands while the products run
+            if (!FIRST) {
+                cell(integral_constant<int, IA>{}, late[0], t - 1);
+                if constexpr (NTL - IA > 1) cell(integral_constant<int, IA + 1>{}, late[1], t - 1);
+            }
+            if (!FIRST || has_state) products(acc, hr, ntl_c, integral_constant<int, 0>{}, integral_constant<int, KA>{});
+            if (!FIRST) {
+                // (the late cells' instructions one by one between the products, from the first product on: the tail of
+                // their dependent chains and the h write have the remaining products beside them)
+#pragma unroll
+                for (int r = 0; r < 16 * (NTL - IA); ++r) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x002, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x400, 1, 0);
+                }
+                publish(integral_constant<int, IA>{}, ntl_c, hb_prev, t - 1);
+            }
+            REC_STAMP(1);
+            __syncthreads();                                       // B(t-1): all of h(t-1) published
+            REC_STAMP(4);
+            // (tile by tile: the early tiles finish first and their cells run beside the later tiles' products)
+            if (!FIRST || has_state) {
+#pragma unroll
+                for (int j = KA; j < KS; ++j) acc[0] = mfma16(wreg[0][j], hr[j * 64], acc[0]);
+            }
+            cell(integral_constant<int, 0>{}, acc[0], t);
+            if (!FIRST || has_state) {
+#pragma unroll
+                for (int j = KA; j < KS; ++j) acc[1] = mfma16(wreg[1][j], hr[j * 64], acc[1]);
+            }
+            cell(integral_constant<int, 1>{}, acc[1], t);
+            if (!FIRST || has_state) {
+#pragma unroll
+                for (int i = IA; i < NTL; ++i) {
+#pragma unroll
+                    for (int j = KA; j < KS; ++j) acc[i] = mfma16(wreg[i][j], hr[j * 64], acc[i]);
+                }
+            }
+#pragma unroll
+            for (int i = IA; i < NTL; ++i) late[i - IA] = acc[i];
+            if (!FIRST) {
+                // (tile 0's products, then the cells of tiles 0 and 1 one instruction per product of the tiles behind them)
+                __builtin_amdgcn_sched_group_barrier(0x008, KS - KA, 0);
+#pragma unroll
+                for (int r = 0; r < 2 * (KS - KA); ++r) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x002, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x400, 1, 0);
+                }
+            }
+            REC_STAMP(5);
+            publish(integral_constant<int, 0>{}, integral_constant<int, IA>{}, hb_next, t);
+            REC_STAMP(2);
+            __syncthreads();                                       // A(t): tiles < IA of h(t) published
+            REC_STAMP(3);
+        };
+        step(0, integral_constant<bool, true>{});
+        for (int t = 1; t < a.T; ++t) step(t, integral_constant<bool, false>{});
+        // the late tiles of the last step
+        cell(integral_constant<int, IA>{}, late[0], a.T - 1);
+        if constexpr (NTL - IA > 1) cell(integral_constant<int, IA + 1>{}, late[1], a.T - 1);
+        publish(integral_constant<int, IA>{}, ntl_c, smem + (a.T & 1) * HB, a.T - 1);
+        __syncthreads();
+    };
+    if (ntile == TPW) run(integral_constant<int, TPW>{});
+    else run(integral_constant<int, TPW - 1>{});
     if (a.state_out && row_ok) {
         float* st = a.state_out + ((size_t)row_raw * SNL + a.st_l0) * 2 * HP;
 #pragma unroll
@@ -2059,7 +2154,7 @@ __global__ void __launch_bounds__(512) lstm_rec16_kernel(const LstmSeqArgs a) {
     }
     if (a.din.gate_out) {
         // bias + W_hh . h_final: the part of the next step's gates shared by all rows continuing from this state
-        const float* hf = hbase + (a.T & 1) * (KS * 64);
+        const float* hf = hbase + (a.T & 1) * HB;
         f32x4 g[TPW];
 #pragma unroll
         for (int i = 0; i < TPW; ++i) {
@@ -2067,7 +2162,8 @@ __global__ void __launch_bounds__(512) lstm_rec16_kernel(const LstmSeqArgs a) {
             const int bi = (gslot[i] >> 4) * 32 + (l32[i] >> 5) * 16 + (gslot[i] & 15);
             g[i] = f32x4{a.b[0][bi], a.b[0][bi + 1], a.b[0][bi + 2], a.b[0][bi + 3]};
         }
-        products(g, hf);
+        if (ntile == TPW) products(g, hf, integral_constant<int, TPW>{}, integral_constant<int, 0>{}, integral_constant<int, KS>{});
+        else products(g, hf, integral_constant<int, TPW - 1>{}, integral_constant<int, 0>{}, integral_constant<int, KS>{});
         if (row_ok) {
             float* go = a.din.gate_out + ((size_t)row_raw * SNL + a.st_l0) * NT * 32;
 #pragma unroll
@@ -4694,7 +4790,13 @@ static bool lstm_rec16_applies(const LstmSeqArgs& a, int NL) {
 
 template <int NT>
 static int launch_lstm_rec16(const LstmSeqArgs& a, hipStream_t st) {
-    const size_t lds = (size_t)2 * 2 * NT * 64 * sizeof(float);
+    const size_t lds = (size_t)2 * (2 * NT + 1) * 64 * sizeof(float);
+    // (the kernel addresses a row tile's part of every array with 32-bit byte offsets)
+    const size_t sl = a.sv_gates && a.sv_nl > 0 ? (size_t)a.sv_nl : 1;
+    const bool fits = a.pre_t && !a.sv_gates
+        ? ((size_t)(32 * NT + 8) * (size_t)a.pre_stride + (size_t)a.n_rows + (size_t)a.T * (size_t)a.pre_tstride) * 4 < (1ull << 32)
+        : (size_t)a.T * sl * (16 * NT) * 256 < (1ull << 32);
+    if (!fits) { set_error("lstm_rec16_kernel: a row tile of pre-activations spans 4 GiB or more"); return -4; }
     // (two 16-row tiles per 32-row tile: the odd one of a ragged tail runs on clamped rows, so that the tile-B
     // outputs the next stage reads are written whole)
     if (a.sv_gates) hipLaunchKernelGGL((lstm_rec16_kernel<NT, true>), dim3((unsigned)(2 * a.n_rowtiles)), dim3(512), lds, st, a);

@@ -30,13 +30,18 @@ for N in [int(a) for a in sys.argv[1:]] or [500, 4000]:
         buf = (ctypes.c_ulonglong * n)()
         assert eng.lib.vsv_debug_stamps(buf, n) == 0
         st = np.frombuffer(buf, dtype=np.uint64).reshape(16384 * 4, 32).astype(np.int64)
-        st = st[(st[:, 0] > 0) & (st[:, 8] > st[:, 0])]
-        print(f"--- {N} days, {label}: {len(st)} waves stamped; 100 ticks = 1 us")
-        for s0 in (0, 8):
-            seq = [0, 1, 4, 5, 6, 2, 3] if st[:, s0 + 4].max() > 0 else [0, 1, 2, 3]
-            names = (["products", "gate activations", "c and h", "h to LDS", "stores", "barrier"] if len(seq) == 7
-                     else ["products", "cell + stores", "barrier"])
+        wv = np.arange(16384 * 4) % 8
+        ok = (st[:, 0] > 0) & (st[:, 8] > st[:, 0])
+        print(f"--- {N} days, {label}: {int(ok.sum())} waves stamped; cycles")
+        for grp, sel in (("waves 0-3", ok & (wv < 4)), ("waves 4-7", ok & (wv >= 4))):
+            g = st[sel]
+            if not len(g):
+                continue
+            seq = [0, 1, 4, 5, 2, 3] if g[:, 4].max() > 0 else [0, 1, 2, 3]
+            names = (["late cells | k < 16", "barrier B", "k >= 16 | early cells", "h to LDS, stores", "barrier A"]
+                     if len(seq) == 6 else ["products", "cell + stores", "barrier"])
+            print(f" {grp} (second stamped step):")
             for i, nm in enumerate(names):
-                d = st[:, s0 + seq[i + 1]] - st[:, s0 + seq[i]]
-                print(f"  {nm:18s} median {np.median(d):7.0f}  p10 {np.percentile(d, 10):7.0f}  p90 {np.percentile(d, 90):7.0f}")
-        print(f"  step period (top to top) median {np.median(st[:, 8] - st[:, 0]):7.0f}")
+                d = g[:, 8 + seq[i + 1]] - g[:, 8 + seq[i]]
+                print(f"  {nm:24s} median {np.median(d):7.0f}  p10 {np.percentile(d, 10):7.0f}  p90 {np.percentile(d, 90):7.0f}")
+            print(f"  step period (top to top) median {np.median(g[:, 8] - g[:, 0]):7.0f}")

@@ -57,13 +57,13 @@ __device__ unsigned long long g_stamps[(size_t)kStampWgs * 4 * 32];
         __builtin_amdgcn_sched_barrier(0);                                                                    \
     } while (0)
 // (lstm_rec4_kernel / lstm_rec16_kernel, tools/stamps_rec.py: two consecutive time steps from the middle of the
-// sequence -- 8s + 0 top of step, + 1 products issued, + 2 cell and stores issued, + 3 past the barrier; lstm_rec16_kernel
-// also + 4 gate activations, + 5 c and h, + 6 h in LDS, inside the cell phase)
+// sequence -- 8s + 0 top of step, + 1 products issued, + 2 cell and stores issued, + 3 past the barrier; lstm_rec16_kernel:
+// + 1 first half issued, + 4 past its barrier, + 5 second half issued, + 2 early tiles published, + 3 past the barrier)
 #define REC_STAMP(i)                                                                                          \
     do {                                                                                                      \
         __builtin_amdgcn_sched_barrier(0);                                                                    \
-        if ((t == (a.T >> 1) || t == (a.T >> 1) + 1) && lane == 0 && wave < 4 && blockIdx.x < kStampWgs)       \
-            g_stamps[((size_t)blockIdx.x * 4 + wave) * 32 + 8 * (t - (a.T >> 1)) + (i)] = __builtin_amdgcn_s_memtime(); \
+        if ((t == (a.T >> 1) || t == (a.T >> 1) + 1) && lane == 0 && wave < 8 && blockIdx.x < kStampWgs / 2)   \
+            g_stamps[((size_t)blockIdx.x * 8 + wave) * 32 + 8 * (t - (a.T >> 1)) + (i)] = __builtin_amdgcn_s_memtime(); \
         __builtin_amdgcn_sched_barrier(0);                                                                    \
     } while (0)
 // (lstm_bwd4_kernel<16>, tools/stamps_bwd.py: one step from the middle of the sequence -- 0 top, 1 products issued,
@@ -1976,7 +1976,11 @@ __global__ void __launch_bounds__(512) lstm_rec16_kernel(const LstmSeqArgs a) {
         hvo[i] = 4u * (unsigned)(hslot[i] * 64 + l32[i]);
     }
     const int t_outs = a.T - a.t_out0;
-    const wrsrc_t hrs = make_wrsrc(a.hout ? a.hout + (size_t)rowtile * t_outs * HPK * 64 : a.hout);
+    // (h sequence: a descriptor of 2 GiB where the launch wants it and of nothing where not; a step before t_out0 sets
+    // the lane offset's top bit: the hardware drops a store whose lane offset is out of range, so the stores need no
+    // branch -- behind one, the compiler's load counters would wait for the stores at the top of every step)
+    const wrsrc_t hrs = __builtin_amdgcn_make_buffer_rsrc(a.hout ? a.hout + (size_t)rowtile * t_outs * HPK * 64 : a.hout, 0,
+                                                          a.hout ? 0x7fffffff : 0, 0x00020000);
     // (training: the arrays the backward kernels read, this row tile's and this layer's part)
     const wrsrc_t svc = make_wrsrc(SAVE ? a.sv_c + ((size_t)rowtile * a.T * SL + L0) * HPK * 64 : nullptr);
     const wrsrc_t svh = make_wrsrc(SAVE ? a.sv_h + ((size_t)rowtile * a.T * SL + L0) * HPK * 64 : nullptr);
@@ -2026,8 +2030,13 @@ __global__ void __launch_bounds__(512) lstm_rec16_kernel(const LstmSeqArgs a) {
     constexpr int IA = 2, KA = 8 * IA;
     static_assert(KA < KS && IA < TPW - 1, "lstm_rec16_kernel: the two-phase step needs more than IA + 1 tiles per wave");
     using std::integral_constant;
-    auto run = [&](auto ntl_c) {
+    auto run = [&](auto ntl_c, auto young_c) {
         constexpr int NTL = decltype(ntl_c)::value;                // tiles this wave owns
+        // The two waves of a SIMD (w and w + 4) do not share the matrix pipe evenly: the older one's products go first
+        // and the younger one's instruction stream waits behind its own first product.  So the older wave issues a
+        // half's products first and its cells behind them (they then run beside the younger wave's products), the
+        // younger wave its cells first where it has them (beside the older wave's products).
+        constexpr bool YOUNG = decltype(young_c)::value;
         // the LSTM cell of tile i on its gate sums of step ts (lane-local: the four gates of one unit of one day)
         auto cell = [&](auto ic, const f32x4& sum, int ts) {
             constexpr int i = decltype(ic)::value;
@@ -2061,11 +2070,10 @@ __global__ void __launch_bounds__(512) lstm_rec16_kernel(const LstmSeqArgs a) {
         auto publish = [&](auto i0, auto i1, float* hb, int ts) {
 #pragma unroll
             for (int i = decltype(i0)::value; i < decltype(i1)::value; ++i) hb[hwo[i]] = h[i];
-            if (a.hout && ts >= a.t_out0) {
+            const unsigned skip = ts >= a.t_out0 ? 0u : 0x80000000u;
 #pragma unroll
-                for (int i = decltype(i0)::value; i < decltype(i1)::value; ++i)
-                    bstore1(hrs, h[i], hvo[i], (unsigned)(ts - a.t_out0) * (unsigned)(HPK * 256));
-            }
+            for (int i = decltype(i0)::value; i < decltype(i1)::value; ++i)
+                bstore1(hrs, h[i], hvo[i] | skip, (unsigned)(ts - a.t_out0) * (unsigned)(HPK * 256));
         };
         f32x4 late[TPW - IA];
         auto step = [&](int t, auto first_c) {
@@ -2078,55 +2086,66 @@ __global__ void __launch_bounds__(512) lstm_rec16_kernel(const LstmSeqArgs a) {
 #pragma unroll
             for (int i = 0; i < TPW; ++i) acc[i] = pre[i];
             load_pre(pre, t + 1 < a.T ? t + 1 : t);                // lands while the products run
-            if (!FIRST) {
+            auto late_cells = [&]() {
                 cell(integral_constant<int, IA>{}, late[0], t - 1);
                 if constexpr (NTL - IA > 1) cell(integral_constant<int, IA + 1>{}, late[1], t - 1);
+            };
+            // (sched_barrier: nothing moves across; the order of the two groups is the point, see YOUNG above)
+            if (!FIRST && YOUNG) {
+                late_cells();
+                __builtin_amdgcn_sched_barrier(0);
             }
             if (!FIRST || has_state) products(acc, hr, ntl_c, integral_constant<int, 0>{}, integral_constant<int, KA>{});
-            if (!FIRST) {
-                // (the late cells' instructions one by one between the products, from the first product on: the tail of
-                // their dependent chains and the h write have the remaining products beside them)
-#pragma unroll
-                for (int r = 0; r < 16 * (NTL - IA); ++r) {
-                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                    __builtin_amdgcn_sched_group_barrier(0x002, 1, 0);
-                    __builtin_amdgcn_sched_group_barrier(0x400, 1, 0);
-                }
-                publish(integral_constant<int, IA>{}, ntl_c, hb_prev, t - 1);
+            if (!FIRST && !YOUNG) {
+                __builtin_amdgcn_sched_barrier(0);
+                late_cells();
             }
+            if (!FIRST) publish(integral_constant<int, IA>{}, ntl_c, hb_prev, t - 1);
             REC_STAMP(1);
             __syncthreads();                                       // B(t-1): all of h(t-1) published
             REC_STAMP(4);
-            // (tile by tile: the early tiles finish first and their cells run beside the later tiles' products)
-            if (!FIRST || has_state) {
+            if (YOUNG || FIRST) {
+                // (tile by tile: the early tiles finish first and their cells run beside the later tiles' products)
+                if (!FIRST || has_state) {
 #pragma unroll
-                for (int j = KA; j < KS; ++j) acc[0] = mfma16(wreg[0][j], hr[j * 64], acc[0]);
-            }
-            cell(integral_constant<int, 0>{}, acc[0], t);
-            if (!FIRST || has_state) {
-#pragma unroll
-                for (int j = KA; j < KS; ++j) acc[1] = mfma16(wreg[1][j], hr[j * 64], acc[1]);
-            }
-            cell(integral_constant<int, 1>{}, acc[1], t);
-            if (!FIRST || has_state) {
-#pragma unroll
-                for (int i = IA; i < NTL; ++i) {
-#pragma unroll
-                    for (int j = KA; j < KS; ++j) acc[i] = mfma16(wreg[i][j], hr[j * 64], acc[i]);
+                    for (int j = KA; j < KS; ++j) acc[0] = mfma16(wreg[0][j], hr[j * 64], acc[0]);
                 }
+                if (!FIRST) __builtin_amdgcn_sched_barrier(0);
+                cell(integral_constant<int, 0>{}, acc[0], t);
+                if (!FIRST || has_state) {
+#pragma unroll
+                    for (int j = KA; j < KS; ++j) acc[1] = mfma16(wreg[1][j], hr[j * 64], acc[1]);
+                }
+                cell(integral_constant<int, 1>{}, acc[1], t);
+                if (!FIRST || has_state) {
+#pragma unroll
+                    for (int i = IA; i < NTL; ++i) {
+#pragma unroll
+                        for (int j = KA; j < KS; ++j) acc[i] = mfma16(wreg[i][j], hr[j * 64], acc[i]);
+                    }
+                }
+                if (!FIRST) {
+                    // (the cells of tiles 0 and 1 one instruction per product of the tiles behind them)
+#pragma unroll
+                    for (int r = 0; r < 2 * (KS - KA); ++r) {
+                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x002, 1, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x400, 1, 0);
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int j = KA; j < KS; ++j) {
+                    const float b = hr[j * 64];
+#pragma unroll
+                    for (int i = 0; i < NTL; ++i) acc[i] = mfma16(wreg[i][j], b, acc[i]);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                cell(integral_constant<int, 0>{}, acc[0], t);
+                cell(integral_constant<int, 1>{}, acc[1], t);
             }
 #pragma unroll
             for (int i = IA; i < NTL; ++i) late[i - IA] = acc[i];
-            if (!FIRST) {
-                // (tile 0's products, then the cells of tiles 0 and 1 one instruction per product of the tiles behind them)
-                __builtin_amdgcn_sched_group_barrier(0x008, KS - KA, 0);
-#pragma unroll
-                for (int r = 0; r < 2 * (KS - KA); ++r) {
-                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                    __builtin_amdgcn_sched_group_barrier(0x002, 1, 0);
-                    __builtin_amdgcn_sched_group_barrier(0x400, 1, 0);
-                }
-            }
             REC_STAMP(5);
             publish(integral_constant<int, 0>{}, integral_constant<int, IA>{}, hb_next, t);
             REC_STAMP(2);
@@ -2141,8 +2160,13 @@ __global__ void __launch_bounds__(512) lstm_rec16_kernel(const LstmSeqArgs a) {
         publish(integral_constant<int, IA>{}, ntl_c, smem + (a.T & 1) * HB, a.T - 1);
         __syncthreads();
     };
-    if (ntile == TPW) run(integral_constant<int, TPW>{});
-    else run(integral_constant<int, TPW - 1>{});
+    if (wave < 4) {
+        if (ntile == TPW) run(integral_constant<int, TPW>{}, integral_constant<bool, false>{});
+        else run(integral_constant<int, TPW - 1>{}, integral_constant<bool, false>{});
+    } else {
+        if (ntile == TPW) run(integral_constant<int, TPW>{}, integral_constant<bool, true>{});
+        else run(integral_constant<int, TPW - 1>{}, integral_constant<bool, true>{});
+    }
     if (a.state_out && row_ok) {
         float* st = a.state_out + ((size_t)row_raw * SNL + a.st_l0) * 2 * HP;
 #pragma unroll
@@ -4796,7 +4820,10 @@ static int launch_lstm_rec16(const LstmSeqArgs& a, hipStream_t st) {
     const bool fits = a.pre_t && !a.sv_gates
         ? ((size_t)(32 * NT + 8) * (size_t)a.pre_stride + (size_t)a.n_rows + (size_t)a.T * (size_t)a.pre_tstride) * 4 < (1ull << 32)
         : (size_t)a.T * sl * (16 * NT) * 256 < (1ull << 32);
-    if (!fits) { set_error("lstm_rec16_kernel: a row tile of pre-activations spans 4 GiB or more"); return -4; }
+    if (!fits || (size_t)a.T * (4 * NT) * 256 >= (1ull << 31)) {
+        set_error("lstm_rec16_kernel: a row tile's part of an array spans more than 32-bit offsets reach");
+        return -4;
+    }
     // (two 16-row tiles per 32-row tile: the odd one of a ragged tail runs on clamped rows, so that the tile-B
     // outputs the next stage reads are written whole)
     if (a.sv_gates) hipLaunchKernelGGL((lstm_rec16_kernel<NT, true>), dim3((unsigned)(2 * a.n_rowtiles)), dim3(512), lds, st, a);

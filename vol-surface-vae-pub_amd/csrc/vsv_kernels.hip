@@ -1091,6 +1091,13 @@ struct LstmSeqArgs {
     // the state arrays (state_in / state_out / gate_out) hold st_nl layers per row and this launch's layer 0
     // is layer st_l0 of them (0: NL layers, this launch's own)
     int st_nl, st_l0;
+    // lstm_rec16_kernel<13>, inference: a Linear on the layer's h of every step rides as the spare gate tile of
+    // wave 2 (the posterior encoder's z_mean in the date-range prefix).  hd_w / hd_b: one packed dense layer of one
+    // output tile over the layer's 4*NT k-steps; hd_out: tile-B [inst][hd_slots][64] in natural feature order
+    // (feature j: slot j >> 1, lane half j & 1), features >= hd_n written as zeros; hd_slots <= 8
+    const float *hd_w, *hd_b;
+    float* hd_out;
+    int hd_n, hd_slots;
 };
 
 // per-thread constants of the decoder input assembly
@@ -1928,6 +1935,9 @@ __global__ void __launch_bounds__(512) lstm_rec16_kernel(const LstmSeqArgs a) {
     const DropArgs drop = dropping ? resolve_drop(a.drop) : a.drop;
     const int ntile = __builtin_amdgcn_readfirstlane((KS - wave + 7) / 8);     // tiles this wave owns (TPW or TPW - 1)
     float* const hbase = smem + lane;
+    // (a Linear head on h rides as wave 2's spare tile, see LstmSeqArgs::hd_out)
+    constexpr bool HD_BUILT = !SAVE && NT == 13;
+    const bool hd = HD_BUILT && a.hd_out != nullptr && wave == 2;
 
     // per owned tile: this lane's hidden unit and where its values live in the 32-row layouts
     int gslot[TPW], l32[TPW], hpos[TPW], hslot[TPW], hwo[TPW];
@@ -1959,6 +1969,15 @@ __global__ void __launch_bounds__(512) lstm_rec16_kernel(const LstmSeqArgs a) {
                 wreg[i][j] = a.w[0][((size_t)((kk >> 3) * NT + (n >> 5)) * 64 + ((kk & 1) * 32 + (n & 31))) * 4 + ((kk >> 1) & 3)];
             }
         }
+        if (hd) {
+            // the head's rows as the wave's spare tile: A[i][k] = W_head[output i][unit 4j + k] from the dense layer's
+            // fragments ([quad][tile 0][lane half * 32 + output][k-step of the quad], k-step s = units 2s, 2s + 1)
+#pragma unroll
+            for (int j = 0; j < KS; ++j) {
+                const int u = 4 * j + ul;
+                wreg[TPW - 1][j] = a.hd_w[((size_t)(u >> 3) * 64 + ((u & 1) * 32 + ir)) * 4 + ((u >> 1) & 3)];
+            }
+        }
     }
     // Per-step traffic is buffer-addressed: descriptor base (this row tile's part of the array) + a lane offset that
     // never changes + a scalar step offset, so that a load or store costs no vector instruction and no address pair.
@@ -1985,6 +2004,25 @@ __global__ void __launch_bounds__(512) lstm_rec16_kernel(const LstmSeqArgs a) {
     const wrsrc_t svc = make_wrsrc(SAVE ? a.sv_c + ((size_t)rowtile * a.T * SL + L0) * HPK * 64 : nullptr);
     const wrsrc_t svh = make_wrsrc(SAVE ? a.sv_h + ((size_t)rowtile * a.T * SL + L0) * HPK * 64 : nullptr);
     const wrsrc_t svd = make_wrsrc(dropping ? a.sv_hd + (size_t)rowtile * a.T * HPK * 64 : nullptr);
+    // the head's bias (this lane: outputs 4 ul .. 4 ul + 3 of its day), where its outputs go and which of them exist
+    f32x4 hbias = {0.0f, 0.0f, 0.0f, 0.0f};
+    unsigned zvo[4] = {0x80000000u, 0x80000000u, 0x80000000u, 0x80000000u};
+    if (hd) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int j = 4 * ul + r;
+            hbias[r] = a.hd_b[(ul & 1) * 16 + 4 * (ul >> 1) + r];
+            if (j < 2 * a.hd_slots) zvo[r] = 4u * (unsigned)((j >> 1) * 64 + (j & 1) * 32 + m);
+        }
+    }
+    const wrsrc_t hds = __builtin_amdgcn_make_buffer_rsrc(hd ? a.hd_out + (size_t)rowtile * a.T * a.hd_slots * 64 : a.hd_out, 0,
+                                                          hd ? 0x7fffffff : 0, 0x00020000);
+    auto head_store = [&](const f32x4& v, int ts) {
+        const unsigned skip = ts >= 0 ? 0u : 0x80000000u;
+        const unsigned so = (unsigned)ts * (unsigned)(a.hd_slots * 256);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) bstore1(hds, (4 * ul + r < a.hd_n) ? v[r] : 0.0f, zvo[r] | skip, so);
+    };
     auto load_pre = [&](f32x4 (&pre)[TPW], int t) {
         const unsigned so = (unsigned)t * pstep;
 #pragma unroll
@@ -2030,8 +2068,11 @@ __global__ void __launch_bounds__(512) lstm_rec16_kernel(const LstmSeqArgs a) {
     constexpr int IA = 2, KA = 8 * IA;
     static_assert(KA < KS && IA < TPW - 1, "lstm_rec16_kernel: the two-phase step needs more than IA + 1 tiles per wave");
     using std::integral_constant;
-    auto run = [&](auto ntl_c, auto young_c) {
+    auto run = [&](auto ntl_c, auto young_c, auto hd_c) {
         constexpr int NTL = decltype(ntl_c)::value;                // tiles this wave owns
+        constexpr bool HD = decltype(hd_c)::value;                 // ... and the head as one more tile of products
+        constexpr int NTP = HD ? NTL + 1 : NTL;
+        const integral_constant<int, NTP> ntp_c{};
         // The two waves of a SIMD (w and w + 4) do not share the matrix pipe evenly: the older one's products go first
         // and the younger one's instruction stream waits behind its own first product.  So the older wave issues a
         // half's products first and its cells behind them (they then run beside the younger wave's products), the
@@ -2085,6 +2126,7 @@ __global__ void __launch_bounds__(512) lstm_rec16_kernel(const LstmSeqArgs a) {
             REC_STAMP(0);
 #pragma unroll
             for (int i = 0; i < TPW; ++i) acc[i] = pre[i];
+            if (HD) acc[NTL] = hbias;
             load_pre(pre, t + 1 < a.T ? t + 1 : t);                // lands while the products run
             auto late_cells = [&]() {
                 cell(integral_constant<int, IA>{}, late[0], t - 1);
@@ -2095,7 +2137,7 @@ __global__ void __launch_bounds__(512) lstm_rec16_kernel(const LstmSeqArgs a) {
                 late_cells();
                 __builtin_amdgcn_sched_barrier(0);
             }
-            if (!FIRST || has_state) products(acc, hr, ntl_c, integral_constant<int, 0>{}, integral_constant<int, KA>{});
+            if (!FIRST || has_state) products(acc, hr, ntp_c, integral_constant<int, 0>{}, integral_constant<int, KA>{});
             if (!FIRST && !YOUNG) {
                 __builtin_amdgcn_sched_barrier(0);
                 late_cells();
@@ -2138,7 +2180,7 @@ __global__ void __launch_bounds__(512) lstm_rec16_kernel(const LstmSeqArgs a) {
                 for (int j = KA; j < KS; ++j) {
                     const float b = hr[j * 64];
 #pragma unroll
-                    for (int i = 0; i < NTL; ++i) acc[i] = mfma16(wreg[i][j], b, acc[i]);
+                    for (int i = 0; i < NTP; ++i) acc[i] = mfma16(wreg[i][j], b, acc[i]);
                 }
                 __builtin_amdgcn_sched_barrier(0);
                 cell(integral_constant<int, 0>{}, acc[0], t);
@@ -2146,6 +2188,7 @@ __global__ void __launch_bounds__(512) lstm_rec16_kernel(const LstmSeqArgs a) {
             }
 #pragma unroll
             for (int i = IA; i < NTL; ++i) late[i - IA] = acc[i];
+            if (HD) head_store(acc[NTL], t - 1);                   // (the head of h(t-1): the step's B operands)
             REC_STAMP(5);
             publish(integral_constant<int, 0>{}, integral_constant<int, IA>{}, hb_next, t);
             REC_STAMP(2);
@@ -2159,13 +2202,24 @@ __global__ void __launch_bounds__(512) lstm_rec16_kernel(const LstmSeqArgs a) {
         if constexpr (NTL - IA > 1) cell(integral_constant<int, IA + 1>{}, late[1], a.T - 1);
         publish(integral_constant<int, IA>{}, ntl_c, smem + (a.T & 1) * HB, a.T - 1);
         __syncthreads();
+        if (HD) {
+            // the head of the last step's h
+            const float* hf = hbase + (a.T & 1) * HB;
+            f32x4 hv = hbias;
+#pragma unroll
+            for (int j = 0; j < KS; ++j) hv = mfma16(wreg[NTL][j], hf[j * 64], hv);
+            head_store(hv, a.T - 1);
+        }
     };
+    const integral_constant<bool, false> no{};
+    const integral_constant<bool, true> yes{};
     if (wave < 4) {
-        if (ntile == TPW) run(integral_constant<int, TPW>{}, integral_constant<bool, false>{});
-        else run(integral_constant<int, TPW - 1>{}, integral_constant<bool, false>{});
+        if (ntile == TPW) run(integral_constant<int, TPW>{}, no, no);
+        else if (HD_BUILT && hd) run(integral_constant<int, TPW - 1>{}, no, integral_constant<bool, HD_BUILT>{});
+        else run(integral_constant<int, TPW - 1>{}, no, no);
     } else {
-        if (ntile == TPW) run(integral_constant<int, TPW>{}, integral_constant<bool, true>{});
-        else run(integral_constant<int, TPW - 1>{}, integral_constant<bool, true>{});
+        if (ntile == TPW) run(integral_constant<int, TPW>{}, yes, no);
+        else run(integral_constant<int, TPW - 1>{}, yes, no);
     }
     if (a.state_out && row_ok) {
         float* st = a.state_out + ((size_t)row_raw * SNL + a.st_l0) * 2 * HP;
@@ -4885,7 +4939,8 @@ constexpr int kPreMaxQ = 16;     // input quads (8 features each) of a layer: <=
 // later overwrites it with the activated gates.
 template <int NT>
 __device__ __forceinline__ void lstm_pre_body(const float* w, const float* b, int nq_in, const float* x,
-                                              long x_stride, float* gates, long g_stride, long n_inst, int ipw) {
+                                              long x_stride, float* gates, long g_stride, long n_inst, int ipw,
+                                              const float* x2 = nullptr, long x2_stride = 0, int n4a = 0) {
     // an instance's x (4 nq_in k-steps x 64 lanes, contiguous) is shared by the NT waves: the workgroup copies it
     // into LDS once -- the NEXT instance's while this one's products run (double buffer, one barrier per instance) --
     // and every wave reads its B operands from there.  (Read straight from global memory, quad by quad in front of
@@ -4913,10 +4968,14 @@ __device__ __forceinline__ void lstm_pre_body(const float* w, const float* b, in
     // trip and the acknowledgement of the previous instance's sixteen stores before the products could start)
     float4 pf0 = make_float4(0.0f, 0.0f, 0.0f, 0.0f), pf1 = pf0;
     const int e0 = tid, e1 = tid + 64 * NT;
+    // (x2: an instance's x in two pieces -- its first n4a float4s at x, the rest at x2; the decoder's [ctx | z] read
+    // where the two encoders left them)
+    if (!x2) n4a = n4;
     auto fetch = [&](int k) {
         const float4* src = (const float4*)(x + (size_t)(i0 + k) * (size_t)x_stride);
-        if (e0 < n4) pf0 = src[e0];
-        if (e1 < n4) pf1 = src[e1];
+        const float4* src2 = x2 ? (const float4*)(x2 + (size_t)(i0 + k) * (size_t)x2_stride) - n4a : src;
+        if (e0 < n4) pf0 = e0 < n4a ? src[e0] : src2[e0];
+        if (e1 < n4) pf1 = e1 < n4a ? src[e1] : src2[e1];
     };
     auto stash = [&](int buf, int off) {
         float4* dst = (float4*)xs[buf] + off;
@@ -4958,8 +5017,9 @@ __device__ __forceinline__ void lstm_pre_body(const float* w, const float* b, in
 }
 template <int NT>
 __global__ void __launch_bounds__(64 * NT) lstm_pre_kernel(const float* w, const float* b, int nq_in, const float* x,
-                                                           long x_stride, float* gates, long g_stride, long n_inst, int ipw) {
-    lstm_pre_body<NT>(w, b, nq_in, x, x_stride, gates, g_stride, n_inst, ipw);
+                                                           long x_stride, float* gates, long g_stride, long n_inst, int ipw,
+                                                           const float* x2, long x2_stride, int n4a) {
+    lstm_pre_body<NT>(w, b, nq_in, x, x_stride, gates, g_stride, n_inst, ipw, x2, x2_stride, n4a);
 }
 // two launches as one (see lstm_rec4_pair_kernel): blockIdx.y picks the argument set, all of it scalars
 struct PreArgs {
@@ -4977,7 +5037,8 @@ __global__ void __launch_bounds__(64 * NT) lstm_pre_pair_kernel(const PreArgs p0
 }
 
 static int launch_lstm_pre(int NT, const float* w, const float* b, int nq_in, const float* x, long x_stride,
-                           float* gates, long g_stride, long insts, hipStream_t st) {
+                           float* gates, long g_stride, long insts, hipStream_t st,
+                           const float* x2 = nullptr, long x2_stride = 0, int n4a = 0) {
     if (insts > 0x7fffffffL) { set_error("lstm_pre_kernel: too many instances"); return -2; }
     if (nq_in < 1 || nq_in > kPreMaxQ) { set_error("lstm_pre_kernel: %d input quads (1..%d built)", nq_in, kPreMaxQ); return -4; }
     if (insts <= 0) return 0;
@@ -4987,8 +5048,9 @@ static int launch_lstm_pre(int NT, const float* w, const float* b, int nq_in, co
     int ipw = (int)((insts + 255) / 256);
     ipw = ipw < 1 ? 1 : (ipw > 64 ? 64 : ipw);
     const unsigned grid = (unsigned)((insts + ipw - 1) / ipw);
-    if (NT == 13) hipLaunchKernelGGL(lstm_pre_kernel<13>, dim3(grid), dim3(64 * 13), 0, st, w, b, nq_in, x, x_stride, gates, g_stride, insts, ipw);
-    else if (NT == 16) hipLaunchKernelGGL(lstm_pre_kernel<16>, dim3(grid), dim3(64 * 16), 0, st, w, b, nq_in, x, x_stride, gates, g_stride, insts, ipw);
+    if (x2 && (n4a < 1 || n4a >= nq_in * 64)) { set_error("lstm_pre_kernel: bad split of the input"); return -1; }
+    if (NT == 13) hipLaunchKernelGGL(lstm_pre_kernel<13>, dim3(grid), dim3(64 * 13), 0, st, w, b, nq_in, x, x_stride, gates, g_stride, insts, ipw, x2, x2_stride, n4a);
+    else if (NT == 16) hipLaunchKernelGGL(lstm_pre_kernel<16>, dim3(grid), dim3(64 * 16), 0, st, w, b, nq_in, x, x_stride, gates, g_stride, insts, ipw, x2, x2_stride, n4a);
     else { set_error("unsupported LSTM hidden size: %d tiles of 8 units", NT); return -4; }
     return launch_check("lstm_pre_kernel");
 }
@@ -5240,7 +5302,8 @@ extern "C" int vsv_encode_windows_layer0(const vsv_dims* dims, const float* pack
 
 static int encode_windows_layer1_impl(const vsv_dims* dims, const float* packed, int which, long n_windows, int T,
                                       const float* state_in, float* state_out, float* out, int out_f, void* ws,
-                                      size_t ws_bytes, void* stream);
+                                      size_t ws_bytes, void* stream, float* head_tb = nullptr, int head_slots = 0,
+                                      bool no_head = false);
 
 extern "C" int vsv_encode_windows_layer1(const vsv_dims* dims, const float* packed, int which, long n_windows, int T,
                                          const float* state_in, float* state_out, float* out, void* ws,
@@ -5248,16 +5311,20 @@ extern "C" int vsv_encode_windows_layer1(const vsv_dims* dims, const float* pack
     return encode_windows_layer1_impl(dims, packed, which, n_windows, T, state_in, state_out, out, 0, ws, ws_bytes, stream);
 }
 
-// out_f: head outputs written per (window, step), 0 = all (the prefix pipeline wants z_mean only: L of 2L)
+// out_f: head outputs written per (window, step), 0 = all (the prefix pipeline wants z_mean only: L of 2L).
+// The date-range prefix (vsv_context_prefix, fused hand-over) has the decoder read the encoders' outputs in the
+// tile-B form the recurrent launch leaves them in: head_tb / head_slots -- the head's first out_f outputs of every
+// step as tile-B [inst][head_slots][64], computed inside the recurrent launch (LstmSeqArgs::hd_out), no head launch;
+// no_head -- the head is the identity (compress_context off) and the consumer reads h1 from the workspace itself.
 static int encode_windows_layer1_impl(const vsv_dims* dims, const float* packed, int which, long n_windows, int T,
                                       const float* state_in, float* state_out, float* out, int out_f, void* ws,
-                                      size_t ws_bytes, void* stream) {
+                                      size_t ws_bytes, void* stream, float* head_tb, int head_slots, bool no_head) {
     VSV_LAYOUT_OR_FAIL("vsv_encode_windows_layer1")
     if (which < 0 || which > 1) { set_error("vsv_encode_windows_layer1: which must be 0 or 1"); return -1; }
     if (lay.NL != 2) { set_error("vsv_encode_windows_layer1: the layer split is for two-layer memories"); return -4; }
     if (n_windows < 0 || T < 0) { set_error("vsv_encode_windows_layer1: negative size"); return -1; }
     if (n_windows == 0 || T == 0) return 0;
-    if (!packed || !out || !ws) { set_error("vsv_encode_windows_layer1: null pointer"); return -1; }
+    if (!packed || (!out && !head_tb && !no_head) || !ws) { set_error("vsv_encode_windows_layer1: null pointer"); return -1; }
     const long rt = (n_windows + 31) / 32;
     if (rt > kWideMaxRowtiles) { set_error("vsv_encode_windows_layer1: at most %ld windows per call", kWideMaxRowtiles * 32); return -5; }
     size_t off[5];
@@ -5282,8 +5349,16 @@ static int encode_windows_layer1_impl(const vsv_dims* dims, const float* packed,
     l.din.state_in = state_in; l.din.state_div = 1;
     l.state_out = state_out;
     l.st_nl = 2; l.st_l0 = 1;
+    if (head_tb) {
+        if (NT != 13 || e.head.nt != 1 || e.head.nq != NT || out_f < 1 || out_f > 16 || head_slots < 1 || head_slots > 8 ||
+            !lstm_rec16_applies(l, 1) || lstm_rec4_applies(l)) {
+            set_error("vsv_encode_windows_layer1: the head cannot ride in this recurrent launch"); return -4;
+        }
+        l.hd_w = packed + e.head.w_off; l.hd_b = packed + e.head.b_off;
+        l.hd_out = head_tb; l.hd_n = out_f; l.hd_slots = head_slots;
+    }
     rc = launch_lstm<0>(l, NT, 1, false, st);
-    if (rc) return rc;
+    if (rc || head_tb || no_head) return rc;
     DenseChainArgs h = {};
     h.n_layers = 1;
     fill_dense(h, 0, packed, e.head);
@@ -5323,12 +5398,26 @@ static int decode_prefix_check(const char* who, const Layout& lay, const float* 
     return 0;
 }
 
+// ctx_tb / z_tb (the fused hand-over of vsv_context_prefix): the input [ctx_t | z_mean_t] of every step read in two
+// pieces where the encoders' recurrent launches left them in tile-B -- the context head's outputs or the context
+// memory's h1 ([inst][ctx_slots][64], the first Lc/2 slots) and the posterior head's outputs ([inst][z_slots][64]) --
+// instead of assembled by a launch of its own
+static int decode_prefix_layer0_impl(const vsv_dims* dims, const float* packed, const vsv_decode_in* in, long n_rows,
+                                     int T, float* state_out, void* ws, size_t ws_bytes, void* stream,
+                                     const float* ctx_tb, int ctx_slots, const float* z_tb, int z_slots);
+
 extern "C" int vsv_decode_prefix_layer0(const vsv_dims* dims, const float* packed, const vsv_decode_in* in, long n_rows,
                                         int T, float* state_out, void* ws, size_t ws_bytes, void* stream) {
+    return decode_prefix_layer0_impl(dims, packed, in, n_rows, T, state_out, ws, ws_bytes, stream, nullptr, 0, nullptr, 0);
+}
+
+static int decode_prefix_layer0_impl(const vsv_dims* dims, const float* packed, const vsv_decode_in* in, long n_rows,
+                                     int T, float* state_out, void* ws, size_t ws_bytes, void* stream,
+                                     const float* ctx_tb, int ctx_slots, const float* z_tb, int z_slots) {
     VSV_LAYOUT_OR_FAIL("vsv_decode_prefix_layer0")
     size_t off[4];
     if (int rc = decode_prefix_check("vsv_decode_prefix_layer0", lay, packed, in, n_rows, T, ws, ws_bytes, off)) return rc;
-    if (in->ctx_T != T || in->z_T != T || !in->ctx || !in->zb || in->lv) {
+    if (!ctx_tb && (in->ctx_T != T || in->z_T != T || !in->ctx || !in->zb || in->lv)) {
         set_error("vsv_decode_prefix_layer0: the prefix runs on (ctx_t, z_mean_t) for all T steps"); return -1;
     }
     const DecLayout& dc = lay.dec;
@@ -5348,18 +5437,28 @@ extern "C" int vsv_decode_prefix_layer0(const vsv_dims* dims, const float* packe
     hipStream_t st = (hipStream_t)stream;
     LstmSeqArgs r = l;
     r.pre_g = (const float*)(base + off[2]);
-    if (!lstm_rec16_applies(r, 1)) return launch_lstm<1>(l, lay.NTd, 1, false, st);
+    if (!lstm_rec16_applies(r, 1)) {
+        if (ctx_tb) { set_error("vsv_decode_prefix_layer0: the tile-B hand-over needs the layer-stage launches"); return -4; }
+        return launch_lstm<1>(l, lay.NTd, 1, false, st);
+    }
     // [ctx_t | z_mean_t] of every step, its gate pre-activations as one GEMM over all (row tile, step) instances, and
     // the 16-row recurrent launch
-    float* x = (float*)(base + off[3]);
-    l.sv_x = x;
-    const long total = l.n_rowtiles * T * dc.kx * 64;
-    if ((total + 255) / 256 > 0x7fffffffL) { set_error("vsv_decode_prefix_layer0: too many instances"); return -2; }
-    hipLaunchKernelGGL(decoder_input_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, l);
-    int rc = launch_check("decoder_input_kernel");
-    if (rc) return rc;
-    rc = launch_lstm_pre(lay.NTd, l.w[0], l.b[0], dc.kx >> 2, x, (long)dc.kx * 64, (float*)(base + off[2]), (long)16 * lay.NTd * 64,
-                         l.n_rowtiles * T, st);
+    int rc;
+    if (ctx_tb) {
+        if (lay.Lc % 2 || z_slots != dc.kx - lay.Lc / 2 || z_slots < 1) { set_error("vsv_decode_prefix_layer0: bad tile-B hand-over"); return -1; }
+        rc = launch_lstm_pre(lay.NTd, l.w[0], l.b[0], dc.kx >> 2, ctx_tb, (long)ctx_slots * 64, (float*)(base + off[2]),
+                             (long)16 * lay.NTd * 64, l.n_rowtiles * T, st, z_tb, (long)z_slots * 64, (lay.Lc / 2) * 16);
+    } else {
+        float* x = (float*)(base + off[3]);
+        l.sv_x = x;
+        const long total = l.n_rowtiles * T * dc.kx * 64;
+        if ((total + 255) / 256 > 0x7fffffffL) { set_error("vsv_decode_prefix_layer0: too many instances"); return -2; }
+        hipLaunchKernelGGL(decoder_input_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, l);
+        rc = launch_check("decoder_input_kernel");
+        if (rc) return rc;
+        rc = launch_lstm_pre(lay.NTd, l.w[0], l.b[0], dc.kx >> 2, x, (long)dc.kx * 64, (float*)(base + off[2]), (long)16 * lay.NTd * 64,
+                             l.n_rowtiles * T, st);
+    }
     if (rc) return rc;
     r.din = vsv_decode_in();
     r.din.state_in = in->state_in; r.din.state_div = 1;
@@ -5407,6 +5506,30 @@ struct PrefixPlan {
     size_t total;
 };
 
+// a head's outputs for every (day, step): row-major (width floats), or -- the fused hand-over -- tile-B of up to 8
+// slots per (row tile, step)
+static size_t prefix_head_bytes(long n_days, int T, int width) {
+    const size_t rows = (size_t)n_days * T * width, tb = (size_t)((n_days + 31) / 32) * T * 8 * 64;
+    return align256((rows > tb ? rows : tb) * sizeof(float));
+}
+
+// The decoder reads the encoders' outputs where their recurrent launches leave them (no head launches, no input
+// assembly): the posterior head's z_mean -- and with compress_context the context head -- ride as the spare gate
+// tile of lstm_rec16_kernel<13> and land in tile-B; without compress_context the context embedding is the memory's
+// h1 itself.  For the sizes that run the 16-row launches.  VSV_PREFIX_FUSE=0: off.
+static bool prefix_fused(const vsv_dims& dims, const Layout& lay, long n_days) {
+    static const bool off = [] { const char* e = getenv("VSV_PREFIX_FUSE"); return e && e[0] == '0'; }();
+    const int cs = lay.Lc / 2, zs = lay.dec.kx - cs;
+    LstmSeqArgs probe = {};
+    probe.n_rowtiles = (n_days + 31) / 32;
+    probe.pre_g = (const float*)&probe;                          // (any non-null pointer: the test is on the launch's kind)
+    const bool ctx_ok = dims.compress_context ? (lay.enc[1].head.nt == 1 && lay.enc[1].head.nq == 13 && lay.Lc <= 16 && cs >= 1 && cs <= 8)
+                                              : lay.Lc == lay.Hm;
+    return !off && ctx_ok && lay.gru == 0 && lay.NL == 2 && lay.Lc % 2 == 0 && lay.NTm == 13 &&
+           lay.enc[0].head.nt == 1 && lay.enc[0].head.nq == 13 && lay.L <= 16 && 2 * zs >= lay.L && zs >= 1 && zs <= 8 &&
+           lstm_rec16_applies(probe, 1) && !lstm_rec4_applies(probe);
+}
+
 static int prefix_plan(const Layout& lay, long n_days, int C, int n_seg, PrefixPlan& p) {
     if (n_seg < 1 || n_seg > 64 || C < n_seg) return -1;
     p.n_seg = n_seg;
@@ -5422,7 +5545,7 @@ static int prefix_plan(const Layout& lay, long n_days, int C, int n_seg, PrefixP
         b += align256(wse);                                    // posterior encoder workspace
         b += align256(wse);                                    // context encoder workspace
         b += align256(wsd);                                    // decoder workspace
-        b += align256((size_t)n_days * T * lay.L * sizeof(float)) + align256((size_t)n_days * T * lay.Lc * sizeof(float));   // z_mean, ctx embedding
+        b += prefix_head_bytes(n_days, T, lay.L) + prefix_head_bytes(n_days, T, lay.Lc);   // z_mean, ctx embedding
         b += 2 * align256((size_t)n_days * nse * sizeof(float));            // encoder states
         b += align256((size_t)n_days * nsd * sizeof(float));                // decoder state
         cur += b;
@@ -5482,6 +5605,8 @@ extern "C" int vsv_context_prefix(const vsv_dims* dims, const float* packed, con
     char* base = (char*)(((uintptr_t)ws + 255) & ~(uintptr_t)255);
     const size_t nse = (size_t)lay.NL * 2 * 8 * lay.NTm;
     const float *st_e = nullptr, *st_c = nullptr, *st_d = nullptr;
+    const bool fused = prefix_fused(*dims, lay, n_days);
+    const int cslots = lay.Lc / 2, zslots = lay.dec.kx - cslots;
     int rc = 0;
     for (int i = 0; i < n_seg && rc == 0; ++i) {
         const int t0 = (i * ctx_len) / n_seg, T = ((i + 1) * ctx_len) / n_seg - t0;
@@ -5492,8 +5617,8 @@ extern "C" int vsv_context_prefix(const vsv_dims* dims, const float* packed, con
         void* ws_e = b; b += align256(wse);
         void* ws_c = b; b += align256(wse);
         void* ws_d = b; b += align256(wsd);
-        float* zm = (float*)b; b += align256((size_t)n_days * T * lay.L * sizeof(float));
-        float* cx = (float*)b; b += align256((size_t)n_days * T * lay.Lc * sizeof(float));
+        float* zm = (float*)b; b += prefix_head_bytes(n_days, T, lay.L);
+        float* cx = (float*)b; b += prefix_head_bytes(n_days, T, lay.Lc);
         float* ne = (float*)b; b += align256((size_t)n_days * nse * sizeof(float));
         float* nc = (float*)b; b += align256((size_t)n_days * nse * sizeof(float));
         float* nd = last ? state_out : (float*)b;
@@ -5510,7 +5635,10 @@ extern "C" int vsv_context_prefix(const vsv_dims* dims, const float* packed, con
             if (rc) break;
             (void)hipEventRecord(evs[which], s0);
             (void)hipStreamWaitEvent(s1, evs[which], 0);
-            rc = encode_windows_layer1_impl(dims, packed, which, n_days, T, si, so, which ? cx : zm, which ? 0 : lay.L, w, wse, s1);
+            if (fused && which == 0) rc = encode_windows_layer1_impl(dims, packed, 0, n_days, T, si, so, nullptr, lay.L, w, wse, s1, zm, zslots, false);
+            else if (fused && dims->compress_context) rc = encode_windows_layer1_impl(dims, packed, 1, n_days, T, si, so, nullptr, lay.Lc, w, wse, s1, cx, cslots, false);
+            else if (fused) rc = encode_windows_layer1_impl(dims, packed, 1, n_days, T, si, so, nullptr, 0, w, wse, s1, nullptr, 0, true);
+            else rc = encode_windows_layer1_impl(dims, packed, which, n_days, T, si, so, which ? cx : zm, which ? 0 : lay.L, w, wse, s1);
             if (rc) break;
             (void)hipEventRecord(evs[2 + which], s1);
             (void)hipStreamWaitEvent(sq[4], evs[2 + which], 0);
@@ -5521,7 +5649,14 @@ extern "C" int vsv_context_prefix(const vsv_dims* dims, const float* packed, con
             din.zb = zm; din.z_rs = (long)T * lay.L; din.z_T = T; din.z_div = 1;
             din.S = 1; din.state_in = st_d; din.state_div = 1;
             din.gate_out = last ? gate_out : nullptr;
-            rc = vsv_decode_prefix_layer0(dims, packed, &din, n_days, T, nd, ws_d, wsd, sq[4]);
+            if (fused) {
+                // (the context memory's h1 of every step: block 4 of its workspace, see enc_split_bytes)
+                const float* h1c = (const float*)((char*)(((uintptr_t)ws_c + 255) & ~(uintptr_t)255) + off5[4]);
+                if (dims->compress_context) rc = decode_prefix_layer0_impl(dims, packed, &din, n_days, T, nd, ws_d, wsd, sq[4], cx, cslots, zm, zslots);
+                else rc = decode_prefix_layer0_impl(dims, packed, &din, n_days, T, nd, ws_d, wsd, sq[4], h1c, 4 * lay.NTm, zm, zslots);
+            } else {
+                rc = vsv_decode_prefix_layer0(dims, packed, &din, n_days, T, nd, ws_d, wsd, sq[4]);
+            }
             if (rc == 0) {
                 (void)hipEventRecord(evs[4], sq[4]);
                 (void)hipStreamWaitEvent(sq[5], evs[4], 0);

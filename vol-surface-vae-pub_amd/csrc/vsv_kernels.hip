@@ -59,10 +59,13 @@ __device__ unsigned long long g_stamps[(size_t)kStampWgs * 4 * 32];
 // (lstm_rec4_kernel / lstm_rec16_kernel, tools/stamps_rec.py: two consecutive time steps from the middle of the
 // sequence -- 8s + 0 top of step, + 1 products issued, + 2 cell and stores issued, + 3 past the barrier; lstm_rec16_kernel:
 // + 1 first half issued, + 4 past its barrier, + 5 second half issued, + 2 early tiles published, + 3 past the barrier)
+#ifndef VSV_STAMP_NT
+#define VSV_STAMP_NT 16      /* gate tiles of the launches that write recurrent-step stamps (-DVSV_STAMP_NT=13: the encoders') */
+#endif
 #define REC_STAMP(i)                                                                                          \
     do {                                                                                                      \
         __builtin_amdgcn_sched_barrier(0);                                                                    \
-        if ((t == (a.T >> 1) || t == (a.T >> 1) + 1) && lane == 0 && wave < 8 && blockIdx.x < kStampWgs / 2)   \
+        if (NT == VSV_STAMP_NT && (t == (a.T >> 1) || t == (a.T >> 1) + 1) && lane == 0 && wave < 8 && blockIdx.x < kStampWgs / 2) \
             g_stamps[((size_t)blockIdx.x * 8 + wave) * 32 + 8 * (t - (a.T >> 1)) + (i)] = __builtin_amdgcn_s_memtime(); \
         __builtin_amdgcn_sched_barrier(0);                                                                    \
     } while (0)
@@ -1910,6 +1913,17 @@ __global__ void __launch_bounds__(64 * NT, (NT + 3) / 4) lstm_rec_kernel(const L
 // The products are summed four k at a time instead of two: results agree with lstm_kernel's to rounding, not bit
 // for bit.
 // ---------------------------------------------------------------------------
+#ifndef VSV_REC16_IA13
+#define VSV_REC16_IA13 1
+#endif
+// f(integral_constant<int, I>) for I = I0 .. I1-1, unrolled at compile time
+template <int I0, int I1, typename F>
+__device__ __forceinline__ void static_for(F&& f) {
+    if constexpr (I0 < I1) {
+        f(std::integral_constant<int, I0>{});
+        static_for<I0 + 1, I1>(f);
+    }
+}
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
 
@@ -2065,8 +2079,11 @@ __global__ void __launch_bounds__(512) lstm_rec16_kernel(const LstmSeqArgs a) {
     // Every tile's sum still takes its k-steps in ascending order on one accumulator chain: bit for bit the sums of
     // the other recurrent kernels.  The whole recurrence is compiled twice, for waves that own TPW tiles and for
     // those that own TPW - 1 (wave-uniform), so that a step has no branch between its products and its cells.
-    constexpr int IA = 2, KA = 8 * IA;
-    static_assert(KA < KS && IA < TPW - 1, "lstm_rec16_kernel: the two-phase step needs more than IA + 1 tiles per wave");
+    // (IA: half of the step's k-steps at 16 gate tiles; at 13 -- 26 k-steps, waves of 3 or 4 tiles -- one early tile,
+    // whose cell then has two tiles' products behind it: 2.214 -> 2.200 ms for the 4000-day prefix; -DVSV_REC16_IA13=2
+    // builds the other split)
+    constexpr int IA = NT == 13 ? VSV_REC16_IA13 : 2, KA = 8 * IA;
+    static_assert(KA < KS && IA >= 1 && IA < TPW - 1, "lstm_rec16_kernel: the two-phase step needs more than IA + 1 tiles per wave");
     using std::integral_constant;
     auto run = [&](auto ntl_c, auto young_c, auto hd_c) {
         constexpr int NTL = decltype(ntl_c)::value;                // tiles this wave owns
@@ -2129,8 +2146,7 @@ __global__ void __launch_bounds__(512) lstm_rec16_kernel(const LstmSeqArgs a) {
             if (HD) acc[NTL] = hbias;
             load_pre(pre, t + 1 < a.T ? t + 1 : t);                // lands while the products run
             auto late_cells = [&]() {
-                cell(integral_constant<int, IA>{}, late[0], t - 1);
-                if constexpr (NTL - IA > 1) cell(integral_constant<int, IA + 1>{}, late[1], t - 1);
+                static_for<IA, NTL>([&](auto ic) { cell(ic, late[decltype(ic)::value - IA], t - 1); });
             };
             // (sched_barrier: nothing moves across; the order of the two groups is the point, see YOUNG above)
             if (!FIRST && YOUNG) {
@@ -2148,17 +2164,15 @@ __global__ void __launch_bounds__(512) lstm_rec16_kernel(const LstmSeqArgs a) {
             REC_STAMP(4);
             if (YOUNG || FIRST) {
                 // (tile by tile: the early tiles finish first and their cells run beside the later tiles' products)
-                if (!FIRST || has_state) {
+                static_for<0, IA>([&](auto ic) {
+                    constexpr int i = decltype(ic)::value;
+                    if (!FIRST || has_state) {
 #pragma unroll
-                    for (int j = KA; j < KS; ++j) acc[0] = mfma16(wreg[0][j], hr[j * 64], acc[0]);
-                }
-                if (!FIRST) __builtin_amdgcn_sched_barrier(0);
-                cell(integral_constant<int, 0>{}, acc[0], t);
-                if (!FIRST || has_state) {
-#pragma unroll
-                    for (int j = KA; j < KS; ++j) acc[1] = mfma16(wreg[1][j], hr[j * 64], acc[1]);
-                }
-                cell(integral_constant<int, 1>{}, acc[1], t);
+                        for (int j = KA; j < KS; ++j) acc[i] = mfma16(wreg[i][j], hr[j * 64], acc[i]);
+                    }
+                    if (!FIRST && i == 0) __builtin_amdgcn_sched_barrier(0);
+                    cell(ic, acc[i], t);
+                });
                 if (!FIRST || has_state) {
 #pragma unroll
                     for (int i = IA; i < NTL; ++i) {
@@ -2167,9 +2181,9 @@ __global__ void __launch_bounds__(512) lstm_rec16_kernel(const LstmSeqArgs a) {
                     }
                 }
                 if (!FIRST) {
-                    // (the cells of tiles 0 and 1 one instruction per product of the tiles behind them)
+                    // (the early tiles' cells one instruction per product of the tiles behind them)
 #pragma unroll
-                    for (int r = 0; r < 2 * (KS - KA); ++r) {
+                    for (int r = 0; r < 32 * IA; ++r) {
                         __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
                         __builtin_amdgcn_sched_group_barrier(0x002, 1, 0);
                         __builtin_amdgcn_sched_group_barrier(0x400, 1, 0);
@@ -2183,8 +2197,7 @@ __global__ void __launch_bounds__(512) lstm_rec16_kernel(const LstmSeqArgs a) {
                     for (int i = 0; i < NTP; ++i) acc[i] = mfma16(wreg[i][j], b, acc[i]);
                 }
                 __builtin_amdgcn_sched_barrier(0);
-                cell(integral_constant<int, 0>{}, acc[0], t);
-                cell(integral_constant<int, 1>{}, acc[1], t);
+                static_for<0, IA>([&](auto ic) { cell(ic, acc[decltype(ic)::value], t); });
             }
 #pragma unroll
             for (int i = IA; i < NTL; ++i) late[i - IA] = acc[i];
@@ -2198,8 +2211,7 @@ __global__ void __launch_bounds__(512) lstm_rec16_kernel(const LstmSeqArgs a) {
         step(0, integral_constant<bool, true>{});
         for (int t = 1; t < a.T; ++t) step(t, integral_constant<bool, false>{});
         // the late tiles of the last step
-        cell(integral_constant<int, IA>{}, late[0], a.T - 1);
-        if constexpr (NTL - IA > 1) cell(integral_constant<int, IA + 1>{}, late[1], a.T - 1);
+        static_for<IA, NTL>([&](auto ic) { cell(ic, late[decltype(ic)::value - IA], a.T - 1); });
         publish(integral_constant<int, IA>{}, ntl_c, smem + (a.T & 1) * HB, a.T - 1);
         __syncthreads();
         if (HD) {

@@ -2338,22 +2338,44 @@ __device__ __forceinline__ void lstm_rec4_body(const LstmSeqArgs& a) {
             wreg[8 * q + 5] = uok ? wo.z : 0.0f; wreg[8 * q + 7] = uok ? wo.w : 0.0f;
         }
     }
+    // Per-step traffic is buffer-addressed as in lstm_rec16_kernel: descriptor base (this row tile's part of the array)
+    // + a constant lane offset + a scalar step offset; stores are unconditional -- a lane without a unit, a launch
+    // without an h sequence and a step before t_out0 put the lane offset out of the descriptor's range and the hardware
+    // drops the store -- so that the wait for the next step's pre-activations does not also wait for the stores.
+    const bool from_t = !SAVE && a.pre_t != nullptr;               // wave-uniform
+    const float* pbase = SAVE ? a.sv_gates + ((size_t)rowtile * a.T * SL + L0) * (16 * NT) * 64
+                       : from_t ? a.pre_t : a.pre_g + (size_t)rowtile * a.T * (16 * NT) * 64;
+    const wrsrc_t prs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(pbase), 0, 0x7fffffff, 0x00020000);
+    const unsigned pstep = SAVE ? (unsigned)SL * (16 * NT) * 256u : from_t ? (unsigned)a.pre_tstride * 4u : (16 * NT) * 256u;
+    const unsigned pgate = from_t ? 8u * (unsigned)a.pre_stride : 256u;
+    const unsigned nouse = uok ? 0u : 0x80000000u;                 // (stores of a lane without a unit)
+    unsigned pvo[R], hvo[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        pvo[r] = from_t ? 4u * ((unsigned)(2 * gslot + (l32 >> 5)) * (unsigned)a.pre_stride + (unsigned)row[r])
+                        : 4u * (unsigned)(gslot * 64 + l32 + 4 * r);
+        hvo[r] = 4u * (unsigned)(hslot * 64 + l32 + 4 * r) | nouse;
+    }
+    const int t_outs = a.T - a.t_out0;
+    const wrsrc_t hrs = __builtin_amdgcn_make_buffer_rsrc(a.hout ? a.hout + (size_t)rowtile * t_outs * HPK * 64 : a.hout, 0,
+                                                          a.hout ? 0x7fffffff : 0, 0x00020000);
+    const wrsrc_t svc = __builtin_amdgcn_make_buffer_rsrc(SAVE ? a.sv_c + ((size_t)rowtile * a.T * SL + L0) * HPK * 64 : nullptr, 0,
+                                                          SAVE ? 0x7fffffff : 0, 0x00020000);
+    const wrsrc_t svh = __builtin_amdgcn_make_buffer_rsrc(SAVE ? a.sv_h + ((size_t)rowtile * a.T * SL + L0) * HPK * 64 : nullptr, 0,
+                                                          SAVE ? 0x7fffffff : 0, 0x00020000);
+    const wrsrc_t svd = __builtin_amdgcn_make_buffer_rsrc(dropping ? a.sv_hd + (size_t)rowtile * a.T * HPK * 64 : nullptr, 0,
+                                                          dropping ? 0x7fffffff : 0, 0x00020000);
     auto load_pre = [&](int r, int t) -> f32x4 {
-        if (SAVE) {
-            const float* p = a.sv_gates + (((size_t)(rowtile * a.T + t) * SL + L0) * (16 * NT) + gslot) * 64 + l32 + 4 * r;
-            return f32x4{p[0], p[64], p[128], p[192]};
-        } else if (a.pre_t) {
-            const float* p = a.pre_t + (size_t)(2 * gslot + (l32 >> 5)) * a.pre_stride + row[r] + (size_t)t * a.pre_tstride;
-            const size_t st = 2 * (size_t)a.pre_stride;
-            return f32x4{p[0], p[st], p[2 * st], p[3 * st]};
-        }
-        const float* p = a.pre_g + ((size_t)(rowtile * a.T + t) * (16 * NT) + gslot) * 64 + l32 + 4 * r;
-        return f32x4{p[0], p[64], p[128], p[192]};
+        const unsigned so = (unsigned)t * pstep;
+        return f32x4{bload1(prs, pvo[r], so), bload1(prs, pvo[r], so + pgate), bload1(prs, pvo[r], so + 2 * pgate),
+                     bload1(prs, pvo[r], so + 3 * pgate)};
     };
     f32x4 pre[R];
     float c[R], h[R];
     const bool has_state = a.din.state_in != nullptr;              // wave-uniform
     float* const hcol = smem + j * HPAD;                           // this lane's day: tile r, buffer p at (p * R + r) * 4 HPAD
+    const int uw = uok ? u0 : HPAD - 1;                            // where this lane's h goes (no unit: a pad float nothing reads)
+    static_assert(HP < HPAD, "a pad float per day for the lanes without a unit");
 #pragma unroll
     for (int r = 0; r < R; ++r) {
         pre[r] = load_pre(r, 0);
@@ -2365,10 +2387,9 @@ __device__ __forceinline__ void lstm_rec4_body(const LstmSeqArgs& a) {
             h[r] = ps[0];
             c[r] = ps[HP];
         }
-        if (uok) hcol[(size_t)r * (4 * HPAD) + u0] = h[r];
+        hcol[(size_t)r * (4 * HPAD) + uw] = h[r];
     }
     __syncthreads();
-    const int t_outs = a.T - a.t_out0;
     // per tile ONE chain in ascending k: the matrix pipe accumulates a product at a time in k order whatever the
     // tile shape, so this is bit for bit what lstm_kernel / lstm_rec16_kernel compute; the R chains (and the two
     // waves of a SIMD) fill each other's issue gaps
@@ -2423,10 +2444,8 @@ __device__ __forceinline__ void lstm_rec4_body(const LstmSeqArgs& a) {
         REC_STAMP(0);
 #pragma unroll
         for (int r = 0; r < R; ++r) acc[r] = pre[r];
-        if (t + 1 < a.T) {
 #pragma unroll
-            for (int r = 0; r < R; ++r) pre[r] = load_pre(r, t + 1);   // lands while the products run
-        }
+        for (int r = 0; r < R; ++r) pre[r] = load_pre(r, t + 1 < a.T ? t + 1 : t);   // lands while the products run
         if ((t > 0 || has_state) && active) products(acc, hr);
         REC_STAMP(1);
 #pragma unroll
@@ -2437,24 +2456,26 @@ __device__ __forceinline__ void lstm_rec4_body(const LstmSeqArgs& a) {
             const float og = fast_sigmoid(acc[r][3]);
             c[r] = __builtin_fmaf(fg, c[r], ig * gg);
             h[r] = og * fast_tanh(c[r]);
-            if (uok) {
-                hw[(size_t)r * (4 * HPAD) + u0] = h[r];
-                if (SAVE) {
-                    // activated gates, cell and hidden state of the step, where the backward kernels read them
-                    const size_t il = (size_t)(rowtile * a.T + t) * SL + L0;
-                    float* sg = a.sv_gates + (il * (16 * NT) + gslot) * 64 + l32 + 4 * r;
-                    sg[0] = ig; sg[64] = fg; sg[128] = gg; sg[192] = og;
-                    a.sv_c[(il * HPK + hslot) * 64 + l32 + 4 * r] = c[r];
-                    a.sv_h[(il * HPK + hslot) * 64 + l32 + 4 * r] = h[r];
-                    if (dropping) {
-                        float fct[4];
-                        dropout_factors(drop, (uint32_t)row[r], (uint32_t)t, u >> 3, u & 1, L0, fct);
-                        a.sv_hd[((size_t)(rowtile * a.T + t) * HPK + hslot) * 64 + l32 + 4 * r] = h[r] * fct[(u & 7) >> 1];
-                    }
+            hw[(size_t)r * (4 * HPAD) + uw] = h[r];
+            if (SAVE) {
+                // activated gates, cell and hidden state of the step, where the backward kernels read them (sv_gates:
+                // the slots the pre-activations were read from)
+                const unsigned so = (unsigned)t * pstep, po = pvo[r] | nouse;
+                bstore1(prs, ig, po, so);
+                bstore1(prs, fg, po, so + 256u);
+                bstore1(prs, gg, po, so + 512u);
+                bstore1(prs, og, po, so + 768u);
+                const unsigned sc = (unsigned)t * (unsigned)(SL * HPK * 256);
+                bstore1(svc, c[r], hvo[r], sc);
+                bstore1(svh, h[r], hvo[r], sc);
+                if (dropping) {
+                    float fct[4];
+                    dropout_factors(drop, (uint32_t)row[r], (uint32_t)t, u >> 3, u & 1, L0, fct);
+                    bstore1(svd, h[r] * fct[(u & 7) >> 1], hvo[r], (unsigned)t * (unsigned)(HPK * 256));
                 }
-                if (a.hout && t >= a.t_out0)                       // (padding rows too: the next stage reads whole tiles)
-                    a.hout[((size_t)(rowtile * t_outs + (t - a.t_out0)) * HPK + hslot) * 64 + l32 + 4 * r] = h[r];
             }
+            // (padding rows too: the next stage reads whole tiles)
+            bstore1(hrs, h[r], hvo[r] | (t >= a.t_out0 ? 0u : 0x80000000u), (unsigned)(t - a.t_out0) * (unsigned)(HPK * 256));
         }
         REC_STAMP(2);
         __syncthreads();                                           // h(t) published (the other buffer is free again)
@@ -4878,18 +4899,23 @@ static bool lstm_rec16_applies(const LstmSeqArgs& a, int NL) {
     return a.pre_t != nullptr || a.pre_g != nullptr;
 }
 
+// lstm_rec16_kernel / lstm_rec4_kernel address a row tile's part of every array with 32-bit byte offsets
+static int rec_spans_fit(const LstmSeqArgs& a, int NT) {
+    const size_t sl = a.sv_gates && a.sv_nl > 0 ? (size_t)a.sv_nl : 1;
+    const bool fits = a.pre_t && !a.sv_gates
+        ? ((size_t)(32 * NT + 8) * (size_t)a.pre_stride + (size_t)a.n_rows + (size_t)a.T * (size_t)a.pre_tstride) * 4 < (1ull << 31)
+        : (size_t)a.T * sl * (16 * NT) * 256 < (1ull << 31);
+    if (!fits || (size_t)a.T * (4 * NT) * 256 >= (1ull << 31)) {
+        set_error("recurrent launch: a row tile's part of an array spans more than 31-bit offsets reach");
+        return -4;
+    }
+    return 0;
+}
+
 template <int NT>
 static int launch_lstm_rec16(const LstmSeqArgs& a, hipStream_t st) {
     const size_t lds = (size_t)2 * (2 * NT + 1) * 64 * sizeof(float);
-    // (the kernel addresses a row tile's part of every array with 32-bit byte offsets)
-    const size_t sl = a.sv_gates && a.sv_nl > 0 ? (size_t)a.sv_nl : 1;
-    const bool fits = a.pre_t && !a.sv_gates
-        ? ((size_t)(32 * NT + 8) * (size_t)a.pre_stride + (size_t)a.n_rows + (size_t)a.T * (size_t)a.pre_tstride) * 4 < (1ull << 32)
-        : (size_t)a.T * sl * (16 * NT) * 256 < (1ull << 32);
-    if (!fits || (size_t)a.T * (4 * NT) * 256 >= (1ull << 31)) {
-        set_error("lstm_rec16_kernel: a row tile's part of an array spans more than 32-bit offsets reach");
-        return -4;
-    }
+    if (int rc = rec_spans_fit(a, NT)) return rc;
     // (two 16-row tiles per 32-row tile: the odd one of a ragged tail runs on clamped rows, so that the tile-B
     // outputs the next stage reads are written whole)
     if (a.sv_gates) hipLaunchKernelGGL((lstm_rec16_kernel<NT, true>), dim3((unsigned)(2 * a.n_rowtiles)), dim3(512), lds, st, a);
@@ -4903,6 +4929,7 @@ static int launch_lstm_rec16(const LstmSeqArgs& a, hipStream_t st) {
 template <int NT, bool SAVE, int R>
 static int launch_lstm_rec4_r(const LstmSeqArgs& a, hipStream_t st) {
     const size_t lds = (size_t)2 * R * 4 * 144 * sizeof(float);
+    if (int rc = rec_spans_fit(a, NT)) return rc;
     hipLaunchKernelGGL((lstm_rec4_kernel<NT, SAVE, R>), dim3((unsigned)(8 * a.n_rowtiles / R)), dim3(512), lds, st, a);
     return launch_check("lstm_rec4_kernel");
 }
@@ -6358,6 +6385,8 @@ extern "C" int vsv_train_encode_pair(const vsv_dims* dims, const float* packed,
         hipLaunchKernelGGL(lstm_pre_pair_kernel<13>, dim3(grid, 2), dim3(64 * 13), 0, st, pre[0], pre[1]);
         if (int rc = launch_check("lstm_pre_pair_kernel")) return rc;
         const size_t lds = (size_t)2 * 1 * 4 * 144 * sizeof(float);
+        for (int k = 0; k < 2; ++k)
+            if (int rc = rec_spans_fit(r[k], 13)) return rc;
         hipLaunchKernelGGL((lstm_rec4_pair_kernel<13, true, 1>), dim3((unsigned)(8 * rt), 2), dim3(512), lds, st, r[0], r[1]);
         if (int rc = launch_check("lstm_rec4_pair_kernel")) return rc;
     }

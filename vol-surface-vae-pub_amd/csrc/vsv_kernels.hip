@@ -1907,11 +1907,13 @@ __global__ void __launch_bounds__(64 * NT, (NT + 3) / 4) lstm_rec_kernel(const L
 //     where the cell of gate tile j left h': h goes through LDS as [k-step][lane], no transposition;
 //   * 8 waves per workgroup, wave w owns gate tiles w, w+8, w+16, w+24; its W_hh fragments (one register per tile and
 //     k-step: 4 x 32 = 128 at hidden 128) are gathered ONCE from the blob's 32x32x2 section and stay in registers for
-//     all T steps; h is double-buffered in LDS, one barrier per step; the next step's pre-activations are fetched
-//     while the products run.
+//     all T steps; h is double-buffered in LDS; the next step's pre-activations are fetched while the products run;
+//   * a step runs in two halves with a barrier each, so that cells and barrier waits have products beside them (see
+//     the comment at `run` below and DESIGN.md, "Date-range prefix, 2.50 -> 2.20 ms").
 // Reads and writes the 32-row formats of the other kernels (pre_t / pre_g, hout in tile-B, state and gate arrays).
-// The products are summed four k at a time instead of two: results agree with lstm_kernel's to rounding, not bit
-// for bit.
+// Every gate sum takes its k-steps in ascending order on one accumulator chain, which the matrix pipe adds one
+// product at a time whatever the instruction's shape: bit for bit the sums of lstm_kernel and lstm_rec4_kernel
+// (tests/test_gpu_parity.py::test_segmented_context_prefix_equals_single_launches and its neighbours hold it).
 // ---------------------------------------------------------------------------
 #ifndef VSV_REC16_IA13
 #define VSV_REC16_IA13 1

@@ -224,7 +224,11 @@ int vsv_decode_prefix_layer1(const vsv_dims *dims, const float *packed, const st
  * (n_streams = 6: one per stage; 4: the two encoders' same-layer stages share a stream -- HIP's default number of
  * hardware queues) and ordered by HIP events; the work is forked from `stream` and joined back into it.
  * Creates and destroys HIP events (host objects); no device memory is allocated.  Results are bit-equal to the
- * fused launches for any n_seg.  Two-layer memories, at most 8192 days per call. */
+ * fused launches for any n_seg.  Two-layer memories, at most 8192 days per call.
+ * Beyond 2048 days (where the stages run on 16-row tiles) the encoders' heads and the decoder's input assembly are
+ * not launches of their own: the heads ride inside the encoders' layer-1 recurrent launches and the decoder's
+ * layer-0 stage reads their outputs where those launches leave them (same numbers bit for bit; VSV_PREFIX_FUSE=0
+ * keeps the separate launches). */
 size_t vsv_context_prefix_ws_bytes(const vsv_dims *dims, long n_days, int ctx_len, int n_seg);
 int vsv_context_prefix(const vsv_dims *dims, const float *packed, const float *vol, const float *ex, long n_days,
                        int ctx_len, int n_seg, void *const *streams, int n_streams,

@@ -45,7 +45,7 @@
 extern "C" {
 #endif
 
-#define VSV_ABI_VERSION 22
+#define VSV_ABI_VERSION 23
 #define VSV_MAX_CONV 4
 #define VSV_MAX_CHAIN 8
 #define VSV_MAX_INTERACT 3
@@ -519,6 +519,14 @@ typedef struct vsv_loss {
     const float *weights_dev;               /* optional DEVICE pair {ex_weight, kl_weight} read by the kernel in place of
                                              * the two fields above: a captured graph follows a KL-annealing schedule
                                              * (kl_weight changed between steps) without being captured again */
+    /* optional: the five numbers a step reports -- loss, re_surface, re_ex_feats, reconstruction_loss, kl_loss -- as
+     * loss_vec (5 doubles) = mix (DEVICE 5 x 3 doubles, row-major) . sums, written by the LAST workgroup to finish,
+     * which then puts sums and *ticket back to zero: sums and ticket (one unsigned) must be zero before the first call
+     * and are zero again after every call (no fill and no matrix-vector launch per step); one call at a time per
+     * (sums, ticket) pair.  All three NULL: sums is only accumulated into, as before. */
+    const double *mix;
+    double *loss_vec;
+    unsigned *ticket;
 } vsv_loss;
 int vsv_loss_grad(const vsv_loss *d, void *stream);
 

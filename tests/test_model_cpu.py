@@ -95,7 +95,7 @@ def test_library_exports_every_declared_symbol():
     L = vlib.load()
     for name in declared:
         assert hasattr(L, name), name
-    assert L.vsv_abi_version() == 22
+    assert L.vsv_abi_version() == 23
     # argument validation happens before any GPU work
     d = vlib.make_dims(5, 0, 100, 2, [5, 5, 5], [5, 5, 5], 3)
     assert L.vsv_packed_floats(C.byref(d)) > 0

@@ -4463,6 +4463,23 @@ __global__ void __launch_bounds__(256) loss_grad_kernel(const LossArgs a) {
         __syncthreads();
     }
     if (tid < 3) atomicAdd(&a.sums[tid], red[tid][0]);
+    if (a.loss_vec) {
+        // the last workgroup to finish mixes the three sums into the five numbers a step reports and leaves sums and
+        // the ticket at zero for the next call (vsv_loss::mix)
+        __shared__ unsigned last;
+        __threadfence();
+        __syncthreads();
+        if (tid == 0) last = atomicAdd(a.ticket, 1u) == gridDim.x - 1 ? 1u : 0u;
+        __syncthreads();
+        if (last && tid == 0) {
+            __threadfence();
+            const double s0 = atomicAdd(&a.sums[0], 0.0), s1 = atomicAdd(&a.sums[1], 0.0), s2 = atomicAdd(&a.sums[2], 0.0);
+            for (int r = 0; r < 5; ++r) a.loss_vec[r] = a.mix[3 * r + 0] * s0 + a.mix[3 * r + 1] * s1 + a.mix[3 * r + 2] * s2;
+            a.sums[0] = 0.0; a.sums[1] = 0.0; a.sums[2] = 0.0;
+            __threadfence();
+            atomicExch(a.ticket, 0u);
+        }
+    }
 }
 
 // ---------------------------------------------------------------------------
@@ -7028,6 +7045,9 @@ extern "C" int vsv_loss_grad(const vsv_loss* d, void* stream) {
     if (d->Hs != 0 && d->Hs < d->H) { set_error("vsv_loss_grad: Hs < H"); return -1; }
     if (d->surf_l2 && d->Q != 1) { set_error("vsv_loss_grad: the MSE surface loss is the one-channel decoder's (Q = 1)"); return -1; }
     if (d->ex_pred && (!d->ex_target || !d->d_ex || d->X < 1 || d->ex_n < 1 || d->ex_n > d->X)) { set_error("vsv_loss_grad: bad ex arguments"); return -1; }
+    if ((d->loss_vec != nullptr) != (d->mix != nullptr) || (d->loss_vec != nullptr) != (d->ticket != nullptr)) {
+        set_error("vsv_loss_grad: mix, loss_vec and ticket go together"); return -1;
+    }
     hipLaunchKernelGGL(loss_grad_kernel, dim3(64), dim3(256), 0, (hipStream_t)stream, *d);
     return launch_check("loss_grad_kernel");
 }

@@ -128,7 +128,7 @@ class VsvLoss(C.Structure):
                 ("zm", C.c_void_p), ("zl", C.c_void_p), ("L", C.c_int),
                 ("d_pred", C.c_void_p), ("d_ex", C.c_void_p), ("d_zm", C.c_void_p), ("d_zl", C.c_void_p),
                 ("sums", C.c_void_p), ("Hs", C.c_int), ("grad_scale", C.c_float), ("surf_l2", C.c_int),
-                ("weights_dev", C.c_void_p)]
+                ("weights_dev", C.c_void_p), ("mix", C.c_void_p), ("loss_vec", C.c_void_p), ("ticket", C.c_void_p)]
 
 
 # name -> (restype, argtypes); the full list of symbols include/vsv_hip.h declares
@@ -243,7 +243,7 @@ def load() -> C.CDLL:
             fn = getattr(lib, name)
             fn.restype = res
             fn.argtypes = args
-        if lib.vsv_abi_version() != 22:
+        if lib.vsv_abi_version() != 23:
             raise RuntimeError("libvsv_hip.so ABI version mismatch")
         _lib = lib
     return _lib

@@ -736,10 +736,30 @@ class TrainEngine:
                 la.weights_dev = wdev.data_ptr()
             la.zm, la.zl, la.L = zm.data_ptr(), zl.data_ptr(), L
             la.d_pred, la.d_zm, la.d_zl = d_pred.data_ptr(), d_zm.data_ptr(), d_zl.data_ptr()
-            sums = torch.zeros(3, dtype=torch.float64, device=dev)
+            # loss = re_surface + ex_weight * re_ex_feats + kl_weight * kl etc.: five numbers = a 5 x 3 matrix times the
+            # kernel's three sums.  Without a custom KL term the kernel's last workgroup does it (vsv_loss.mix) and puts
+            # its accumulators back to zero: no fill and no matrix-vector launch per step.
+            exw = float(loss_cfg["ex_weight"]) if X > 0 else 0.0
+            M = loss_cfg.get("mix_dev")
+            if M is None:
+                M = self.__dict__.setdefault("_loss_mix", {}).get((exw, klw))
+            if M is None:
+                M = self._loss_mix[(exw, klw)] = torch.tensor([[1.0, exw, klw], [1.0, 0.0, 0.0], [0.0, 1.0, 0.0],
+                                                               [1.0, exw, 0.0], [0.0, 0.0, 1.0]], dtype=torch.float64, device=dev)
+            in_kernel = kl_fn is None
+            if in_kernel:
+                acc = self.__dict__.get("_loss_acc")
+                if acc is None:          # (zero before the first call, zero again after every call)
+                    acc = self._loss_acc = (torch.zeros(3, dtype=torch.float64, device=dev),
+                                            torch.zeros(1, dtype=torch.int32, device=dev))
+                sums = acc[0]
+                v = torch.empty(5, dtype=torch.float64, device=dev)
+                la.mix, la.loss_vec, la.ticket = M.data_ptr(), v.data_ptr(), acc[1].data_ptr()
+            else:
+                sums = torch.zeros(3, dtype=torch.float64, device=dev)
             la.sums = sums.data_ptr()
             _lib.check(lib.vsv_loss_grad(C.byref(la), st), "vsv_loss_grad")
-            kl = sums[2]
+            kl = None if in_kernel else sums[2]
             if extra_d_pred is not None:
                 d_pred = d_pred + extra_d_pred.to(dev, torch.float32).reshape(B, horizon, Q * 25)
             if kl_fn is not None:
@@ -747,18 +767,8 @@ class TrainEngine:
                 kl = kl.to(torch.float64)
                 d_zm = d_zm + g_zm
                 d_zl = d_zl + g_zl
-            # loss = re_surface + ex_weight * re_ex_feats + kl_weight * kl etc. as ONE small matrix-vector product
-            exw = float(loss_cfg["ex_weight"]) if X > 0 else 0.0
-            key = (exw, klw)
-            M = loss_cfg.get("mix_dev")
-            if M is None:
-                M = self.__dict__.setdefault("_loss_mix", {}).get(key)
-            if M is None:
-                M = self._loss_mix[key] = torch.tensor([[1.0, exw, klw], [1.0, 0.0, 0.0], [0.0, 1.0, 0.0],
-                                                        [1.0, exw, 0.0], [0.0, 0.0, 1.0]], dtype=torch.float64, device=dev)
             if kl_fn is not None:
-                sums = torch.stack([sums[0], sums[1], kl])
-            v = torch.mv(M, sums)
+                v = torch.mv(M, torch.stack([sums[0], sums[1], kl]))
             losses = {"loss": v[0], "re_surface": v[1], "re_ex_feats": v[2], "reconstruction_loss": v[3], "kl_loss": v[4]}
             outputs["loss_vec"] = v                               # (the five numbers above as one float64 vector)
             if not want_grads:
